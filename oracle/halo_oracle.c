@@ -1,0 +1,563 @@
+/* TEST INFRASTRUCTURE -- not part of the product.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call this file.
+ *
+ * CPU restatement (plain C, optional OpenMP) of the reference's per-pixel
+ * hyperbolic acquisition-scoring path.  Reference = paolomandica/HALO, pure
+ * Python; every function cites the reference lines it follows.  The geoopt
+ * formulas (expmap0/project/logmap0/dist0/dist) are restated from geoopt's
+ * published stereographic/math.py -- geoopt is an un-pinned, un-vendored
+ * dependency of the reference (requirements.txt:13), so that layer is
+ * "parity unpinned"; everything in-tree is pinned by the .npz files under tests/golden, which
+ * were produced by running the reference's own code (tests/golden/make_fixtures.py).
+ *
+ * Layout convention: tensors are dense row-major exactly as the reference holds
+ * them: logit (O,H,W) f32, decoder_out (C,H,W) f64 or f32, maps (H,W).
+ *
+ * Numeric contract (shared with the HIP kernels): per-pixel sums run
+ * sequentially over the channel / class index with explicit fma; exp/log come
+ * from halo_oracle_math.h; sqrt and division are IEEE.  Compile with
+ * -ffp-contract=off.
+ */
+#include "halo_oracle_math.h"
+#include <stdlib.h>
+
+typedef long long i64;
+typedef unsigned char u8;
+
+enum { HALO_UNC_ENTROPY = 0, HALO_UNC_PIXEL_ENTROPY = 1, HALO_UNC_ORACLE_ACC = 2, HALO_UNC_ZEROS = 3 };
+enum { HALO_PUR_RIPU = 0, HALO_PUR_ORACLE_RIPU = 1, HALO_PUR_HYPER = 2, HALO_PUR_NONE = 3,
+       HALO_PUR_RADIUS = 4, HALO_PUR_EUC_NORM = 5 };
+enum { HALO_F32 = 0, HALO_F64 = 1 };
+
+/* ---- exported math probes (so tests can pin the elementary functions) ---- */
+float halo_o_expf(float x) { return ho_expf(x); }
+float halo_o_logf(float x) { return ho_logf(x); }
+double halo_o_log(double x) { return ho_log(x); }
+
+/* sabs(k)**0.5 with k = -c  (geoopt sabs: |x| + 1e-15) */
+static double k_sqrt(double c) { return sqrt(fabs(-c) + 1e-15); }
+
+/* geoopt artanh: clamp to +-(1-1e-7), 0.5*(log(1+z) - log(1-z)) in float64 */
+static double artanh_clamped(double z)
+{
+    const double lim = 1.0 - 1e-7;
+    if (z > lim) z = lim;
+    if (z < -lim) z = -lim;
+    return (ho_log(1.0 + z) - ho_log(1.0 - z)) * 0.5;
+}
+
+/* sum of squares over a strided vector, sequential fma chain in float64 */
+static double ssq_f64(const double *x, i64 n, i64 stride)
+{
+    double a = 0.0;
+    for (i64 i = 0; i < n; ++i) { double v = x[i * stride]; a = fma(v, v, a); }
+    return a;
+}
+/* x.double() first (hyperbolic.py:37), then the float64 chain */
+static double ssq_f32_as_f64(const float *x, i64 n, i64 stride)
+{
+    double a = 0.0;
+    for (i64 i = 0; i < n; ++i) { double v = (double)x[i * stride]; a = fma(v, v, a); }
+    return a;
+}
+/* float32 tensor reduced in float32 (x.norm on a float32 decoder_out): fmaf chain.
+ * Both chains reproduce ATen's CPU norm over dim=1 bit for bit on FMA hosts
+ * (checked against torch 2.10 in the build container). */
+static float ssq_f32(const float *x, i64 n, i64 stride)
+{
+    float a = 0.0f;
+    for (i64 i = 0; i < n; ++i) { float v = x[i * stride]; a = fmaf(v, v, a); }
+    return a;
+}
+
+/* ------------------------------------------------------------------------- *
+ * HyperMapper.expmap (core/utils/hyperbolic.py:28-39):
+ *   expmap0(x.double(), k=-c, dim) then project(.., k=-c, dim), eps=1e-5 (f64).
+ * x viewed as (outer, C, inner), reduction over C.  in_dtype: HALO_F32/HALO_F64.
+ * ------------------------------------------------------------------------- */
+void halo_o_expmap0_project(const void *x, int in_dtype, double *y, i64 outer, i64 C, i64 inner, double c)
+{
+    const double ks = k_sqrt(c), rks = 1.0 / ks;
+    const double maxnorm = (1.0 - 1e-5) / sqrt(fabs(-c) + 1e-15);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 o = 0; o < outer; ++o)
+        for (i64 i = 0; i < inner; ++i) {
+            const i64 base = o * C * inner + i;
+            double n = in_dtype == HALO_F64 ? sqrt(ssq_f64((const double *)x + base, C, inner))
+                                            : sqrt(ssq_f32_as_f64((const float *)x + base, C, inner));
+            if (n < 1e-15) n = 1e-15;
+            double a = n * ks;
+            if (a > 15.0) a = 15.0;
+            if (a < -15.0) a = -15.0;
+            const double g = rks * tanh(a);
+            double s2 = 0.0;
+            for (i64 ch = 0; ch < C; ++ch) {
+                double u = in_dtype == HALO_F64 ? ((const double *)x)[base + ch * inner]
+                                                : (double)((const float *)x)[base + ch * inner];
+                double v = g * (u / n);
+                y[base + ch * inner] = v;
+                s2 = fma(v, v, s2);
+            }
+            double ny = sqrt(s2);
+            if (ny < 1e-15) ny = 1e-15;
+            if (ny > maxnorm)
+                for (i64 ch = 0; ch < C; ++ch) y[base + ch * inner] = y[base + ch * inner] / ny * maxnorm;
+        }
+}
+
+/* HyperMapper.logmap (hyperbolic.py:51-60): project(logmap0(x.double())), last dim => inner=1 */
+void halo_o_logmap0_project(const double *x, double *y, i64 outer, i64 C, i64 inner, double c)
+{
+    const double ks = k_sqrt(c), rks = 1.0 / ks;
+    const double maxnorm = (1.0 - 1e-5) / sqrt(fabs(-c) + 1e-15);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 o = 0; o < outer; ++o)
+        for (i64 i = 0; i < inner; ++i) {
+            const i64 base = o * C * inner + i;
+            double n = sqrt(ssq_f64(x + base, C, inner));
+            if (n < 1e-15) n = 1e-15;
+            const double g = rks * artanh_clamped(n * ks);
+            double s2 = 0.0;
+            for (i64 ch = 0; ch < C; ++ch) {
+                double v = (x[base + ch * inner] / n) * g;
+                y[base + ch * inner] = v;
+                s2 = fma(v, v, s2);
+            }
+            double ny = sqrt(s2);
+            if (ny < 1e-15) ny = 1e-15;
+            if (ny > maxnorm)
+                for (i64 ch = 0; ch < C; ++ch) y[base + ch * inner] = y[base + ch * inner] / ny * maxnorm;
+        }
+}
+
+/* radius of one pixel: geoopt dist0 = 2 * artan_k(||x||) (hyperbolic.py:74-83) */
+static double dist0_from_ssq_f64(double ssq, double ks, double rks)
+{
+    return 2.0 * (rks * artanh_clamped(sqrt(ssq) * ks));
+}
+/* float32 input: norm, scaling and clamp happen in float32, the logs in float64 */
+static float dist0_from_ssq_f32(float ssq, double ks, double rks)
+{
+    float n = sqrtf(ssq);
+    float z = n * (float)ks;
+    const float lim = (float)(1.0 - 1e-7);
+    if (z > lim) z = lim;
+    if (z < -lim) z = -lim;
+    double zd = (double)z;
+    float a = (float)((ho_log(1.0 + zd) - ho_log(1.0 - zd)) * 0.5);
+    return 2.0f * ((float)rks * a);
+}
+
+/* HyperMapper.poincare_distance_origin (hyperbolic.py:74-83); out dtype = in dtype */
+void halo_o_dist0(const void *x, int dtype, void *out, i64 outer, i64 C, i64 inner, double c)
+{
+    const double ks = k_sqrt(c), rks = 1.0 / ks;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 o = 0; o < outer; ++o)
+        for (i64 i = 0; i < inner; ++i) {
+            const i64 base = o * C * inner + i;
+            if (dtype == HALO_F64)
+                ((double *)out)[o * inner + i] = dist0_from_ssq_f64(ssq_f64((const double *)x + base, C, inner), ks, rks);
+            else
+                ((float *)out)[o * inner + i] = dist0_from_ssq_f32(ssq_f32((const float *)x + base, C, inner), ks, rks);
+        }
+}
+
+/* HyperMapper.poincare_distance (hyperbolic.py:62-72): geoopt dist over the last dim, f64 */
+void halo_o_dist(const double *x, const double *y, double *out, i64 n, i64 d, double c)
+{
+    const double k = -c, ks = k_sqrt(c), rks = 1.0 / ks;
+#pragma omp parallel for schedule(static)
+    for (i64 r = 0; r < n; ++r) {
+        const double *a = x + r * d, *b = y + r * d;
+        double x2 = 0, y2 = 0, xy = 0;
+        for (i64 j = 0; j < d; ++j) {
+            double u = -a[j], v = b[j];
+            x2 = fma(u, u, x2); y2 = fma(v, v, y2); xy = fma(u, v, xy);
+        }
+        const double ca = 1.0 - 2.0 * k * xy - k * y2, cb = 1.0 + k * x2;
+        double den = 1.0 - 2.0 * k * xy + k * k * x2 * y2;
+        if (den < 1e-15) den = 1e-15;
+        double s2 = 0;
+        for (i64 j = 0; j < d; ++j) {
+            double m = (ca * (-a[j]) + cb * b[j]) / den;
+            s2 = fma(m, m, s2);
+        }
+        out[r] = 2.0 * (rks * artanh_clamped(sqrt(s2) * ks));
+    }
+}
+
+/* ------------------------------------------------------------------------- *
+ * HyperMLR._hyper_logits (hyperbolic.py:120-184).  x (B,C,hw) f64, P/A (O,C) f64,
+ * out (B,O,hw) f64.
+ * ------------------------------------------------------------------------- */
+void halo_o_hypermlr(const double *x, const double *P, const double *A, double *out,
+                     i64 B, i64 C, i64 O, i64 hw, double c)
+{
+    const double K = c, sqK = sqrt(K);
+    const double maxnorm = (1.0 - 1e-3) / sqK;
+    double *pp = (double *)malloc(sizeof(double) * O), *anorm = (double *)malloc(sizeof(double) * O);
+    double *pa = (double *)malloc(sizeof(double) * O), *An = (double *)malloc(sizeof(double) * O * C);
+    for (i64 o = 0; o < O; ++o) {
+        double sp = 0, sa = 0;
+        for (i64 j = 0; j < C; ++j) { sp = fma(P[o * C + j], P[o * C + j], sp); sa = fma(A[o * C + j], A[o * C + j], sa); }
+        double np_ = sqrt(sp); pp[o] = np_ * np_;                 /* torch.norm(-P)**2, :137 */
+        anorm[o] = sqrt(sa);                                       /* :172 */
+        double dn = anorm[o] < 1e-12 ? 1e-12 : anorm[o];           /* F.normalize eps, :173 */
+        double s = 0;
+        for (i64 j = 0; j < C; ++j) { An[o * C + j] = A[o * C + j] / dn; s = fma(-P[o * C + j], An[o * C + j], s); }
+        pa[o] = s;                                                 /* sum(-P * normed_A), :176 */
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 b = 0; b < B; ++b)
+        for (i64 i = 0; i < hw; ++i) {
+            const double *xb = x + b * C * hw + i;
+            double nx = sqrt(ssq_f64(xb, C, hw));
+            const double xx = nx * nx;                             /* torch.norm(x,dim=1)**2, :136 */
+            for (i64 o = 0; o < O; ++o) {
+                double px = 0, xa = 0;
+                for (i64 j = 0; j < C; ++j) { px = fma(xb[j * hw], -P[o * C + j], px); xa = fma(xb[j * hw], An[o * C + j], xa); }
+                const double sqsq = ((K * xx) * K) * pp[o];        /* :146 */
+                const double Aa = (1.0 + (2.0 * K) * px) + K * xx; /* :150 */
+                const double Bb = 1.0 - K * pp[o];                 /* :151 */
+                double D = (1.0 + (2.0 * K) * px) + sqsq;          /* :152 */
+                if (!(D >= 1e-12)) D = D != D ? D : 1e-12;         /* torch.max(D, 1e-12), :153 */
+                const double al = Aa / D, be = Bb / D;
+                const double mob = ((al * al) * pp[o] + (be * be) * xx) + ((2.0 * al) * be) * px; /* :159 */
+                const double sq = sqrt(mob);
+                double sqc = sq;
+                if (!(sqc >= 1e-12)) sqc = sqc != sqc ? sqc : 1e-12;
+                const double pn = sq > maxnorm ? maxnorm / sqc : 1.0;          /* :163-166 */
+                const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;       /* :167-170 */
+                double md = (be * xa + al * pa[o]) * pn;                        /* :175-178 */
+                double lden = 1.0 - K * mp;
+                if (!(lden >= 1e-12)) lden = lden != lden ? lden : 1e-12;
+                const double lamb = 2.0 / lden;                                 /* :179 */
+                const double sine = (sqK * md) * lamb;                          /* :180 */
+                out[(b * O + o) * hw + i] = ((2.0 / sqK) * anorm[o]) * asinh(sine); /* :182-183 */
+            }
+        }
+    free(pp); free(anorm); free(pa); free(An);
+}
+
+/* ------------------------------------------------------------------------- *
+ * F.interpolate(mode="bilinear", align_corners=True)  (build.py:123-125,133-135;
+ * classifier.py:375-377,556-557).  planes x (h,w) -> planes x (H,W).
+ * Source index = dst * (in-1)/(out-1) evaluated in the tensor's own dtype; the four
+ * taps are combined as  fma(v11,w11, fma(v10,w10, fma(v00,w00, v01*w01))),  w_ij = ly_i*lx_j.
+ * That is bit-for-bit what ATen's generic CPU kernel produces for some shapes/thread
+ * counts (e.g. C<=3, one thread) -- ATen itself rounds differently from shape to shape
+ * and thread count to thread count (DESIGN.md "What 'exact' can mean"), so 1-ulp
+ * agreement is the only well-defined target here.
+ * ------------------------------------------------------------------------- */
+void halo_o_bilinear_f64(const double *src, double *dst, i64 planes, i64 h, i64 w, i64 H, i64 W)
+{
+    const double sh = H > 1 ? (double)(h - 1) / (double)(H - 1) : 0.0;
+    const double sw = W > 1 ? (double)(w - 1) / (double)(W - 1) : 0.0;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 p = 0; p < planes; ++p)
+        for (i64 y = 0; y < H; ++y) {
+            const double fy = sh * (double)y;
+            i64 y0 = (i64)fy; if (y0 > h - 1) y0 = h - 1;
+            const i64 y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const double ly1 = fy - (double)y0, ly0 = 1.0 - ly1;
+            const double *r0 = src + (p * h + y0) * w, *r1 = src + (p * h + y1) * w;
+            for (i64 x = 0; x < W; ++x) {
+                const double fx = sw * (double)x;
+                i64 x0 = (i64)fx; if (x0 > w - 1) x0 = w - 1;
+                const i64 x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const double lx1 = fx - (double)x0, lx0 = 1.0 - lx1;
+                double a = r0[x1] * (ly0 * lx1);
+                a = fma(r0[x0], ly0 * lx0, a);
+                a = fma(r1[x0], ly1 * lx0, a);
+                dst[(p * H + y) * W + x] = fma(r1[x1], ly1 * lx1, a);
+            }
+        }
+}
+void halo_o_bilinear_f32(const float *src, float *dst, i64 planes, i64 h, i64 w, i64 H, i64 W)
+{
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 p = 0; p < planes; ++p)
+        for (i64 y = 0; y < H; ++y) {
+            const float fy = sh * (float)y;
+            i64 y0 = (i64)fy; if (y0 > h - 1) y0 = h - 1;
+            const i64 y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+            const float *r0 = src + (p * h + y0) * w, *r1 = src + (p * h + y1) * w;
+            for (i64 x = 0; x < W; ++x) {
+                const float fx = sw * (float)x;
+                i64 x0 = (i64)fx; if (x0 > w - 1) x0 = w - 1;
+                const i64 x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+                float a = r0[x1] * (ly0 * lx1);
+                a = fmaf(r0[x0], ly0 * lx0, a);
+                a = fmaf(r1[x0], ly1 * lx0, a);
+                dst[(p * H + y) * W + x] = fmaf(r1[x1], ly1 * lx1, a);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------- *
+ * FloatingRegionScore.forward (core/active/floating_region.py:129-217)
+ * ------------------------------------------------------------------------- */
+
+/* softmax over O classes at pixel i (floating_region.py:152); p[] has O entries */
+static void softmax_px(const float *logit, i64 O, i64 hw, i64 i, float *p)
+{
+    float m = logit[i];
+    for (i64 c = 1; c < O; ++c) { float v = logit[c * hw + i]; if (v > m) m = v; }
+    float s = 0.0f;
+    for (i64 c = 0; c < O; ++c) { p[c] = ho_expf(logit[c * hw + i] - m); s = s + p[c]; }
+    for (i64 c = 0; c < O; ++c) p[c] = p[c] / s;
+}
+static i64 argmax_px(const float *p, i64 O)
+{
+    i64 b = 0;
+    for (i64 c = 1; c < O; ++c) if (p[c] > p[b]) b = c;
+    return b;
+}
+/* sum_c -p*log(p+1e-6) / log(19)   (floating_region.py:72-76,123-127: the 19 is hard-coded) */
+static float entropy_px(const float *p, i64 O)
+{
+    float a = 0.0f;
+    for (i64 c = 0; c < O; ++c) a = a + (-p[c]) * ho_logf(p[c] + 1e-6f);
+    return a / (float)log(19.0);
+}
+
+/* k x k all-ones conv, zero padding k/2 (floating_region.py:42-51,90): row-major tap order */
+static void box_sum_f32(const float *in, float *out, i64 H, i64 W, int k)
+{
+    const int r = k / 2;
+#pragma omp parallel for schedule(static)
+    for (i64 y = 0; y < H; ++y)
+        for (i64 x = 0; x < W; ++x) {
+            float a = 0.0f;
+            for (int dy = -r; dy <= r; ++dy)
+                for (int dx = -r; dx <= r; ++dx) {
+                    i64 yy = y + dy, xx = x + dx;
+                    float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[yy * W + xx] : 0.0f;
+                    a = a + v;
+                }
+            out[y * W + x] = a;
+        }
+}
+
+/* compute_region_impurity (floating_region.py:112-121): window class histogram -> entropy/log(K) */
+static void region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *imp, float *count)
+{
+    const int r = k / 2;
+    const float logK = (float)log((double)K);
+#pragma omp parallel
+    {
+        float *hist = (float *)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(static)
+        for (i64 y = 0; y < H; ++y)
+            for (i64 x = 0; x < W; ++x) {
+                for (i64 c = 0; c < K; ++c) hist[c] = 0.0f;
+                float cnt = 0.0f;
+                for (int dy = -r; dy <= r; ++dy)
+                    for (int dx = -r; dx <= r; ++dx) {
+                        i64 yy = y + dy, xx = x + dx;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { hist[pred[yy * W + xx]] += 1.0f; cnt += 1.0f; }
+                    }
+                float a = 0.0f;
+                for (i64 c = 0; c < K; ++c)
+                    if (hist[c] > 0.0f) { float d = hist[c] / cnt; a = a + (-d) * ho_logf(d + 1e-6f); }
+                imp[y * W + x] = a / logK;
+                count[y * W + x] = cnt;
+            }
+        free(hist);
+    }
+}
+
+/* normalize_map (floating_region.py:22-23) */
+static void normalize_f32(float *x, i64 n)
+{
+    float mn = x[0], mx = x[0];
+    int has_nan = 0;
+    for (i64 i = 0; i < n; ++i) { if (x[i] != x[i]) has_nan = 1; if (x[i] < mn) mn = x[i]; if (x[i] > mx) mx = x[i]; }
+    if (has_nan) { mn = NAN; mx = NAN; }                    /* torch min/max propagate NaN */
+    const float den = (float)((double)mx - (double)mn);
+    for (i64 i = 0; i < n; ++i) x[i] = (x[i] - mn) / den;
+}
+static void normalize_f64(double *x, i64 n)
+{
+    double mn = x[0], mx = x[0];
+    int has_nan = 0;
+    for (i64 i = 0; i < n; ++i) { if (x[i] != x[i]) has_nan = 1; if (x[i] < mn) mn = x[i]; if (x[i] > mx) mx = x[i]; }
+    if (has_nan) { mn = NAN; mx = NAN; }
+    const double den = mx - mn;
+    for (i64 i = 0; i < n; ++i) x[i] = (x[i] - mn) / den;
+}
+
+/* quantize_uncert_map (floating_region.py:94-110) on an (H,W) radius map */
+static void quantize_f64(double *r, i64 n, i64 K, i64 *pred)
+{
+    normalize_f64(r, n);
+    for (i64 i = 0; i < n; ++i) r[i] = 1.0 - r[i];
+    normalize_f64(r, n);
+    const double lo = -0.5 + 1e-5, hi = (double)K - 0.5 - 1e-5;
+    for (i64 i = 0; i < n; ++i) {
+        double p = r[i] * (double)K - 0.5;
+        if (p < lo) p = lo;
+        if (p > hi) p = hi;
+        pred[i] = (i64)rint(p);
+    }
+}
+static void quantize_f32(float *r, i64 n, i64 K, i64 *pred)
+{
+    normalize_f32(r, n);
+    for (i64 i = 0; i < n; ++i) r[i] = 1.0f - r[i];
+    normalize_f32(r, n);
+    const float lo = (float)(-0.5 + 1e-5), hi = (float)((double)K - 0.5 - 1e-5);
+    for (i64 i = 0; i < n; ++i) {
+        float p = r[i] * (float)K - 0.5f;
+        if (p < lo) p = lo;
+        if (p > hi) p = hi;
+        pred[i] = (i64)rintf(p);
+    }
+}
+
+/* The whole forward.  Outputs: score / impurity in f64 when (pur is RADIUS|EUC_NORM and
+ * feat is f64), else f32 -- the caller passes buffers of the right width and reads
+ * *score_dtype.  unc_out is always f32.  ksize = entropy conv size; pksize = purity conv
+ * size (3 when the module was built for 'hyper', floating_region.py:54-55).
+ * Returns 0, or -1 for an unknown purity type (NotImplementedError, :199-202). */
+int halo_o_floating_region_score(const float *logit, const void *feat, int feat_dtype, const i64 *gt,
+                                 i64 O, i64 C, i64 H, i64 W, int unc_type, int pur_type, int normalize,
+                                 int ksize, int pksize, i64 K, double c,
+                                 void *score, void *impurity, float *unc_out, int *score_dtype)
+{
+    const i64 hw = H * W;
+    if (pur_type < 0 || pur_type > HALO_PUR_EUC_NORM) return -1;
+    float *ent = (float *)malloc(sizeof(float) * hw);
+    float *cnt = (float *)malloc(sizeof(float) * hw);
+    i64 *pred = (i64 *)malloc(sizeof(i64) * hw);
+    const int need_argmax = pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU || unc_type == HALO_UNC_ORACLE_ACC;
+
+    /* --- uncertainty (floating_region.py:158-163, 70-92) --- */
+#pragma omp parallel
+    {
+        float *p = (float *)malloc(sizeof(float) * (size_t)O);
+#pragma omp for schedule(static)
+        for (i64 i = 0; i < hw; ++i) {
+            softmax_px(logit, O, hw, i, p);
+            i64 am = need_argmax ? argmax_px(p, O) : 0;
+            if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) ent[i] = entropy_px(p, O);
+            else if (unc_type == HALO_UNC_ORACLE_ACC) {
+                i64 g = gt[i] == 255 ? am : gt[i];
+                ent[i] = 1.0f - p[g];
+            } else ent[i] = 0.0f;
+            if (pur_type == HALO_PUR_RIPU) pred[i] = am;
+            else if (pur_type == HALO_PUR_ORACLE_RIPU) pred[i] = gt[i] == 255 ? am : gt[i];
+        }
+        free(p);
+    }
+    if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_ORACLE_ACC) box_sum_f32(ent, unc_out, H, W, ksize);
+    else for (i64 i = 0; i < hw; ++i) unc_out[i] = ent[i];   /* pixel_entropy: no conv; zeros: conv(0)=0 */
+
+    /* --- purity (floating_region.py:165-202) --- */
+    const double ks = k_sqrt(c), rks = 1.0 / ks;
+    const int f64out = (pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM) && feat_dtype == HALO_F64;
+    *score_dtype = f64out ? HALO_F64 : HALO_F32;
+    double *imp64 = (double *)impurity;
+    float *imp32 = (float *)impurity;
+    if (pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU) {
+        region_impurity(pred, O, pksize, H, W, imp32, cnt);
+    } else if (pur_type == HALO_PUR_HYPER) {
+        if (feat_dtype == HALO_F64) {
+            double *r = (double *)malloc(sizeof(double) * hw);
+#pragma omp parallel for schedule(static)
+            for (i64 i = 0; i < hw; ++i) r[i] = dist0_from_ssq_f64(ssq_f64((const double *)feat + i, C, hw), ks, rks);
+            quantize_f64(r, hw, K, pred);
+            free(r);
+        } else {
+            float *r = (float *)malloc(sizeof(float) * hw);
+#pragma omp parallel for schedule(static)
+            for (i64 i = 0; i < hw; ++i) r[i] = dist0_from_ssq_f32(ssq_f32((const float *)feat + i, C, hw), ks, rks);
+            quantize_f32(r, hw, K, pred);
+            free(r);
+        }
+        region_impurity(pred, K, pksize, H, W, imp32, cnt);
+    } else {
+#pragma omp parallel for schedule(static)
+        for (i64 i = 0; i < hw; ++i) {
+            cnt[i] = 1.0f;
+            if (pur_type == HALO_PUR_NONE) imp32[i] = 0.0f;
+            else if (feat_dtype == HALO_F64) {
+                double s = ssq_f64((const double *)feat + i, C, hw);
+                imp64[i] = pur_type == HALO_PUR_RADIUS ? dist0_from_ssq_f64(s, ks, rks) : sqrt(s);
+            } else {
+                float s = ssq_f32((const float *)feat + i, C, hw);
+                imp32[i] = pur_type == HALO_PUR_RADIUS ? dist0_from_ssq_f32(s, ks, rks) : sqrtf(s);
+            }
+        }
+    }
+    /* prediction_uncertainty = region_uncertainty / count (:204) */
+    for (i64 i = 0; i < hw; ++i) unc_out[i] = unc_out[i] / cnt[i];
+    if (normalize) {                                                   /* :206-208 */
+        normalize_f32(unc_out, hw);
+        if (f64out) normalize_f64(imp64, hw); else normalize_f32(imp32, hw);
+    }
+    /* score = region_impurity * prediction_uncertainty (:210), f64*f32 -> f64 */
+    if (f64out) for (i64 i = 0; i < hw; ++i) ((double *)score)[i] = imp64[i] * (double)unc_out[i];
+    else for (i64 i = 0; i < hw; ++i) ((float *)score)[i] = imp32[i] * unc_out[i];
+    free(ent); free(cnt); free(pred);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * select_pixels_to_label (core/active/build.py:27-64)
+ * torch.max ordering: NaN beats everything; ties keep the FIRST occurrence, so the
+ * two-stage max over dim 0 then dim 0 picks the smallest w, then the smallest h.
+ * picks (n,3) f64 rows (h, w, value) in selection order; returns the number picked.
+ * ------------------------------------------------------------------------- */
+#define BETTER(a, b) (((a) != (a)) ? !((b) != (b)) : (!((b) != (b)) && (a) > (b)))
+
+i64 halo_o_select(void *score, int dtype, i64 H, i64 W, i64 n_regions, i64 active_radius, i64 mask_radius,
+                  u8 *active, u8 *selected, i64 *active_mask, const i64 *gt, double *picks)
+{
+    double *colv = (double *)malloc(sizeof(double) * W);
+    i64 *colh = (i64 *)malloc(sizeof(i64) * W);
+    i64 np_ = 0;
+    for (i64 it = 0; it < n_regions; ++it) {
+        /* values, indices_h = torch.max(score, dim=0)   (:38) */
+#pragma omp parallel for schedule(static)
+        for (i64 x = 0; x < W; ++x) {
+            double bv = dtype == HALO_F64 ? ((double *)score)[x] : (double)((float *)score)[x];
+            i64 bh = 0;
+            for (i64 y = 1; y < H; ++y) {
+                double v = dtype == HALO_F64 ? ((double *)score)[y * W + x] : (double)((float *)score)[y * W + x];
+                if (BETTER(v, bv)) { bv = v; bh = y; }
+            }
+            colv[x] = bv; colh[x] = bh;
+        }
+        /* max_value, indices_w = torch.max(values, dim=0)   (:39) */
+        i64 w = 0;
+        for (i64 x = 1; x < W; ++x) if (BETTER(colv[x], colv[w])) w = x;
+        const double mv = colv[w];
+        if (mv == -INFINITY) break;                                   /* :40-41 */
+        const i64 h = colh[w];
+        const i64 as_w = w - active_radius >= 0 ? w - active_radius : 0, as_h = h - active_radius >= 0 ? h - active_radius : 0;
+        i64 ae_w = w + active_radius + 1, ae_h = h + active_radius + 1;
+        const i64 ms_w = w - mask_radius >= 0 ? w - mask_radius : 0, ms_h = h - mask_radius >= 0 ? h - mask_radius : 0;
+        i64 me_w = w + mask_radius + 1, me_h = h + mask_radius + 1;
+        if (ae_w > W) ae_w = W;
+        if (ae_h > H) ae_h = H;
+        if (me_w > W) me_w = W;
+        if (me_h > H) me_h = H;
+        for (i64 y = ms_h; y < me_h; ++y)
+            for (i64 x = ms_w; x < me_w; ++x) {
+                if (dtype == HALO_F64) ((double *)score)[y * W + x] = -INFINITY; else ((float *)score)[y * W + x] = -INFINITY;
+                active[y * W + x] = 1;
+            }
+        for (i64 y = as_h; y < ae_h; ++y)
+            for (i64 x = as_w; x < ae_w; ++x) { selected[y * W + x] = 1; active_mask[y * W + x] = gt[y * W + x]; }
+        picks[np_ * 3 + 0] = (double)h; picks[np_ * 3 + 1] = (double)w; picks[np_ * 3 + 2] = mv;
+        ++np_;
+    }
+    free(colv); free(colh);
+    return np_;
+}

@@ -1,0 +1,73 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# (unc_type, pur_type) behind each fixture tag written by tests/golden/make_fixtures.py
+COMBOS = {
+    "halo": ("entropy", "radius"),
+    "ripu": ("entropy", "ripu"),
+    "hyper": ("entropy", "hyper"),
+    "hyperK10": ("entropy", "hyper"),
+    "none_radius": ("none", "radius"),
+    "pixent_euc": ("pixel_entropy", "euc_norm"),
+    "oracle": ("oracle_acc", "oracle_ripu"),
+    "ent_none": ("entropy", "none"),
+    "vestigial": ("hyperbolic", "ripu"),
+}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+def case_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "case_*.npz")))
+
+
+def case_tags(d):
+    return sorted({k.split("__")[0] for k in d.files if k.endswith("__score")})
+
+
+def all_case_combos():
+    out = []
+    for f in case_files():
+        d = np.load(f)
+        for t in case_tags(d):
+            out.append((os.path.basename(f)[:-4], t))
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+        return cache[name]
+    return load
+
+
+def assert_same_nan(a, b):
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN pattern differs"
+
+
+def max_abs_diff(a, b):
+    """max |a-b| where NaNs must coincide and infinities must be equal."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert_same_nan(a, b)
+    inf = np.isinf(a) | np.isinf(b)
+    assert np.array_equal(a[inf], b[inf]), "infinities differ"
+    m = np.isnan(a) | inf
+    if m.all():
+        return 0.0
+    return float(np.abs(a[~m] - b[~m]).max())

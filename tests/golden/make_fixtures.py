@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING the reference's own Python.
+
+Run in the build container only (it needs /root/reference, which never travels
+to the GPU box):
+
+    python tests/golden/make_fixtures.py            # writes tests/golden/*.npz
+
+What runs is the reference's code, imported from /root/reference:
+  core/utils/hyperbolic.py   HyperMapper.expmap/logmap/poincare_distance[_origin], HyperMLR
+  core/active/floating_region.py  FloatingRegionScore.forward (every branch)
+  core/active/build.py       select_pixels_to_label, RegionSelection
+with three stand-ins for things this image lacks (tests/golden/_shims):
+  * yacs.config.CfgNode        -> attribute dict
+  * geoopt.manifolds.stereographic.math -> torch restatement of geoopt's formulas
+    (=> the geoopt layer is "parity unpinned"; see the shim's docstring)
+  * torch.Tensor.cuda / nn.Module.cuda -> identity (floating_region.py:85-87,181-198
+    hard-code .cuda(); there is no GPU in the build container)
+
+Only DATA is written: inputs and the reference's outputs.  No reference source
+is copied into the repository.
+"""
+import math
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("HALO_REFERENCE", "/root/reference")
+
+
+def import_reference():
+    sys.path.insert(0, os.path.join(HERE, "_shims"))
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    # core/models/__init__ pulls torchvision/mmcv (absent); the hot path does not need it.
+    import core.configs  # noqa: F401
+    import core.utils.hyperbolic as hyp
+    import core.active.floating_region as fr
+    import core.active.build as ab
+    return core.configs.cfg, hyp, fr, ab
+
+
+def bilinear_up(x, size):
+    """The reference's resize (build.py:123-125,133-135)."""
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+
+def make_inputs(hyp, H, W, C, O, seed, sigma=0.1, scale=4, curvature=1.0):
+    """Low-res latent -> reference head tail -> reference x4 upsample."""
+    g = torch.Generator().manual_seed(seed)
+    h, w = H // scale, W // scale
+    z = torch.randn(1, C, h, w, generator=g, dtype=torch.float32) * sigma
+    # a few far-out vectors so tanh clamp (+-15) and project() saturation are exercised
+    z[0, :, 0, 0] *= 400.0
+    z[0, :, h // 2, w // 3] *= 60.0
+    z[0, :, h - 1, w - 1] = 0.0  # exact origin: norm clamp_min(1e-15) path
+    mapper = hyp.HyperMapper(c=curvature)
+    mlr = hyp.HyperMLR(C, O, c=curvature)
+    with torch.no_grad():
+        torch.manual_seed(seed + 7)
+        torch.nn.init.kaiming_uniform_(mlr.P_MLR, a=math.sqrt(5))
+        torch.nn.init.kaiming_uniform_(mlr.A_MLR, a=math.sqrt(5))
+        embed_lr = mapper.expmap(z, dim=1)                    # classifier.py:553
+        logit_lr64 = mlr(embed_lr.double())                   # classifier.py:554
+        logit_lr = logit_lr64.float()
+        logit = bilinear_up(logit_lr, (H, W))                 # build.py:123-125
+        embed = bilinear_up(embed_lr, (H, W))                 # build.py:133-135
+        radius_lr = mapper.poincare_distance_origin(embed_lr, dim=1)
+    gt = torch.randint(0, O, (H, W), generator=g, dtype=torch.int64)
+    ign = torch.rand(H, W, generator=g) < 0.05
+    gt[ign] = 255
+    prior_active = torch.zeros(H, W, dtype=torch.bool)
+    # a previously labelled block plus scattered pixels (round > 1 state)
+    prior_active[H // 4: H // 4 + 7, W // 2: W // 2 + 9] = True
+    prior_active |= torch.rand(H, W, generator=g) < 0.01
+    return dict(z=z, P_MLR=mlr.P_MLR.detach().clone(), A_MLR=mlr.A_MLR.detach().clone(),
+                embed_lr=embed_lr, logit_lr64=logit_lr64, logit_lr=logit_lr,
+                radius_lr=radius_lr, logit=logit, embed=embed, gt=gt,
+                prior_active=prior_active)
+
+
+def _better(a, b):
+    """torch.max ordering: NaN beats everything, otherwise '>'."""
+    if math.isnan(a):
+        return not math.isnan(b)
+    if math.isnan(b):
+        return False
+    return a > b
+
+
+def run_selection(ab, score, n, active_radius, mask_radius, active, selected, active_mask, gt):
+    """Drive the reference's select_pixels_to_label one region at a time (n calls
+    with active_regions=1 are the same loop as one call with active_regions=n,
+    build.py:37-62) so that the ORDER of picks and the runner-up gap can be
+    recorded; the state that is stored is the reference's own."""
+    picks = []
+    min_rel_gap = float("inf")
+    for _ in range(n):
+        before = score.clone()
+        if not torch.isnan(before).any() and float(before.max()) == -float("inf"):
+            break
+        ab.select_pixels_to_label(score, 1, active_radius, mask_radius,
+                                  active, selected, active_mask, gt)
+        changed = torch.isinf(score) & (score < 0) & ~(torch.isinf(before) & (before < 0))
+        idx = torch.nonzero(changed)
+        best = None
+        for hh, ww in idx.tolist():
+            v = float(before[hh, ww])
+            if best is None:
+                best = (v, hh, ww)
+                continue
+            bv, bh, bw = best
+            if _better(v, bv) or (not _better(bv, v) and (ww, hh) < (bw, bh)):
+                best = (v, hh, ww)
+        assert best is not None
+        v, hh, ww = best
+        picks.append((hh, ww, v))
+        if not math.isnan(v):
+            rest = before.clone()
+            rest[hh, ww] = -float("inf")
+            ru = float(rest.max())
+            if math.isfinite(ru) and v != 0.0:
+                min_rel_gap = min(min_rel_gap, (v - ru) / abs(v))
+    arr = np.array(picks, dtype=np.float64).reshape(-1, 3)
+    return arr, min_rel_gap
+
+
+COMBOS = [
+    # (tag, unc_type, pur_type, normalize, mask_radius, K)
+    ("halo", "entropy", "radius", True, 5, 100),           # configs/gtav/source_target.yaml:20-27
+    ("ripu", "entropy", "ripu", False, 3, 100),            # configs/gtav/ripu.yaml:23-29
+    ("hyper", "entropy", "hyper", True, 5, 100),           # defaults.py:68 (PURITY default)
+    ("hyperK10", "entropy", "hyper", True, 5, 10),
+    ("none_radius", "none", "radius", True, 5, 100),       # 0/0 -> NaN map
+    ("pixent_euc", "pixel_entropy", "euc_norm", True, 5, 100),
+    ("oracle", "oracle_acc", "oracle_ripu", False, 3, 100),
+    ("ent_none", "entropy", "none", False, 5, 100),
+    ("vestigial", "hyperbolic", "ripu", True, 5, 100),     # visualize.py:27-30: zeros branch
+]
+
+
+def gen_case(cfg, hyp, fr, ab, name, H, W, C, O, seed, n_regions, combos, f32_embed=False):
+    cfg.MODEL.NUM_CLASSES = O
+    inp = make_inputs(hyp, H, W, C, O, seed)
+    out = {k: v.numpy() for k, v in inp.items()}
+    out["meta_HWCO"] = np.array([H, W, C, O], dtype=np.int64)
+    out["meta_n_regions"] = np.array([n_regions], dtype=np.int64)
+    embed = inp["embed"].float() if f32_embed else inp["embed"]
+    if f32_embed:
+        out["embed"] = embed.numpy()
+    gaps = {}
+    for tag, unc, pur, norm, mrad, K in combos:
+        frs = fr.FloatingRegionScore(in_channels=O, size=3, purity_type=pur, K=K)
+        with torch.no_grad():
+            score, imp, uncm = frs(inp["logit"].clone(), decoder_out=embed.clone(),
+                                   unc_type=unc, pur_type=pur, normalize=norm,
+                                   ground_truth=inp["gt"].clone())
+        out[f"{tag}__score"] = score.numpy().copy()
+        out[f"{tag}__impurity"] = imp.numpy().copy()
+        out[f"{tag}__uncertainty"] = uncm.numpy().copy()
+        # round 1 (build.py:145-160), prior picks masked first
+        active = inp["prior_active"].clone()
+        selected = torch.zeros(H, W, dtype=torch.bool)
+        active_mask = torch.full((H, W), 255, dtype=torch.int64)
+        s = score.clone()
+        s[active] = -float("inf")
+        picks1, g1 = run_selection(ab, s, n_regions, 1, mrad, active, selected, active_mask, inp["gt"])
+        out[f"{tag}__r1_picks"] = picks1
+        out[f"{tag}__r1_score"] = s.numpy().copy()
+        out[f"{tag}__r1_active"] = active.numpy().copy()
+        out[f"{tag}__r1_selected"] = selected.numpy().copy()
+        out[f"{tag}__r1_active_mask"] = active_mask.numpy().copy()
+        # round 2 carries active/selected/active_mask over (cityscapes.py:245-251)
+        s = score.clone()
+        s[active] = -float("inf")
+        picks2, g2 = run_selection(ab, s, n_regions, 1, mrad, active, selected, active_mask, inp["gt"])
+        out[f"{tag}__r2_picks"] = picks2
+        out[f"{tag}__r2_active"] = active.numpy().copy()
+        out[f"{tag}__r2_selected"] = selected.numpy().copy()
+        out[f"{tag}__r2_active_mask"] = active_mask.numpy().copy()
+        out[f"{tag}__params"] = np.array([mrad, K, int(norm)], dtype=np.int64)
+        gaps[tag] = min(g1, g2)
+        out[f"{tag}__min_rel_gap"] = np.array([gaps[tag]], dtype=np.float64)
+        print(f"  {name}/{tag}: score {score.dtype} picks r1={len(picks1)} r2={len(picks2)} "
+              f"min_rel_gap={gaps[tag]:.3e}")
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+
+
+def gen_hypermapper(hyp):
+    """Last-dim API of HyperMapper incl. the in-tree-dead methods (hyperbolic.py:41-97)."""
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for c in (1.0, 0.5):
+        m = hyp.HyperMapper(c=c)
+        x = torch.randn(37, 12, generator=g, dtype=torch.float32) * 0.4
+        x[3] *= 100.0
+        x[5] = 0.0
+        xh = m.expmap(x)
+        yh = m.expmap(torch.randn(37, 12, generator=g, dtype=torch.float32) * 0.7)
+        tag = f"c{c}"
+        out[f"{tag}__x"] = x.numpy()
+        out[f"{tag}__expmap"] = xh.numpy()
+        out[f"{tag}__y_h"] = yh.numpy()
+        out[f"{tag}__logmap"] = m.logmap(xh).numpy()
+        out[f"{tag}__dist0"] = m.poincare_distance_origin(xh).numpy()
+        out[f"{tag}__dist"] = m.poincare_distance(xh, yh).numpy()
+        out[f"{tag}__expmap2"] = m.expmap2(x.double()).numpy()
+        out[f"{tag}__cosine"] = m.cosine_distance(x[6:], yh[6:].float()).numpy()
+    np.savez_compressed(os.path.join(HERE, "hypermapper.npz"), **out)
+
+
+class _FakeExtractor(torch.nn.Module):
+    def forward(self, x):
+        return x
+
+
+class _FakeClassifier(torch.nn.Module):
+    """Returns pre-computed low-res (logits, embed) per call -- stands for backbone+head."""
+
+    def __init__(self, outs):
+        super().__init__()
+        self.outs = outs
+        self.i = 0
+
+    def forward(self, feat, size=None):
+        o = self.outs[self.i % len(self.outs)]
+        self.i += 1
+        return o
+
+
+def gen_region_selection(cfg, hyp, fr, ab):
+    """Two rounds of the reference's RegionSelection driver (build.py:71-186) over a
+    3-image pool, through its real PNG / torch.save persistence."""
+    from PIL import Image
+    H, W, C, O = 48, 96, 8, 19
+    cfg.MODEL.NUM_CLASSES = O
+    cfg.MODEL.HYPER = True
+    cfg.ACTIVE.UNCERTAINTY = "entropy"
+    cfg.ACTIVE.PURITY = "radius"
+    cfg.ACTIVE.NORMALIZE = True
+    cfg.ACTIVE.RADIUS_K = 1
+    cfg.ACTIVE.MASK_RADIUS_K = 5
+    cfg.ACTIVE.BUDGET = 0.05
+    cfg.ACTIVE.SELECT_ITER = [0, 1, 2, 3, 4]
+    cfg.ACTIVE.K = 100
+    cfg.ACTIVE.VIZ_MASK = False
+    out = {"meta_HWCO": np.array([H, W, C, O], dtype=np.int64)}
+    tmp = tempfile.mkdtemp(prefix="halo_fix_")
+    imgs = []
+    for i in range(3):
+        inp = make_inputs(hyp, H, W, C, O, seed=500 + i)
+        imgs.append(inp)
+        out[f"img{i}__logit_lr"] = inp["logit_lr"].numpy()
+        out[f"img{i}__embed_lr"] = inp["embed_lr"].numpy()
+        out[f"img{i}__gt"] = inp["gt"].numpy()
+        Image.fromarray(np.full((H, W), 255, dtype=np.uint8)).save(os.path.join(tmp, f"m{i}.png"))
+        torch.save({"active": torch.tensor([0], dtype=torch.bool),
+                    "selected": torch.tensor([0], dtype=torch.bool)},
+                   os.path.join(tmp, f"i{i}.pth"))
+
+    def loader():
+        for i, inp in enumerate(imgs):
+            ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+            a, s = ind["active"], ind["selected"]
+            mask = torch.from_numpy(np.array(Image.open(os.path.join(tmp, f"m{i}.png")),
+                                             dtype=np.uint8)).long()
+            if a.size() == (1,):  # cityscapes.py:249-251
+                a = torch.zeros(H, W, dtype=torch.bool)
+                s = torch.zeros(H, W, dtype=torch.bool)
+            yield {"img": torch.zeros(1, 3, H // 2, W // 2),
+                   "path_to_mask": [os.path.join(tmp, f"m{i}.png")],
+                   "origin_mask": mask[None], "origin_label": inp["gt"][None],
+                   "size": torch.tensor([[H, W]]), "active": a[None], "selected": s[None],
+                   "path_to_indicator": [os.path.join(tmp, f"i{i}.pth")],
+                   "name": [f"img{i}"]}
+
+    for rnd in (1, 2):
+        clf = _FakeClassifier([(inp["logit_lr"], inp["embed_lr"]) for inp in imgs])
+        ab.RegionSelection(cfg, _FakeExtractor(), clf, list(loader()), rnd)
+        for i in range(3):
+            ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+            out[f"r{rnd}_img{i}__active"] = ind["active"].numpy()
+            out[f"r{rnd}_img{i}__selected"] = ind["selected"].numpy()
+            out[f"r{rnd}_img{i}__mask_png"] = np.array(
+                Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8)
+        print(f"  region_selection round {rnd}: selected px img0 = "
+              f"{int(out[f'r{rnd}_img0__selected'].sum())}")
+    np.savez_compressed(os.path.join(HERE, "region_selection.npz"), **out)
+
+
+def main():
+    torch.set_num_threads(4)
+    cfg, hyp, fr, ab = import_reference()
+    cfg.MODEL.CURVATURE = 1.0
+    print("torch", torch.__version__)
+    print("case A 32x64 C8 O19 (selection runs to exhaustion)")
+    gen_case(cfg, hyp, fr, ab, "case_a_32x64_c8_o19", 32, 64, 8, 19, 11, 200, COMBOS)
+    print("case B 64x128 C16 O19")
+    gen_case(cfg, hyp, fr, ab, "case_b_64x128_c16_o19", 64, 128, 16, 19, 22, 60, COMBOS)
+    print("case C 48x96 C8 O16 (SYNTHIA class count; log(19) stays hard-coded)")
+    gen_case(cfg, hyp, fr, ab, "case_c_48x96_c8_o16", 48, 96, 8, 16, 33, 40,
+             [c for c in COMBOS if c[0] in ("halo", "ripu", "hyper", "oracle")])
+    print("case D 40x72 C8 O19 float32 embed (MODEL.HYPER=False style input)")
+    gen_case(cfg, hyp, fr, ab, "case_d_40x72_c8_o19_f32", 40, 72, 8, 19, 44, 30,
+             [c for c in COMBOS if c[0] in ("halo", "hyper", "pixent_euc")], f32_embed=True)
+    print("hypermapper last-dim API")
+    gen_hypermapper(hyp)
+    print("RegionSelection driver, 2 rounds")
+    gen_region_selection(cfg, hyp, fr, ab)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""Closed-form known answers for the geoopt layer (expmap0 / project / dist0 / logmap0 /
+dist) and HyperMLR, evaluated with mpmath -- independent of any implementation.
+
+geoopt is an un-pinned third-party dependency of the reference (requirements.txt:13) that
+is absent from /root/reference and from this image, so its layer of the oracle is
+"parity unpinned"; these identities are what pins it instead.
+"""
+import mpmath as mp
+import numpy as np
+import pytest
+
+from oracle import halo_oracle as ho
+
+mp.mp.prec = 160
+RNG = np.random.default_rng(7)
+
+
+def _mpnorm(v):
+    return mp.sqrt(sum(mp.mpf(float(x)) ** 2 for x in v))
+
+
+@pytest.mark.parametrize("c", [1.0, 0.5, 2.0])
+def test_expmap_norm_and_dist0_roundtrip(c):
+    u = RNG.normal(size=(64, 10)) * 0.3
+    y = ho.expmap(u, c)
+    r = ho.dist0(y, c)
+    ks = mp.sqrt(mp.mpf(c) + mp.mpf("1e-15"))
+    for i in range(len(u)):
+        n = _mpnorm(u[i])
+        want_norm = mp.tanh(ks * n) / ks                  # ||expmap0(u)|| = tanh(sqrt(c)||u||)/sqrt(c)
+        assert abs(_mpnorm(y[i]) - want_norm) < 1e-14
+        assert abs(mp.mpf(float(r[i])) - 2 * n) < 1e-12   # dist0(expmap0(u)) = 2||u|| inside the ball
+        # direction is preserved
+        cos = float(np.dot(u[i], y[i]) / (np.linalg.norm(u[i]) * np.linalg.norm(y[i])))
+        assert abs(cos - 1.0) < 1e-14
+
+
+@pytest.mark.parametrize("c", [1.0, 0.5])
+def test_project_saturation(c):
+    u = RNG.normal(size=(8, 6)) * 40.0                     # far outside: tanh clamp + project
+    y = ho.expmap(u, c)
+    maxnorm = (1 - 1e-5) / np.sqrt(c + 1e-15)
+    assert np.all(np.linalg.norm(y, axis=1) <= maxnorm * (1 + 1e-15))
+    assert np.allclose(np.linalg.norm(y, axis=1), maxnorm, rtol=1e-14)
+    want = 2 / mp.sqrt(mp.mpf(c)) * mp.atanh(mp.mpf(1) - mp.mpf("1e-5"))   # = 12.2061 for c=1
+    assert np.allclose(ho.dist0(y, c), float(want), rtol=1e-9)
+    if c == 1.0:
+        assert abs(float(want) - 12.2061) < 1e-4
+
+
+def test_origin_and_clamps():
+    z = np.zeros((3, 5))
+    assert np.array_equal(ho.expmap(z, 1.0), z)            # norm clamp_min(1e-15): 0/1e-15 = 0
+    assert np.array_equal(ho.dist0(z, 1.0), np.zeros(3))
+    # artanh argument clamp at 1-1e-7: a point ON the boundary has a finite radius
+    e = np.zeros((1, 4)); e[0, 0] = 1.0
+    want = 2 * mp.atanh(mp.mpf(1) - mp.mpf("1e-7"))
+    assert abs(float(ho.dist0(e, 1.0)[0]) - float(want)) < 1e-8
+
+
+def test_logmap_inverts_expmap():
+    u = RNG.normal(size=(32, 7)) * 0.15                    # ||u|| < 1: see the quirk below
+    assert np.linalg.norm(u, axis=1).max() < 0.99
+    assert np.abs(ho.logmap(ho.expmap(u, 1.0), 1.0) - u).max() < 1e-13
+    # reference quirk kept on purpose: HyperMapper.logmap project()s the TANGENT vector
+    # (hyperbolic.py:60), so tangent vectors longer than (1-1e-5)/sqrt(c) come back clipped
+    big = RNG.normal(size=(8, 7)) * 0.8
+    back = ho.logmap(ho.expmap(big, 1.0), 1.0)
+    long_ = np.linalg.norm(big, axis=1) > 1.0
+    assert long_.any()
+    assert np.allclose(np.linalg.norm(back[long_], axis=1), 1 - 1e-5, rtol=1e-12)
+
+
+def test_dist_identities():
+    x = ho.expmap(RNG.normal(size=(40, 6)) * 0.5, 1.0)
+    y = ho.expmap(RNG.normal(size=(40, 6)) * 0.5, 1.0)
+    assert np.abs(ho.dist(x, x, 1.0)).max() < 1e-7          # dist(x,x) = 0 (sqrt of rounding noise)
+    assert np.abs(ho.dist(x, y, 1.0) - ho.dist(y, x, 1.0)).max() < 1e-12
+    assert np.abs(ho.dist(np.zeros_like(y), y, 1.0) - ho.dist0(y, 1.0)).max() < 1e-12
+    # closed form: cosh d = 1 + 2|x-y|^2 / ((1-|x|^2)(1-|y|^2))
+    for i in range(10):
+        nx, ny = _mpnorm(x[i]), _mpnorm(y[i])
+        d2 = sum((mp.mpf(float(a)) - mp.mpf(float(b))) ** 2 for a, b in zip(x[i], y[i]))
+        want = mp.acosh(1 + 2 * d2 / ((1 - nx ** 2) * (1 - ny ** 2)))
+        assert abs(mp.mpf(float(ho.dist(x[i:i + 1], y[i:i + 1], 1.0)[0])) - want) < 1e-11
+
+
+@pytest.mark.parametrize("c", [1.0, 0.7])
+def test_hypermlr_at_origin(c):
+    """x = 0: logits reduce to 2/sqrt(c) * ||a|| * asinh( sqrt(c) <-p, a^> * 2/(1 - c||p||^2) )."""
+    O, C = 5, 6
+    P = RNG.uniform(-0.3, 0.3, size=(O, C))
+    A = RNG.uniform(-0.4, 0.4, size=(O, C))
+    out = ho.hypermlr(np.zeros((1, C, 2, 3)), P, A, c)
+    for o in range(O):
+        na = _mpnorm(A[o])
+        pa = sum(-mp.mpf(float(p)) * mp.mpf(float(a)) / na for p, a in zip(P[o], A[o]))
+        pp = _mpnorm(P[o]) ** 2
+        want = 2 / mp.sqrt(c) * na * mp.asinh(mp.sqrt(c) * pa * 2 / (1 - mp.mpf(c) * pp))
+        assert abs(mp.mpf(float(out[0, o, 0, 0])) - want) < 1e-13
+        assert np.ptp(out[0, o]) == 0.0
+
+
+def test_hypermlr_matches_hyperplane_distance():
+    """General x (c=1): logit = 2||a|| asinh( 2<(-p)(+)x, a^> / (1 - ||(-p)(+)x||^2) ) -- the
+    Ganea et al. hyperbolic MLR the reference implements (hyperbolic.py:120-184)."""
+    O, C = 4, 5
+    P = RNG.uniform(-0.3, 0.3, size=(O, C))
+    A = RNG.uniform(-0.4, 0.4, size=(O, C))
+    x = ho.expmap(RNG.normal(size=(1, C, 3, 3)) * 0.3, 1.0, dim=1)
+    out = ho.hypermlr(x, P, A, 1.0)
+    for o in range(O):
+        for (i, j) in ((0, 0), (1, 2), (2, 1)):
+            xv = [mp.mpf(float(v)) for v in x[0, :, i, j]]
+            pv = [-mp.mpf(float(v)) for v in P[o]]
+            av = [mp.mpf(float(v)) for v in A[o]]
+            x2 = sum(v * v for v in xv); p2 = sum(v * v for v in pv); px = sum(a * b for a, b in zip(pv, xv))
+            den = 1 + 2 * px + x2 * p2
+            mob = [((1 + 2 * px + x2) * p + (1 - p2) * xx) / den for p, xx in zip(pv, xv)]
+            m2 = sum(v * v for v in mob)
+            na = mp.sqrt(sum(v * v for v in av))
+            dot = sum(m * a for m, a in zip(mob, av)) / na
+            want = 2 * na * mp.asinh(2 * dot / (1 - m2))
+            assert abs(mp.mpf(float(out[0, o, i, j])) - want) < 1e-12
+
+
+def test_elementary_functions_accuracy():
+    """The contract's own expf/logf/log stay within 1 ulp of the true value."""
+    L = ho.lib()
+    xs = np.concatenate([RNG.uniform(-100, 0, 4000), RNG.uniform(0, 80, 500)]).astype(np.float32)
+    for x in xs:
+        got = np.float32(L.halo_o_expf(float(x)))
+        want = mp.exp(mp.mpf(float(x)))
+        ulp = float(np.spacing(np.float32(max(float(want), 1.2e-38))))
+        assert abs(mp.mpf(float(got)) - want) <= 1.0 * ulp
+    xs = np.concatenate([RNG.uniform(1e-6, 1.2, 4000), 10 ** RNG.uniform(-20, 20, 500)]).astype(np.float32)
+    for x in xs:
+        got = np.float32(L.halo_o_logf(float(x)))
+        want = mp.log(mp.mpf(float(x)))
+        ulp = float(np.spacing(np.float32(abs(float(want))))) or 1e-45
+        assert abs(mp.mpf(float(got)) - want) <= 1.0 * ulp
+    xs = np.concatenate([RNG.uniform(1e-7, 2, 3000), 10 ** RNG.uniform(-200, 200, 300)])
+    for x in xs:
+        got = L.halo_o_log(float(x))
+        want = mp.log(mp.mpf(float(x)))
+        ulp = float(np.spacing(abs(float(want)))) or 5e-324
+        assert abs(mp.mpf(got) - want) <= 1.0 * ulp
