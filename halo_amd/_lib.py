@@ -1,0 +1,117 @@
+"""ctypes binding of libhalo_hip.so (C ABI: include/halo_hip.h).
+
+This is the only place that touches the shared library.  Nothing here falls back to a CPU
+implementation: a missing library, a missing symbol or a non-ROCm tensor raises.
+"""
+import ctypes as C
+import os
+import threading
+
+from . import _build
+
+F32, F64 = 0, 1
+UNC = {"entropy": 0, "pixel_entropy": 1, "oracle_acc": 2}          # everything else -> zeros (3)
+UNC_ZEROS = 3
+PUR = {"ripu": 0, "oracle_ripu": 1, "hyper": 2, "none": 3, "radius": 4, "euc_norm": 5}
+E_UNSUPPORTED = -2
+
+_i64, _dbl, _int, _vp, _sz = C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/halo_hip.h declares
+SIGNATURES = {
+    "halo_version": (_int, []),
+    "halo_last_error": (C.c_char_p, []),
+    "halo_expmap0_project": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _dbl, _vp]),
+    "halo_logmap0_project": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _vp]),
+    "halo_dist0": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _dbl, _vp]),
+    "halo_pdist": (_int, [_vp, _vp, _vp, _i64, _i64, _dbl, _vp]),
+    "halo_hypermlr_workspace_bytes": (_sz, [_i64, _i64]),
+    "halo_hypermlr_logits": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _vp, _sz, _vp]),
+    "halo_bilinear_upsample": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "halo_score_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "halo_score_maps": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
+                               _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "halo_greedy_select": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _sz, _vp]),
+}
+
+_lock = threading.Lock()
+_handle = None
+
+
+class HaloHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.SO
+
+
+def lib():
+    """Load (building first if the in-tree .so is missing or stale) and type the library."""
+    global _handle
+    if _handle is not None:
+        return _handle
+    with _lock:
+        if _handle is not None:
+            return _handle
+        try:
+            path = _build.build()
+        except Exception as exc:  # no hipcc and no prebuilt .so: fail loudly, never fall back
+            if os.path.exists(_build.SO):
+                path = _build.SO
+            else:
+                raise HaloHipError("libhalo_hip.so is missing and could not be built: %s" % exc) from exc
+        h = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name, None)
+            if fn is None:
+                raise HaloHipError("libhalo_hip.so does not export %s" % name)
+            fn.restype = res
+            fn.argtypes = args
+        _handle = h
+    return _handle
+
+
+def check(rc, what=""):
+    if rc == 0:
+        return
+    msg = lib().halo_last_error().decode("utf-8", "replace")
+    if rc == E_UNSUPPORTED and "not implemented" in msg:
+        raise NotImplementedError(msg)
+    raise HaloHipError("%s failed (%d): %s" % (what or "halo call", rc, msg))
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise TypeError("halo_amd: expected float32/float64 tensor, got %s" % t.dtype)
+
+
+def require_device(*tensors):
+    """All tensors must live on one ROCm device.  No CPU path exists."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HaloHipError(
+                "halo_amd runs on ROCm devices only (got a %s tensor); there is no CPU fallback" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise HaloHipError("halo_amd: tensors on different devices (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,155 @@
+"""FloatingRegionScore on HIP kernels -- host mirror of core/active/floating_region.py.
+
+Same constructor, same `forward(logit, decoder_out, unc_type, pur_type, normalize, ground_truth)
+-> (score, region_impurity, prediction_uncertainty)`, same dtypes (score float64 when the purity is
+'radius'/'euc_norm' on a float64 embedding, float32 otherwise), same errors (AssertionError for an
+even size, NotImplementedError for an unknown purity type; an unknown uncertainty type is a zero
+map, floating_region.py:84-90).  All arithmetic runs in halo_amd/csrc/halo_score.hip; there is no
+CPU path and no one-hot / conv tensors are materialised.
+
+`score_maps` is the batched form (B images per launch) the acquisition driver and bench use.
+"""
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ..configs import cfg
+from ..utils.hyperbolic import HyperMapper
+
+_WS = {}
+
+
+def _workspace(dev, nbytes, tag):
+    """Stream-ordered scratch, cached per (device, stream, tag) and grown on demand."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _WS[key] = buf
+    return buf
+
+
+def score_dtype(pur_type, decoder_out):
+    if pur_type in ("radius", "euc_norm") and decoder_out is not None and decoder_out.dtype == torch.float64:
+        return torch.float64
+    return torch.float32
+
+
+def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
+               size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True):
+    """Batched FloatingRegionScore.forward.
+
+    logit (B,O,H,W) float32; decoder_out (B,C,H,W) float64|float32; ground_truth (B,H,W) int64;
+    active (B,H,W) bool, optional: fuses `score[active] = -inf` (core/active/build.py:146).
+    Returns (score, impurity, uncertainty), each (B,H,W); the last two are None if not want_maps.
+    """
+    if pur_type not in _lib.PUR:
+        raise NotImplementedError("Error: purity type '{}' not implemented".format(pur_type))
+    dev = _lib.require_device(logit, decoder_out, ground_truth, active)
+    assert logit.dim() == 4, "logit must be (B,O,H,W)"
+    if logit.dtype != torch.float32:
+        logit = logit.float()
+    B, O, H, W = logit.shape
+    if logit.stride()[1:] != (H * W, W, 1):
+        logit = logit.contiguous()
+    need_feat = pur_type in ("hyper", "radius", "euc_norm")
+    feat = None
+    Cc, fdt, fbs = 0, _lib.F64, 0
+    if need_feat:
+        if decoder_out is None:
+            raise ValueError("decoder_out is required for purity type '%s'" % pur_type)
+        feat = decoder_out
+        if feat.dtype not in (torch.float32, torch.float64):
+            feat = feat.float()
+        Cc = feat.shape[1]
+        assert feat.shape[0] == B and feat.shape[2:] == (H, W), "decoder_out shape mismatch"
+        if feat.stride()[1:] != (H * W, W, 1):
+            feat = feat.contiguous()
+        fdt, fbs = _lib.dtype_code(feat), feat.stride(0)
+    need_gt = unc_type == "oracle_acc" or pur_type == "oracle_ripu"
+    gt = None
+    if need_gt:
+        if ground_truth is None:
+            raise ValueError("ground_truth is required for '%s'/'%s'" % (unc_type, pur_type))
+        gt = ground_truth.reshape(B, H, W).to(torch.int64).contiguous()
+    act = None
+    if active is not None:
+        act = active.reshape(B, H, W).contiguous()
+        act = act.view(torch.uint8) if act.dtype == torch.bool else act.to(torch.uint8)
+    odt = score_dtype(pur_type, feat)
+    score = torch.empty((B, H, W), dtype=odt, device=dev)
+    imp = torch.empty((B, H, W), dtype=odt, device=dev) if want_maps else None
+    unc = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_maps else None
+    L = _lib.lib()
+    nws = L.halo_score_workspace_bytes(B, H, W)
+    ws = _workspace(dev, nws, "score")
+    psize = size if purity_size is None else purity_size
+    rc = L.halo_score_maps(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt), _lib.ptr(act),
+                           B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS), _lib.PUR[pur_type],
+                           1 if normalize else 0, int(size), int(psize), int(K), float(c),
+                           _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
+                           _lib.stream_ptr(dev))
+    _lib.check(rc, "halo_score_maps")
+    return score, imp, unc
+
+
+class FloatingRegionScore(nn.Module):
+    def __init__(self, in_channels=19, padding_mode="zeros", size=33, purity_type=None, K=100):
+        """
+        purity window: size*size (3*3 over K bins when purity_type == 'hyper')
+        entropy window: size*size
+        """
+        super(FloatingRegionScore, self).__init__()
+        self.in_channels = in_channels
+        assert size % 2 == 1, "error size"
+        if padding_mode != "zeros":
+            raise NotImplementedError("halo_amd FloatingRegionScore implements padding_mode='zeros' only")
+        if purity_type is None:
+            purity_type = cfg.ACTIVE.PURITY
+        self.size = size
+        self.purity_size = size
+        self.purity_channels = in_channels
+        if purity_type == "hyper":                      # floating_region.py:54-55
+            self.K, self.purity_size, self.purity_channels = K, 3, K
+        self.mapper = HyperMapper(c=cfg.MODEL.CURVATURE)
+
+    def _check_purity_channels(self, pur_type):
+        # the reference's depthwise purity_conv has a fixed channel count; a mismatching one-hot
+        # makes F.conv2d raise -- keep that an error instead of inventing a result
+        if pur_type in ("ripu", "oracle_ripu") and self.purity_channels != self.in_channels:
+            raise RuntimeError("purity window was built for %d bins ('hyper'), got a %d-class prediction"
+                               % (self.purity_channels, self.in_channels))
+        if pur_type == "hyper" and not hasattr(self, "K"):
+            raise AttributeError("'FloatingRegionScore' object has no attribute 'K'")
+        if pur_type == "hyper" and self.purity_channels != self.K:
+            raise RuntimeError("purity window channel mismatch")
+
+    def forward(self, logit: torch.Tensor, decoder_out: torch.Tensor = None, unc_type: str = None,
+                pur_type: str = None, normalize: bool = False, ground_truth=None):
+        """
+        Compute regions score, impurity and uncertainty.
+
+        Args:
+            logit: (1, O, H, W) float32 on a ROCm device
+            decoder_out: (1, C, H, W) embedding (float64 from the hyperbolic heads)
+            unc_type: entropy | pixel_entropy | oracle_acc | anything else -> zeros
+            pur_type: ripu | oracle_ripu | hyper | none | radius | euc_norm
+            normalize: min-max normalise the impurity and uncertainty maps
+
+        Return:
+            score, purity, entropy -- each (H, W)
+        """
+        if pur_type not in _lib.PUR:
+            raise NotImplementedError("Error: purity type '{}' not implemented".format(pur_type))
+        self._check_purity_channels(pur_type)
+        if logit.dim() == 3:
+            logit = logit.unsqueeze(0)
+        if logit.shape[0] != 1:
+            raise ValueError("FloatingRegionScore.forward scores one image (as the reference); "
+                             "use score_maps() for a batch")
+        if decoder_out is not None and decoder_out.dim() == 3:
+            decoder_out = decoder_out.unsqueeze(0)
+        gt = None if ground_truth is None else ground_truth.unsqueeze(0)
+        score, imp, unc = score_maps(logit, decoder_out, unc_type, pur_type, normalize, gt, size=self.size,
+                                     purity_size=self.purity_size, K=getattr(self, "K", 100), c=self.mapper.c)
+        return score[0], imp[0], unc[0]

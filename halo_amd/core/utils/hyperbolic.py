@@ -1,0 +1,172 @@
+"""HyperMapper / HyperMLR on HIP kernels -- host mirror of core/utils/hyperbolic.py.
+
+Same class names, method names, argument meaning, parameter names (`P_MLR`, `A_MLR`, float64,
+kaiming-uniform(a=sqrt(5)) -- checkpoint keys `classifier.conv_seg.P_MLR/A_MLR` load unchanged)
+and dtypes as the reference.  The arithmetic (geoopt's stereographic math in the reference,
+hyperbolic.py:8) runs in halo_amd/csrc/halo_hyperbolic.hip.  Inference only: the kernels have
+no autograd; a call that needs gradients raises instead of silently detaching.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_uniform_
+from torch.nn.parameter import Parameter
+
+from ... import _lib
+
+PROJ_EPS = 1e-3
+
+
+def _no_grad_only(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            "halo_amd hyperbolic kernels are inference-only (no autograd); wrap the call in "
+            "torch.no_grad() or keep the PyTorch path for training")
+
+
+def _split(shape, dim):
+    dim = dim % len(shape)
+    outer = 1
+    for s in shape[:dim]:
+        outer *= s
+    inner = 1
+    for s in shape[dim + 1:]:
+        inner *= s
+    return dim, outer, shape[dim], inner
+
+
+class HyperMapper(object):
+    """Maps between Euclidean and hyperbolic space and computes distances (hyperbolic.py:16-97)."""
+
+    def __init__(self, c=1.) -> None:
+        self.c = c
+        self.K = torch.tensor(-self.c, dtype=float)
+
+    def expmap(self, x, dim=-1):
+        """project(expmap0(x.double())) -> float64 (hyperbolic.py:28-39)."""
+        _no_grad_only(x)
+        dev = _lib.require_device(x)
+        x = x.contiguous()
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.double()
+        y = torch.empty(x.shape, dtype=torch.float64, device=dev)
+        if x.numel() == 0:
+            return y
+        _, outer, C, inner = _split(x.shape, dim)
+        _lib.check(_lib.lib().halo_expmap0_project(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(y), outer, C, inner,
+                                                   float(self.c), _lib.stream_ptr(dev)), "halo_expmap0_project")
+        return y
+
+    def expmap2(self, inputs, dim=-1):
+        """Alternative expmap with +1e-15 and eps 1e-3 (hyperbolic.py:41-49; no caller in-tree).
+        Elementwise torch ops on the device; only the projection's norm is a reduction."""
+        dev = _lib.require_device(inputs)
+        sqrt_c = torch.sqrt(torch.abs(self.K)).to(dev)
+        inputs = inputs + 1e-15
+        norm = torch.norm(inputs, dim=dim)
+        gamma = torch.tanh(sqrt_c * norm) / (sqrt_c * norm)
+        scaled = gamma.unsqueeze(dim) * inputs
+        maxnorm = (1 - PROJ_EPS) / ((self.K.abs() + 1e-15) ** 0.5).to(dev)
+        n = scaled.norm(dim=dim, keepdim=True, p=2).clamp_min(1e-15)
+        return torch.where(n > maxnorm, scaled / n * maxnorm, scaled)
+
+    def logmap(self, x):
+        """project(logmap0(x.double())) over the last dim (hyperbolic.py:51-60)."""
+        _no_grad_only(x)
+        dev = _lib.require_device(x)
+        x = x.double().contiguous()
+        y = torch.empty_like(x)
+        if x.numel() == 0:
+            return y
+        _, outer, C, inner = _split(x.shape, -1)
+        _lib.check(_lib.lib().halo_logmap0_project(_lib.ptr(x), _lib.ptr(y), outer, C, inner, float(self.c),
+                                                   _lib.stream_ptr(dev)), "halo_logmap0_project")
+        return y
+
+    def poincare_distance(self, x, y):
+        """geoopt dist over the last dim (hyperbolic.py:62-72; no live caller in-tree)."""
+        _no_grad_only(x, y)
+        dev = _lib.require_device(x, y)
+        in_dtype = torch.promote_types(x.dtype, y.dtype)
+        x, y = torch.broadcast_tensors(x, y)
+        x = x.double().contiguous()
+        y = y.double().contiguous()
+        out = torch.empty(x.shape[:-1], dtype=torch.float64, device=dev)
+        if out.numel():
+            _lib.check(_lib.lib().halo_pdist(_lib.ptr(x), _lib.ptr(y), _lib.ptr(out), out.numel(), x.shape[-1],
+                                             float(self.c), _lib.stream_ptr(dev)), "halo_pdist")
+        return out if in_dtype == torch.float64 else out.to(in_dtype)
+
+    def poincare_distance_origin(self, x, dim=-1):
+        """geoopt dist0: 2/sqrt(c) artanh(sqrt(c)||x||), dtype preserved (hyperbolic.py:74-83)."""
+        _no_grad_only(x)
+        dev = _lib.require_device(x)
+        x = x.contiguous()
+        d, outer, C, inner = _split(x.shape, dim)
+        out = torch.empty(x.shape[:d] + x.shape[d + 1:], dtype=x.dtype, device=dev)
+        if out.numel():
+            _lib.check(_lib.lib().halo_dist0(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(out), outer, C, inner,
+                                             float(self.c), _lib.stream_ptr(dev)), "halo_dist0")
+        return out
+
+    def cosine_distance(self, x, y):
+        """2 - 2 cos (hyperbolic.py:85-97; no caller in-tree)."""
+        _lib.require_device(x, y)
+        x = torch.nn.functional.normalize(x, dim=-1, p=2)
+        y = torch.nn.functional.normalize(y, dim=-1, p=2)
+        return 2 - 2 * (x * y).sum(dim=-1)
+
+
+class HyperMLR(nn.Module):
+    """Multinomial logistic regression in hyperbolic space (hyperbolic.py:100-188)."""
+
+    def __init__(self, out_channels, num_classes, c=1.):
+        super().__init__()
+        self.c = c
+        self.K = torch.tensor(c, dtype=float)
+        self.num_classes = num_classes
+        self.P_MLR = Parameter(torch.empty((num_classes, out_channels), dtype=torch.double))
+        self.A_MLR = Parameter(torch.empty((num_classes, out_channels), dtype=torch.double))
+        kaiming_uniform_(self.P_MLR, a=math.sqrt(5))
+        kaiming_uniform_(self.A_MLR, a=math.sqrt(5))
+
+    def _hyper_logits(self, inputs, out_dtype=torch.float64):
+        """inputs (B,C,H,W) float64 -> (B,O,H,W).  out_dtype=float32 fuses the head's `.float()`
+        (core/models/classifier.py:373,554)."""
+        _no_grad_only(inputs, self.P_MLR, self.A_MLR)
+        dev = _lib.require_device(inputs, self.P_MLR, self.A_MLR)
+        x = inputs.double().contiguous()
+        B, Cc, H, W = x.shape
+        O = self.num_classes
+        P = self.P_MLR.detach().contiguous()
+        A = self.A_MLR.detach().contiguous()
+        out = torch.empty((B, O, H, W), dtype=out_dtype, device=dev)
+        if out.numel() == 0:
+            return out
+        L = _lib.lib()
+        nws = L.halo_hypermlr_workspace_bytes(O, Cc)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        _lib.check(L.halo_hypermlr_logits(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(out), _lib.dtype_code(out),
+                                          B, Cc, O, H * W, float(self.c), _lib.ptr(ws), nws, _lib.stream_ptr(dev)),
+                   "halo_hypermlr_logits")
+        return out
+
+    def forward(self, x):
+        return self._hyper_logits(x)
+
+
+def bilinear_align_corners(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) for float32/float64 NCHW
+    (core/active/build.py:123-125,133-135; classifier.py:375-377,556-557)."""
+    _no_grad_only(x)
+    dev = _lib.require_device(x)
+    x = x.contiguous()
+    H, W = int(size[0]), int(size[1])
+    h, w = x.shape[-2:]
+    out = torch.empty(x.shape[:-2] + (H, W), dtype=x.dtype, device=dev)
+    if out.numel():
+        planes = x.numel() // (h * w)
+        _lib.check(_lib.lib().halo_bilinear_upsample(_lib.ptr(x), _lib.ptr(out), _lib.dtype_code(x), planes, h, w, H, W,
+                                                     _lib.stream_ptr(dev)), "halo_bilinear_upsample")
+    return out

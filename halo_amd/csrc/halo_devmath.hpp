@@ -1,0 +1,132 @@
+// Elementary functions of the HALO-AMD numeric contract for gfx950 device code.
+//
+// The scoring maps feed an argmax-driven greedy selector whose output must be bit-identical
+// between runs, ranks and the CPU checker, so exp/log are not taken from the device libm
+// (whose results differ from any host libm in the last ulp).  Instead each is a fixed
+// sequence of IEEE-754 operations -- Cephes-style single-precision expf/logf, fdlibm-style
+// double log -- with every fused multiply-add written out; the translation unit is built
+// with -ffp-contract=off so nothing else is contracted.  sqrt and '/' are the correctly
+// rounded device instructions sequences hipcc emits by default.
+//
+// Stands in for: torch.softmax / torch.log in FloatingRegionScore
+// (core/active/floating_region.py:72,119,152) and the float64 torch.log inside geoopt's
+// artanh (used by dist0, core/utils/hyperbolic.py:83).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace halo {
+
+__device__ __forceinline__ float pow2f_(int k) { return __uint_as_float((uint32_t)(k + 127) << 23); }
+
+__device__ __forceinline__ float det_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __uint_as_float(0x7f800000u);
+    if (x < -103.97208404541015625f) return 0.0f;
+    float k = __builtin_rintf(x * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(k, -0.693359375f, x);
+    r = __builtin_fmaf(k, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    int ki = (int)k;
+    int k1 = ki >> 1;
+    int k2 = ki - k1;
+    return (y * pow2f_(k1)) * pow2f_(k2);
+}
+
+__device__ __forceinline__ float det_logf(float x)
+{
+    if (x != x) return x;
+    if (x < 0.0f) return __uint_as_float(0x7fc00000u);
+    if (x == 0.0f) return __uint_as_float(0xff800000u);
+    uint32_t u = __float_as_uint(x);
+    if (u == 0x7f800000u) return x;
+    int e = 0;
+    if (u < 0x00800000u) { x = x * 8388608.0f; u = __float_as_uint(x); e = -23; }
+    e += (int)(u >> 23) - 126;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106769084930419921875f) { e -= 1; m = (m + m) - 1.0f; }
+    else { m = m - 1.0f; }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, m, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+    float y = (p * m) * z;
+    float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = m + y;
+    return __builtin_fmaf(fe, 0.693359375f, r);
+}
+
+__device__ __forceinline__ double det_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0.0) return __longlong_as_double(0x7ff8000000000000ll);
+    if (x == 0.0) return __longlong_as_double(0xfff0000000000000ll);
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    if (u == 0x7ff0000000000000ull) return x;
+    int k = 0;
+    if (u < 0x0010000000000000ull) { x = x * 18014398509481984.0; u = (uint64_t)__double_as_longlong(x); k = -54; }
+    uint32_t hx = (uint32_t)(u >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    u = ((uint64_t)hx << 32) | (u & 0xffffffffull);
+    double f = __longlong_as_double((long long)u) - 1.0;
+    double hfsq = (0.5 * f) * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    double R = t2 + t1;
+    double dk = (double)k;
+    return __builtin_fma(dk, ln2_hi, (f - (hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo))));
+}
+
+// geoopt artanh: clamp to +-(1-1e-7), 0.5*(log(1+z) - log(1-z)) in float64
+__device__ __forceinline__ double artanh_clamped(double z)
+{
+    const double lim = 1.0 - 1e-7;
+    if (z > lim) z = lim;
+    if (z < -lim) z = -lim;
+    return (det_log(1.0 + z) - det_log(1.0 - z)) * 0.5;
+}
+
+// geoopt dist0 = 2 * artan_k(||x||), k = -c:  ks = sqrt(|k| + 1e-15), rks = 1/ks (host doubles)
+__device__ __forceinline__ double dist0_from_ssq(double ssq, double ks, double rks)
+{
+    return 2.0 * (rks * artanh_clamped(__builtin_sqrt(ssq) * ks));
+}
+// float32 tensor: norm, scaling and clamp stay in float32, the logs run in float64
+__device__ __forceinline__ float dist0_from_ssq(float ssq, double ks, double rks)
+{
+    float n = __builtin_sqrtf(ssq);
+    float z = n * (float)ks;
+    const float lim = (float)(1.0 - 1e-7);
+    if (z > lim) z = lim;
+    if (z < -lim) z = -lim;
+    double zd = (double)z;
+    float a = (float)((det_log(1.0 + zd) - det_log(1.0 - zd)) * 0.5);
+    return 2.0f * ((float)rks * a);
+}
+
+}  // namespace halo

@@ -1,0 +1,311 @@
+// Hyperbolic head ops for gfx950: HyperMapper.{expmap,logmap,poincare_distance[_origin]} and
+// HyperMLR._hyper_logits (core/utils/hyperbolic.py:16-188; arithmetic = geoopt's
+// stereographic/math.py with k = -c), plus the align_corners bilinear resize the head tails and
+// RegionSelection apply (core/models/classifier.py:375-377,556-557; core/active/build.py:123-135).
+//
+// Tensors are viewed as (outer, C, inner) with the reduction over C, so the NCHW dim=1 case
+// (inner = H*W: consecutive lanes read consecutive pixels of one channel plane, coalesced) and
+// the last-dim case (inner = 1) share one kernel.
+#include "halo_common.hpp"
+#include "halo_devmath.hpp"
+
+namespace halo {
+
+constexpr int HTPB = 256;
+
+template <typename T> __device__ __forceinline__ double ld_as_f64(const T *p) { return (double)*p; }
+
+// ---------------------------------------------------------------- expmap0 + project  (hyperbolic.py:37-38)
+template <typename TIN>
+__global__ void __launch_bounds__(HTPB) k_expmap0_project(const TIN *__restrict__ x, double *__restrict__ y, long long outer,
+                                                          int C, long long inner, double ks, double rks, double maxnorm)
+{
+    const long long idx = (long long)blockIdx.x * HTPB + threadIdx.x;
+    if (idx >= outer * inner) return;
+    const long long o = idx / inner, i = idx % inner;
+    const TIN *xp = x + (size_t)o * C * inner + i;
+    double *yp = y + (size_t)o * C * inner + i;
+    double ssq = 0.0;
+    for (int ch = 0; ch < C; ++ch) { const double v = ld_as_f64(xp + (size_t)ch * inner); ssq = __builtin_fma(v, v, ssq); }
+    double n = __builtin_sqrt(ssq);
+    n = n < 1e-15 ? 1e-15 : n;                               // clamp_min(1e-15)
+    double a = n * ks;
+    a = a > 15.0 ? 15.0 : (a < -15.0 ? -15.0 : a);           // geoopt tanh clamp
+    const double g = rks * tanh(a);                          // tan_k(u_norm, k)
+    double s2 = 0.0;
+    for (int ch = 0; ch < C; ++ch) {
+        const double v = g * (ld_as_f64(xp + (size_t)ch * inner) / n);
+        yp[(size_t)ch * inner] = v;
+        s2 = __builtin_fma(v, v, s2);
+    }
+    double ny = __builtin_sqrt(s2);
+    ny = ny < 1e-15 ? 1e-15 : ny;
+    if (ny > maxnorm)                                        // project: eps = 1e-5 for float64
+        for (int ch = 0; ch < C; ++ch) yp[(size_t)ch * inner] = yp[(size_t)ch * inner] / ny * maxnorm;
+}
+
+// ---------------------------------------------------------------- logmap0 + project  (hyperbolic.py:60)
+__global__ void __launch_bounds__(HTPB) k_logmap0_project(const double *__restrict__ x, double *__restrict__ y, long long outer,
+                                                          int C, long long inner, double ks, double rks, double maxnorm)
+{
+    const long long idx = (long long)blockIdx.x * HTPB + threadIdx.x;
+    if (idx >= outer * inner) return;
+    const long long o = idx / inner, i = idx % inner;
+    const double *xp = x + (size_t)o * C * inner + i;
+    double *yp = y + (size_t)o * C * inner + i;
+    double ssq = 0.0;
+    for (int ch = 0; ch < C; ++ch) { const double v = xp[(size_t)ch * inner]; ssq = __builtin_fma(v, v, ssq); }
+    double n = __builtin_sqrt(ssq);
+    n = n < 1e-15 ? 1e-15 : n;
+    const double g = rks * artanh_clamped(n * ks);
+    double s2 = 0.0;
+    for (int ch = 0; ch < C; ++ch) {
+        const double v = (xp[(size_t)ch * inner] / n) * g;
+        yp[(size_t)ch * inner] = v;
+        s2 = __builtin_fma(v, v, s2);
+    }
+    double ny = __builtin_sqrt(s2);
+    ny = ny < 1e-15 ? 1e-15 : ny;
+    if (ny > maxnorm)
+        for (int ch = 0; ch < C; ++ch) yp[(size_t)ch * inner] = yp[(size_t)ch * inner] / ny * maxnorm;
+}
+
+// ---------------------------------------------------------------- dist0  (hyperbolic.py:83)
+template <typename T>
+__global__ void __launch_bounds__(HTPB) k_dist0(const T *__restrict__ x, T *__restrict__ out, long long outer, int C,
+                                                long long inner, double ks, double rks)
+{
+    const long long idx = (long long)blockIdx.x * HTPB + threadIdx.x;
+    if (idx >= outer * inner) return;
+    const long long o = idx / inner, i = idx % inner;
+    const T *xp = x + (size_t)o * C * inner + i;
+    T ssq = (T)0;
+    for (int ch = 0; ch < C; ++ch) {
+        const T v = xp[(size_t)ch * inner];
+        if constexpr (sizeof(T) == 8) ssq = __builtin_fma(v, v, ssq); else ssq = __builtin_fmaf(v, v, ssq);
+    }
+    out[idx] = dist0_from_ssq(ssq, ks, rks);
+}
+
+// ---------------------------------------------------------------- dist(x, y) over the last dim  (hyperbolic.py:72)
+__global__ void __launch_bounds__(HTPB) k_pdist(const double *__restrict__ x, const double *__restrict__ y,
+                                                double *__restrict__ out, long long n, int d, double k, double ks, double rks)
+{
+    const long long r = (long long)blockIdx.x * HTPB + threadIdx.x;
+    if (r >= n) return;
+    const double *a = x + (size_t)r * d, *b = y + (size_t)r * d;
+    double x2 = 0, y2 = 0, xy = 0;
+    for (int j = 0; j < d; ++j) {
+        const double u = -a[j], v = b[j];
+        x2 = __builtin_fma(u, u, x2); y2 = __builtin_fma(v, v, y2); xy = __builtin_fma(u, v, xy);
+    }
+    const double ca = 1.0 - 2.0 * k * xy - k * y2, cb = 1.0 + k * x2;
+    double den = 1.0 - 2.0 * k * xy + k * k * x2 * y2;
+    den = den < 1e-15 ? 1e-15 : den;
+    double s2 = 0;
+    for (int j = 0; j < d; ++j) { const double m = (ca * (-a[j]) + cb * b[j]) / den; s2 = __builtin_fma(m, m, s2); }
+    out[r] = 2.0 * (rks * artanh_clamped(__builtin_sqrt(s2) * ks));
+}
+
+// ---------------------------------------------------------------- HyperMLR  (hyperbolic.py:120-184)
+// prep: per class  pp = ||P||^2 (as sqrt then square), anorm = ||A||, An = A / max(anorm,1e-12), pa = <-P, An>
+// consts layout: [O] pp | [O] anorm | [O] pa | [O*C] An | [O*C] negP
+__global__ void __launch_bounds__(64) k_mlr_prep(const double *__restrict__ P, const double *__restrict__ A, int O, int C,
+                                                 double *__restrict__ consts)
+{
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    if (o >= O) return;
+    double sp = 0, sa = 0;
+    for (int j = 0; j < C; ++j) { sp = __builtin_fma(P[o * C + j], P[o * C + j], sp); sa = __builtin_fma(A[o * C + j], A[o * C + j], sa); }
+    const double np_ = __builtin_sqrt(sp);
+    const double an = __builtin_sqrt(sa);
+    const double dn = an < 1e-12 ? 1e-12 : an;
+    double *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    double s = 0;
+    for (int j = 0; j < C; ++j) {
+        const double v = A[o * C + j] / dn;
+        An[o * C + j] = v;
+        nP[o * C + j] = -P[o * C + j];
+        s = __builtin_fma(-P[o * C + j], v, s);
+    }
+    consts[o] = np_ * np_;
+    consts[O + o] = an;
+    consts[2 * O + o] = s;
+}
+
+__device__ __forceinline__ double clamp_min_nanprop(double v, double lo) { return (v != v) ? v : (v < lo ? lo : v); }
+
+// One pixel per lane; the 2*O prototype rows are read as wave-uniform (scalar) loads; OB classes per pass.
+template <int OB, typename TOUT>
+__global__ void __launch_bounds__(HTPB) k_hypermlr(const double *__restrict__ x, const double *__restrict__ consts, int O, int C,
+                                                   long long hw, double K, TOUT *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * HTPB + threadIdx.x;
+    if (i >= hw) return;
+    const double *xb = x + (size_t)b * C * hw + i;
+    const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    double ssq = 0.0;
+    for (int j = 0; j < C; ++j) { const double v = xb[(size_t)j * hw]; ssq = __builtin_fma(v, v, ssq); }
+    const double nx = __builtin_sqrt(ssq), xx = nx * nx;
+    const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
+    for (int o0 = 0; o0 < O; o0 += OB) {
+        double px[OB], xa[OB];
+#pragma unroll
+        for (int q = 0; q < OB; ++q) { px[q] = 0.0; xa[q] = 0.0; }
+        for (int j = 0; j < C; ++j) {
+            const double v = xb[(size_t)j * hw];
+#pragma unroll
+            for (int q = 0; q < OB; ++q) {
+                const int o = o0 + q < O ? o0 + q : O - 1;
+                px[q] = __builtin_fma(v, nP[(size_t)o * C + j], px[q]);
+                xa[q] = __builtin_fma(v, An[(size_t)o * C + j], xa[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < OB; ++q) {
+            const int o = o0 + q;
+            if (o >= O) break;
+            const double ppo = pp[o];
+            const double sqsq = ((K * xx) * K) * ppo;
+            const double Aa = (1.0 + (2.0 * K) * px[q]) + K * xx;
+            const double Bb = 1.0 - K * ppo;
+            const double D = clamp_min_nanprop((1.0 + (2.0 * K) * px[q]) + sqsq, 1e-12);
+            const double al = Aa / D, be = Bb / D;
+            const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px[q];
+            const double sq = __builtin_sqrt(mob);
+            const double pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;
+            const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
+            const double md = (be * xa[q] + al * pa[o]) * pn;
+            const double lamb = 2.0 / clamp_min_nanprop(1.0 - K * mp, 1e-12);
+            const double sine = (sqK * md) * lamb;
+            out[((size_t)b * O + o) * hw + i] = (TOUT)(((2.0 / sqK) * anorm[o]) * asinh(sine));
+        }
+    }
+}
+
+// ---------------------------------------------------------------- bilinear, align_corners=True
+// out = fma(v11,w11, fma(v10,w10, fma(v00,w00, v01*w01))), w_ij = ly_i*lx_j, weights in the tensor's dtype
+template <typename T>
+__global__ void __launch_bounds__(HTPB) k_bilinear(const T *__restrict__ src, T *__restrict__ dst, long long planes, int h, int w,
+                                                   int H, int W, T sh, T sw)
+{
+    const long long idx = (long long)blockIdx.x * HTPB + threadIdx.x;
+    const long long per = (long long)H * W;
+    if (idx >= planes * per) return;
+    const long long p = idx / per;
+    const int y = (int)((idx % per) / W), x = (int)(idx % W);
+    const T fy = sh * (T)y, fx = sw * (T)x;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 > h - 1 ? h - 1 : y0;
+    x0 = x0 > w - 1 ? w - 1 : x0;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const T ly1 = fy - (T)y0, ly0 = (T)1 - ly1, lx1 = fx - (T)x0, lx0 = (T)1 - lx1;
+    const T *r0 = src + ((size_t)p * h + y0) * w, *r1 = src + ((size_t)p * h + y1) * w;
+    T a = r0[x1] * (ly0 * lx1);
+    if constexpr (sizeof(T) == 8) {
+        a = __builtin_fma(r0[x0], ly0 * lx0, a);
+        a = __builtin_fma(r1[x0], ly1 * lx0, a);
+        a = __builtin_fma(r1[x1], ly1 * lx1, a);
+    } else {
+        a = __builtin_fmaf(r0[x0], ly0 * lx0, a);
+        a = __builtin_fmaf(r1[x0], ly1 * lx0, a);
+        a = __builtin_fmaf(r1[x1], ly1 * lx1, a);
+    }
+    dst[idx] = a;
+}
+
+}  // namespace halo
+
+using namespace halo;
+
+static inline unsigned nblocks(long long n) { return (unsigned)cdiv(n, HTPB); }
+
+extern "C" int halo_expmap0_project(const void *x, int x_dtype, double *y, int64_t outer, int64_t C, int64_t inner, double c,
+                                    void *stream)
+{
+    if (!x || !y || outer <= 0 || C <= 0 || inner <= 0) return fail(HALO_E_ARG, "halo_expmap0_project: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_expmap0_project: curvature must be > 0 (Poincare ball)");
+    const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks, maxnorm = (1.0 - 1e-5) / sqrt(fabs(-c) + 1e-15);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == HALO_F32)
+        hipLaunchKernelGGL((k_expmap0_project<float>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const float *)x, y, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
+    else if (x_dtype == HALO_F64)
+        hipLaunchKernelGGL((k_expmap0_project<double>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const double *)x, y, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
+    else return fail(HALO_E_ARG, "halo_expmap0_project: bad dtype");
+    return check_launch("halo_expmap0_project");
+}
+
+extern "C" int halo_logmap0_project(const double *x, double *y, int64_t outer, int64_t C, int64_t inner, double c, void *stream)
+{
+    if (!x || !y || outer <= 0 || C <= 0 || inner <= 0) return fail(HALO_E_ARG, "halo_logmap0_project: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_logmap0_project: curvature must be > 0");
+    const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks, maxnorm = (1.0 - 1e-5) / sqrt(fabs(-c) + 1e-15);
+    hipLaunchKernelGGL(k_logmap0_project, dim3(nblocks(outer * inner)), dim3(HTPB), 0, (hipStream_t)stream, x, y, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
+    return check_launch("halo_logmap0_project");
+}
+
+extern "C" int halo_dist0(const void *x, int dtype, void *out, int64_t outer, int64_t C, int64_t inner, double c, void *stream)
+{
+    if (!x || !out || outer <= 0 || C <= 0 || inner <= 0) return fail(HALO_E_ARG, "halo_dist0: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_dist0: curvature must be > 0");
+    const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HALO_F64)
+        hipLaunchKernelGGL((k_dist0<double>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const double *)x, (double *)out, (long long)outer, (int)C, (long long)inner, ks, rks);
+    else if (dtype == HALO_F32)
+        hipLaunchKernelGGL((k_dist0<float>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const float *)x, (float *)out, (long long)outer, (int)C, (long long)inner, ks, rks);
+    else return fail(HALO_E_ARG, "halo_dist0: bad dtype");
+    return check_launch("halo_dist0");
+}
+
+extern "C" int halo_pdist(const double *x, const double *y, double *out, int64_t n, int64_t d, double c, void *stream)
+{
+    if (!x || !y || !out || n <= 0 || d <= 0) return fail(HALO_E_ARG, "halo_pdist: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_pdist: curvature must be > 0");
+    const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks;
+    hipLaunchKernelGGL(k_pdist, dim3(nblocks(n)), dim3(HTPB), 0, (hipStream_t)stream, x, y, out, (long long)n, (int)d, -c, ks, rks);
+    return check_launch("halo_pdist");
+}
+
+extern "C" size_t halo_hypermlr_workspace_bytes(int64_t O, int64_t C)
+{
+    if (O <= 0 || C <= 0) return 0;
+    return (size_t)(3 * O + 2 * O * C) * sizeof(double) + 256;
+}
+
+extern "C" int halo_hypermlr_logits(const double *x, const double *P, const double *A, void *out, int out_dtype, int64_t B,
+                                    int64_t C, int64_t O, int64_t hw, double c, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    if (!x || !P || !A || !out || B <= 0 || C <= 0 || O <= 0 || hw <= 0) return fail(HALO_E_ARG, "halo_hypermlr_logits: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_hypermlr_logits: curvature must be > 0");
+    if (!workspace || workspace_bytes < halo_hypermlr_workspace_bytes(O, C)) return fail(HALO_E_WORKSPACE, "halo_hypermlr_logits: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double *consts = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)cdiv(O, 64)), dim3(64), 0, st, P, A, (int)O, (int)C, consts);
+    dim3 grid(nblocks(hw), (unsigned)B);
+    constexpr int OB = 10;
+    if (out_dtype == HALO_F32)
+        hipLaunchKernelGGL((k_hypermlr<OB, float>), grid, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (float *)out);
+    else if (out_dtype == HALO_F64)
+        hipLaunchKernelGGL((k_hypermlr<OB, double>), grid, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (double *)out);
+    else return fail(HALO_E_ARG, "halo_hypermlr_logits: bad out dtype");
+    return check_launch("halo_hypermlr_logits");
+}
+
+extern "C" int halo_bilinear_upsample(const void *src, void *dst, int dtype, int64_t planes, int64_t h, int64_t w, int64_t H,
+                                      int64_t W, void *stream)
+{
+    if (!src || !dst || planes <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_bilinear_upsample: null/empty argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)planes * H * W;
+    if (dtype == HALO_F64) {
+        const double sh = H > 1 ? (double)(h - 1) / (double)(H - 1) : 0.0, sw = W > 1 ? (double)(w - 1) / (double)(W - 1) : 0.0;
+        hipLaunchKernelGGL((k_bilinear<double>), dim3(nblocks(n)), dim3(HTPB), 0, st, (const double *)src, (double *)dst, (long long)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
+    } else if (dtype == HALO_F32) {
+        const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+        hipLaunchKernelGGL((k_bilinear<float>), dim3(nblocks(n)), dim3(HTPB), 0, st, (const float *)src, (float *)dst, (long long)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
+    } else return fail(HALO_E_ARG, "halo_bilinear_upsample: bad dtype");
+    return check_launch("halo_bilinear_upsample");
+}

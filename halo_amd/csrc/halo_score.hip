@@ -1,0 +1,553 @@
+// FloatingRegionScore.forward as HIP kernels for gfx950 (core/active/floating_region.py:129-217).
+//
+// Data flow for one batch of B images (everything stays in HBM between kernels, no host sync):
+//
+//   logit (B,O,H,W) f32 --k_logit_maps--> ent (B,H,W) f32 [, pred i16]
+//   feat  (B,C,H,W) T   --k_feat_reduce-> imp_raw (B,H,W) T  + per-block min/max      <- HBM roofline kernel
+//   [hyper]  imp_raw --k_quantize--> pred ;  pred --k_region_impurity--> imp_raw f32
+//   ent --k_box_unc--> unc_raw f32 + per-block min/max
+//   partial min/max --k_minmax_finalize--> stats[b] = {imp_min, imp_max, unc_min, unc_max}
+//   imp_raw, unc_raw, stats [, active] --k_combine--> impurity, uncertainty, score
+//
+// k_feat_reduce is the only kernel that touches the C x H x W tensor: each lane owns 16 bytes
+// of consecutive pixels (2 x f64 / 4 x f32), walks the C channel planes with 16-byte
+// coalesced loads (a wave reads 1 KiB contiguous per plane) and keeps the running sum of
+// squares in registers -- one fma chain per pixel in channel order, which is also bit for bit
+// what ATen's CPU norm(dim=1) computes.  Algorithmic traffic: C*sizeof(T) bytes per pixel.
+#include "halo_common.hpp"
+#include "halo_devmath.hpp"
+
+namespace halo {
+
+constexpr int TPB = 256;
+
+// ---------------------------------------------------------------- reductions
+// torch .min()/.max() propagate NaN: once a NaN is seen the result is NaN.
+__device__ __forceinline__ double nan_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+__device__ __forceinline__ double nan_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+
+__device__ __forceinline__ void block_minmax(double mn, double mx, double *out2)
+{
+    __shared__ double smn[TPB / 64], smx[TPB / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = nan_min(mn, __shfl_xor(mn, off));
+        mx = nan_max(mx, __shfl_xor(mx, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smn[wave] = mn; smx[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < TPB / 64; ++i) { mn = nan_min(mn, smn[i]); mx = nan_max(mx, smx[i]); }
+        out2[0] = mn;
+        out2[1] = mx;
+    }
+}
+
+// partials (B, nblk, 2) -> stats[b*4 + slot*2 + {0,1}]
+__global__ void __launch_bounds__(TPB) k_minmax_finalize(const double *__restrict__ partials, int nblk,
+                                                          double *__restrict__ stats, int slot)
+{
+    const int b = blockIdx.x;
+    const double *p = partials + (size_t)b * nblk * 2;
+    double mn = p[0], mx = p[1];
+    for (int i = threadIdx.x; i < nblk; i += TPB) { mn = nan_min(mn, p[2 * i]); mx = nan_max(mx, p[2 * i + 1]); }
+    block_minmax(mn, mx, stats + b * 4 + slot * 2);
+}
+
+// ---------------------------------------------------------------- logits -> entropy / prediction
+template <int O_T>
+__device__ __forceinline__ void softmax_regs(float (&p)[O_T])
+{
+    float m = p[0];
+#pragma unroll
+    for (int c = 1; c < O_T; ++c) m = p[c] > m ? p[c] : m;
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < O_T; ++c) { p[c] = det_expf(p[c] - m); s = s + p[c]; }
+#pragma unroll
+    for (int c = 0; c < O_T; ++c) p[c] = p[c] / s;
+}
+
+// One pixel, classes in registers.  Writes ent (per unc_type) and pred (per pur_type).
+template <int O_T>
+__device__ __forceinline__ void logit_px(float (&p)[O_T], int unc_type, int pur_type, long long g,
+                                         float inv_dummy, float &ent, int &pred)
+{
+    softmax_regs<O_T>(p);
+    int am = 0;               // torch.argmax: first maximal class
+    float best = p[0];
+#pragma unroll
+    for (int c = 1; c < O_T; ++c) { const bool gtb = p[c] > best; am = gtb ? c : am; best = gtb ? p[c] : best; }
+    (void)inv_dummy;
+    if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) {
+        float a = 0.0f;
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) a = a + (-p[c]) * det_logf(p[c] + 1e-6f);
+        ent = a / (float)2.9444389791664403;   // math.log(19): hard-coded in the reference (:74-76)
+    } else if (unc_type == HALO_UNC_ORACLE_ACC) {
+        const int gi = g == 255 ? am : (int)g;
+        float pg = 0.0f;
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) pg = c == gi ? p[c] : pg;
+        ent = 1.0f - pg;
+    } else {
+        ent = 0.0f;
+    }
+    pred = pur_type == HALO_PUR_ORACLE_RIPU ? (g == 255 ? am : (int)g) : am;
+}
+
+template <int O_T, int VEC>
+__global__ void __launch_bounds__(TPB) k_logit_maps(const float *__restrict__ logit, long long bstride,
+                                                    const long long *__restrict__ gt, long long hw,
+                                                    int unc_type, int pur_type, float *__restrict__ ent,
+                                                    short *__restrict__ pred)
+{
+    const int b = blockIdx.y;
+    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * VEC;
+    if (i0 >= hw) return;
+    const float *lp = logit + (size_t)b * bstride + i0;
+    const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
+    float v[VEC][O_T];
+    if constexpr (VEC == 4) {
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) {
+            const float4 q = *reinterpret_cast<const float4 *>(lp + (size_t)c * hw);
+            v[0][c] = q.x; v[1][c] = q.y; v[2][c] = q.z; v[3][c] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) v[0][c] = lp[(size_t)c * hw];
+    }
+    float e[VEC];
+    int pr[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const long long g = need_gt ? gt[(size_t)b * hw + i0 + j] : 0;
+        logit_px<O_T>(v[j], unc_type, pur_type, g, 0.0f, e[j], pr[j]);
+    }
+    float *ep = ent + (size_t)b * hw + i0;
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(ep) = make_float4(e[0], e[1], e[2], e[3]);
+    } else {
+        ep[0] = e[0];
+    }
+    if (pred) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) pred[(size_t)b * hw + i0 + j] = (short)pr[j];
+    }
+}
+
+// Any class count: three passes over the O planes (coalesced scalar loads, L2-resident tile).
+__global__ void __launch_bounds__(TPB) k_logit_maps_generic(const float *__restrict__ logit, long long bstride,
+                                                            const long long *__restrict__ gt, int O, long long hw,
+                                                            int unc_type, int pur_type, float *__restrict__ ent,
+                                                            short *__restrict__ pred)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= hw) return;
+    const float *lp = logit + (size_t)b * bstride + i;
+    float m = lp[0];
+    for (int c = 1; c < O; ++c) { float x = lp[(size_t)c * hw]; m = x > m ? x : m; }
+    float s = 0.0f;
+    for (int c = 0; c < O; ++c) s = s + det_expf(lp[(size_t)c * hw] - m);
+    const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
+    const long long g = need_gt ? gt[(size_t)b * hw + i] : 0;
+    float a = 0.0f, best = 0.0f, pg = 0.0f;
+    int am = 0;
+    for (int c = 0; c < O; ++c) {
+        const float p = det_expf(lp[(size_t)c * hw] - m) / s;
+        if (c == 0 || p > best) { best = p; am = c; }
+        if (c == (int)g) pg = p;
+        a = a + (-p) * det_logf(p + 1e-6f);
+    }
+    float e;
+    if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) e = a / (float)2.9444389791664403;
+    else if (unc_type == HALO_UNC_ORACLE_ACC) {
+        if (g == 255) pg = best;
+        e = 1.0f - pg;
+    } else e = 0.0f;
+    ent[(size_t)b * hw + i] = e;
+    if (pred) pred[(size_t)b * hw + i] = (short)(pur_type == HALO_PUR_ORACLE_RIPU ? (g == 255 ? am : (int)g) : am);
+}
+
+// ---------------------------------------------------------------- features -> radius / norm (HBM roofline)
+template <typename T> struct AccOf;
+template <> struct AccOf<double> { using type = double; };
+template <> struct AccOf<float> { using type = float; };
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T, int VEC> struct VecLoad;
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+template <> struct VecLoad<double, 2> {
+    static __device__ __forceinline__ void ld(const double *p, double (&v)[2])
+    {
+        const d2_t q = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p));   // streamed once
+        v[0] = q.x; v[1] = q.y;
+    }
+};
+template <> struct VecLoad<float, 4> {
+    static __device__ __forceinline__ void ld(const float *p, float (&v)[4])
+    {
+        const f4_t q = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(p));
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+};
+template <typename T> struct VecLoad<T, 1> {
+    static __device__ __forceinline__ void ld(const T *p, T (&v)[1]) { v[0] = *p; }
+};
+
+// MODE 0: poincare_distance_origin (pur 'radius' / 'hyper'), MODE 1: decoder_out.norm(dim=1) ('euc_norm')
+template <typename T, int VEC, int MODE, int UNROLL>
+__global__ void __launch_bounds__(TPB) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
+                                                     long long hw, double ks, double rks, T *__restrict__ out,
+                                                     double *__restrict__ partials)
+{
+    const int b = blockIdx.y;
+    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * VEC;
+    const bool live = i0 < hw;
+    T acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = (T)0;
+    double mn = 0.0, mx = 0.0;
+    if (live) {
+        const T *p = feat + (size_t)b * bstride + i0;
+        int c = 0;
+        for (; c + UNROLL <= C; c += UNROLL) {
+            T v[UNROLL][VEC];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) VecLoad<T, VEC>::ld(p + (size_t)(c + u) * hw, v[u]);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = fma_t(v[u][j], v[u][j], acc[j]);
+        }
+        for (; c < C; ++c) {
+            T v[VEC];
+            VecLoad<T, VEC>::ld(p + (size_t)c * hw, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = fma_t(v[j], v[j], acc[j]);
+        }
+        T r[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if constexpr (MODE == 0) r[j] = dist0_from_ssq(acc[j], ks, rks);
+            else if constexpr (sizeof(T) == 8) r[j] = __builtin_sqrt(acc[j]);
+            else r[j] = __builtin_sqrtf(acc[j]);
+        }
+        T *op = out + (size_t)b * hw + i0;
+        if constexpr (VEC == 2) *reinterpret_cast<double2 *>(op) = make_double2(r[0], r[1]);
+        else if constexpr (VEC == 4) *reinterpret_cast<float4 *>(op) = make_float4(r[0], r[1], r[2], r[3]);
+        else op[0] = r[0];
+        mn = mx = (double)r[0];
+#pragma unroll
+        for (int j = 1; j < VEC; ++j) { mn = nan_min(mn, (double)r[j]); mx = nan_max(mx, (double)r[j]); }
+    }
+    // dead lanes of the last block take thread 0's value (always live) so they cannot disturb min/max
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
+    __syncthreads();
+    if (!live) { mn = seed[0]; mx = seed[1]; }
+    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
+// ---------------------------------------------------------------- quantize_uncert_map (floating_region.py:94-110)
+// r -> (r-min)/(max-min) -> 1-x -> (second min-max: exact no-op, min 0 / max 1) -> x*K-0.5 -> clamp -> round-half-even
+template <typename T>
+__global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const double *__restrict__ stats,
+                                                  long long hw, int K, short *__restrict__ pred)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= hw) return;
+    const T mn = (T)stats[b * 4 + 0], mx = (T)stats[b * 4 + 1];
+    T x;
+    if constexpr (sizeof(T) == 8) {
+        x = (r[(size_t)b * hw + i] - mn) / (mx - mn);
+        x = 1.0 - x;
+        double p = x * (double)K - 0.5;
+        const double lo = -0.5 + 1e-5, hi = (double)K - 0.5 - 1e-5;
+        p = p < lo ? lo : p;
+        p = p > hi ? hi : p;
+        pred[(size_t)b * hw + i] = (short)__builtin_rint(p);
+    } else {
+        const float den = (float)((double)mx - (double)mn);
+        x = (r[(size_t)b * hw + i] - mn) / den;
+        x = 1.0f - x;
+        float p = x * (float)K - 0.5f;
+        const float lo = (float)(-0.5 + 1e-5), hi = (float)((double)K - 0.5 - 1e-5);
+        p = p < lo ? lo : p;
+        p = p > hi ? hi : p;
+        pred[(size_t)b * hw + i] = (short)__builtin_rintf(p);
+    }
+}
+
+// ---------------------------------------------------------------- compute_region_impurity (floating_region.py:112-121)
+// Window class histogram -> sum_c -d*log(d+1e-6) / log(K), classes visited in ascending order
+// (= the reference's sum over the one-hot channel axis; empty classes contribute exactly 0).
+// No one-hot tensor: the <= k*k window labels are re-scanned once per distinct class.
+__global__ void __launch_bounds__(TPB) k_region_impurity(const short *__restrict__ pred, int H, int W, int k,
+                                                         float logK, float *__restrict__ imp)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)H * W;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= hw) return;
+    const int y = (int)(i / W), x = (int)(i % W), r = k / 2;
+    const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+    const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+    const short *pp = pred + (size_t)b * hw;
+    const float cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+    float a = 0.0f;
+    int cur = -1;
+    while (true) {
+        int nxt = 0x7fffffff, n = 0;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+                const int v = pp[(size_t)yy * W + xx];
+                if (v > cur) {
+                    if (v < nxt) { nxt = v; n = 1; }
+                    else if (v == nxt) ++n;
+                }
+            }
+        if (n == 0) break;
+        const float d = (float)n / cnt;
+        a = a + (-d) * det_logf(d + 1e-6f);
+        cur = nxt;
+    }
+    imp[(size_t)b * hw + i] = a / logK;
+}
+
+// ---------------------------------------------------------------- entropy_conv + /count (floating_region.py:42-51,90,204)
+// k x k all-ones box SUM with zero padding, taps added in row-major order starting from +0.
+// count = in-bounds size of the pk x pk purity window for ripu / oracle_ripu / hyper, else 1.
+__global__ void __launch_bounds__(TPB) k_box_unc(const float *__restrict__ ent, int H, int W, int k, int do_box,
+                                                 int pk, float *__restrict__ unc, double *__restrict__ partials)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)H * W;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool live = i < hw;
+    double mn = 0.0, mx = 0.0;
+    if (live) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        const float *ep = ent + (size_t)b * hw;
+        float a;
+        if (do_box) {
+            const int r = k / 2;
+            a = 0.0f;
+            for (int dy = -r; dy <= r; ++dy)
+                for (int dx = -r; dx <= r; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ep[(size_t)yy * W + xx] : 0.0f;
+                    a = a + v;
+                }
+        } else {
+            a = ep[i];
+        }
+        float cnt = 1.0f;
+        if (pk > 0) {
+            const int r = pk / 2;
+            const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+            const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+            cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+        }
+        a = a / cnt;
+        unc[(size_t)b * hw + i] = a;
+        mn = mx = (double)a;
+    }
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
+    __syncthreads();
+    if (!live) { mn = seed[0]; mx = seed[1]; }
+    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
+// per-block min/max of an existing f32 map (impurity of the histogram branches)
+__global__ void __launch_bounds__(TPB) k_minmax_f32(const float *__restrict__ x, long long hw,
+                                                    double *__restrict__ partials)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool live = i < hw;
+    double mn = 0.0, mx = 0.0;
+    if (live) mn = mx = (double)x[(size_t)b * hw + i];
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
+    __syncthreads();
+    if (!live) { mn = seed[0]; mx = seed[1]; }
+    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
+__global__ void __launch_bounds__(TPB) k_fill_f32(float *__restrict__ x, long long n, float v)
+{
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+// ---------------------------------------------------------------- normalize_map + product (+ prior-pick mask)
+// (floating_region.py:22-23,206-210; core/active/build.py:146)
+template <typename TI>
+__global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw, const float *__restrict__ unc_raw,
+                                                 const double *__restrict__ stats, const unsigned char *__restrict__ active,
+                                                 long long hw, int normalize, TI *__restrict__ score,
+                                                 TI *__restrict__ imp_out, float *__restrict__ unc_out)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= hw) return;
+    const size_t o = (size_t)b * hw + i;
+    TI im = imp_raw[o];
+    float un = unc_raw[o];
+    if (normalize) {
+        const float umn = (float)stats[b * 4 + 2], umx = (float)stats[b * 4 + 3];
+        un = (un - umn) / (float)((double)umx - (double)umn);
+        const TI imn = (TI)stats[b * 4 + 0], imx = (TI)stats[b * 4 + 1];
+        if constexpr (sizeof(TI) == 8) im = (im - imn) / (imx - imn);
+        else im = (im - imn) / (float)((double)imx - (double)imn);
+    }
+    TI s = im * (TI)un;
+    if (active && active[o]) {
+        if constexpr (sizeof(TI) == 8) s = __longlong_as_double(0xfff0000000000000ll);
+        else s = __uint_as_float(0xff800000u);
+    }
+    score[o] = s;
+    if (imp_out) imp_out[o] = im;
+    if (unc_out) unc_out[o] = un;
+}
+
+// ---------------------------------------------------------------- host side
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+template <typename T, int VEC>
+static void launch_feat(const T *feat, long long bstride, int C, long long hw, int B, int mode, double ks, double rks,
+                        T *out, double *partials, int nblk, hipStream_t st)
+{
+    dim3 grid(nblk, B), block(TPB);
+    constexpr int UNROLL = 8;
+    if (mode == 0) hipLaunchKernelGGL((k_feat_reduce<T, VEC, 0, UNROLL>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, partials);
+    else hipLaunchKernelGGL((k_feat_reduce<T, VEC, 1, UNROLL>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, partials);
+}
+
+}  // namespace halo
+
+using namespace halo;
+
+extern "C" size_t halo_score_workspace_bytes(int64_t B, int64_t H, int64_t W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t n = (size_t)B * H * W;
+    const size_t nblk = (size_t)cdiv(H * W, TPB);
+    size_t s = 0;
+    s += align_up(n * 4, 256);                   // ent
+    s += align_up(n * 4, 256);                   // unc_raw
+    s += align_up(n * 8, 256);                   // imp_raw
+    s += align_up(n * 2, 256);                   // pred
+    s += 2 * align_up((size_t)B * nblk * 2 * 8, 256);  // partials (imp, unc)
+    s += align_up((size_t)B * 4 * 8, 256);       // stats
+    return s + 1024;
+}
+
+extern "C" int halo_score_maps(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                               int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                               int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                               int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
+    if (unc_type < 0 || unc_type > HALO_UNC_ZEROS) return fail(HALO_E_ARG, "halo_score_maps: bad unc_type %d", unc_type);
+    if (pur_type < 0 || pur_type > HALO_PUR_EUC_NORM) return fail(HALO_E_UNSUPPORTED, "Error: purity type '%d' not implemented", pur_type);
+    if (ksize < 1 || !(ksize & 1) || pksize < 1 || !(pksize & 1)) return fail(HALO_E_ARG, "halo_score_maps: window sizes must be odd");
+    const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
+    if (need_feat && (!feat || C <= 0)) return fail(HALO_E_ARG, "halo_score_maps: decoder_out required for this purity type");
+    if (need_feat && feat_dtype != HALO_F32 && feat_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_score_maps: bad feat dtype");
+    const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
+    if (need_gt && !gt) return fail(HALO_E_ARG, "halo_score_maps: ground_truth required");
+    if (pur_type == HALO_PUR_HYPER && (K < 1 || K > 32767)) return fail(HALO_E_UNSUPPORTED, "halo_score_maps: K out of range");
+    if (O > 32767) return fail(HALO_E_UNSUPPORTED, "halo_score_maps: too many classes");
+    if (workspace_bytes < halo_score_workspace_bytes(B, H, W) || !workspace) return fail(HALO_E_WORKSPACE, "halo_score_maps: workspace too small");
+
+    const long long hw = (long long)H * W;
+    const int nblk1 = (int)cdiv(hw, TPB);
+    Arena ar(workspace, workspace_bytes);
+    float *ent = ar.take<float>((size_t)B * hw);
+    float *unc_raw = ar.take<float>((size_t)B * hw);
+    double *imp_raw = ar.take<double>((size_t)B * hw);
+    short *pred = ar.take<short>((size_t)B * hw);
+    double *part_imp = ar.take<double>((size_t)B * nblk1 * 2);
+    double *part_unc = ar.take<double>((size_t)B * nblk1 * 2);
+    double *stats = ar.take<double>((size_t)B * 4);
+    if (!ar.ok()) return fail(HALO_E_WORKSPACE, "halo_score_maps: workspace too small");
+
+    const bool f64out = (pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM) && feat_dtype == HALO_F64;
+    const bool hist = pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU || pur_type == HALO_PUR_HYPER;
+    const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks;
+    dim3 block(TPB);
+
+    // ---- logits -> ent (+ pred for ripu / oracle_ripu)
+    const bool need_logit_pass = unc_type != HALO_UNC_ZEROS || pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU;
+    short *pred_from_logits = (pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU) ? pred : nullptr;
+    if (need_logit_pass) {
+        const bool vec4 = (hw % 4 == 0) && (logit_bstride % 4 == 0) && aligned16(logit) && aligned16(ent);
+        if (O == 19 && vec4) {
+            dim3 grid((unsigned)cdiv(hw, TPB * 4), (unsigned)B);
+            hipLaunchKernelGGL((k_logit_maps<19, 4>), grid, block, 0, st, logit, (long long)logit_bstride, (const long long *)gt, hw, unc_type, pur_type, ent, pred_from_logits);
+        } else if (O == 16 && vec4) {
+            dim3 grid((unsigned)cdiv(hw, TPB * 4), (unsigned)B);
+            hipLaunchKernelGGL((k_logit_maps<16, 4>), grid, block, 0, st, logit, (long long)logit_bstride, (const long long *)gt, hw, unc_type, pur_type, ent, pred_from_logits);
+        } else {
+            dim3 grid((unsigned)nblk1, (unsigned)B);
+            hipLaunchKernelGGL(k_logit_maps_generic, grid, block, 0, st, logit, (long long)logit_bstride, (const long long *)gt, (int)O, hw, unc_type, pur_type, ent, pred_from_logits);
+        }
+    } else {
+        hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(B * hw, TPB)), block, 0, st, ent, (long long)(B * hw), 0.0f);
+    }
+
+    // ---- features -> radius / norm  (+ min/max partials)
+    int nblk_imp = nblk1;
+    if (need_feat) {
+        const int mode = pur_type == HALO_PUR_EUC_NORM ? 1 : 0;
+        if (feat_dtype == HALO_F64) {
+            const bool v2 = (hw % 2 == 0) && (feat_bstride % 2 == 0) && aligned16(feat) && aligned16(imp_raw);
+            if (v2) { nblk_imp = (int)cdiv(hw, TPB * 2); launch_feat<double, 2>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st); }
+            else { nblk_imp = nblk1; launch_feat<double, 1>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st); }
+        } else {
+            const bool v4 = (hw % 4 == 0) && (feat_bstride % 4 == 0) && aligned16(feat) && aligned16(imp_raw);
+            if (v4) { nblk_imp = (int)cdiv(hw, TPB * 4); launch_feat<float, 4>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
+            else { nblk_imp = nblk1; launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
+        }
+    }
+    dim3 grid1((unsigned)nblk1, (unsigned)B);
+    if (pur_type == HALO_PUR_HYPER) {
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_imp, nblk_imp, stats, 0);
+        if (feat_dtype == HALO_F64) hipLaunchKernelGGL((k_quantize<double>), grid1, block, 0, st, (const double *)imp_raw, stats, hw, (int)K, pred);
+        else hipLaunchKernelGGL((k_quantize<float>), grid1, block, 0, st, (const float *)imp_raw, stats, hw, (int)K, pred);
+    }
+    if (hist) {
+        const float logK = (float)log((double)(pur_type == HALO_PUR_HYPER ? K : O));
+        hipLaunchKernelGGL(k_region_impurity, grid1, block, 0, st, pred, (int)H, (int)W, pksize, logK, (float *)imp_raw);
+        hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
+        nblk_imp = nblk1;
+    } else if (pur_type == HALO_PUR_NONE) {
+        hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(B * hw, TPB)), block, 0, st, (float *)imp_raw, (long long)(B * hw), 0.0f);
+        hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
+        nblk_imp = nblk1;
+    }
+
+    // ---- box-sum of the uncertainty, / count
+    const int do_box = (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_ORACLE_ACC) ? 1 : 0;
+    hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, ent, (int)H, (int)W, ksize, do_box, hist ? pksize : 0, unc_raw, part_unc);
+
+    // ---- global min/max, then normalise + product
+    hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_imp, nblk_imp, stats, 0);
+    hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_unc, nblk1, stats, 1);
+    if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
+    else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
+    return check_launch("halo_score_maps");
+}

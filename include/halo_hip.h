@@ -1,0 +1,118 @@
+/* halo_hip.h -- C ABI of libhalo_hip.so: HALO's per-pixel hyperbolic acquisition-scoring
+ * path as hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+ *
+ * The reference (paolomandica/HALO) is pure Python on stock PyTorch + geoopt; it has no FFI.
+ * Each entry point below replaces the reference call named in its comment (paths relative to
+ * the reference repository).  The Python classes in halo_amd/core/ bind these through ctypes
+ * (halo_amd/_lib.py); INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()); tensors are dense row-major,
+ *     exactly the reference's layouts: logit (B,O,H,W) f32, decoder_out (B,C,H,W) f64|f32,
+ *     maps (B,H,W); batch strides are passed in ELEMENTS so a caller may hand in views
+ *   - stream is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     one call = asynchronous enqueue on that stream, no allocation, no host sync, no global
+ *     state => re-entrant and hipGraph-capturable
+ *   - scratch comes from the caller: size it with the matching *_workspace_bytes()
+ *   - return 0 on success, <0 on error (HALO_E_*); halo_last_error() gives the message of the
+ *     calling thread's last failure
+ *   - dtype codes: HALO_F32 = 0, HALO_F64 = 1
+ */
+#ifndef HALO_HIP_H
+#define HALO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HALO_ABI_VERSION 1
+
+enum { HALO_F32 = 0, HALO_F64 = 1 };
+
+enum { HALO_OK = 0, HALO_E_ARG = -1, HALO_E_UNSUPPORTED = -2, HALO_E_WORKSPACE = -3, HALO_E_LAUNCH = -4 };
+
+/* unc_type of FloatingRegionScore.forward (core/active/floating_region.py:158-163, 70-92).
+ * Every other string the reference accepts ('none', 'hyperbolic', 'certainty', ...) yields a
+ * zero map (floating_region.py:84-90) => HALO_UNC_ZEROS. */
+enum { HALO_UNC_ENTROPY = 0, HALO_UNC_PIXEL_ENTROPY = 1, HALO_UNC_ORACLE_ACC = 2, HALO_UNC_ZEROS = 3 };
+
+/* pur_type of FloatingRegionScore.forward (floating_region.py:165-202); anything else is the
+ * reference's NotImplementedError and must be rejected by the caller. */
+enum { HALO_PUR_RIPU = 0, HALO_PUR_ORACLE_RIPU = 1, HALO_PUR_HYPER = 2, HALO_PUR_NONE = 3,
+       HALO_PUR_RADIUS = 4, HALO_PUR_EUC_NORM = 5 };
+
+int halo_version(void);
+const char *halo_last_error(void);
+
+/* ---- hyperbolic ops: core/utils/hyperbolic.py (arithmetic = geoopt.manifolds.stereographic.math) ---- */
+
+/* HyperMapper.expmap(x, dim) (hyperbolic.py:28-39): project(expmap0(x.double())).
+ * x viewed as (outer, C, inner), reduced over C; x_dtype F32|F64; y is f64. */
+int halo_expmap0_project(const void *x, int x_dtype, double *y, int64_t outer, int64_t C, int64_t inner,
+                         double c, void *stream);
+
+/* HyperMapper.logmap(x) (hyperbolic.py:51-60): project(logmap0(x.double())), f64 in/out. */
+int halo_logmap0_project(const double *x, double *y, int64_t outer, int64_t C, int64_t inner, double c,
+                         void *stream);
+
+/* HyperMapper.poincare_distance_origin(x, dim) (hyperbolic.py:74-83): geoopt dist0; out dtype = dtype. */
+int halo_dist0(const void *x, int dtype, void *out, int64_t outer, int64_t C, int64_t inner, double c,
+               void *stream);
+
+/* HyperMapper.poincare_distance(x, y) (hyperbolic.py:62-72): geoopt dist over the last dim, f64. */
+int halo_pdist(const double *x, const double *y, double *out, int64_t n, int64_t d, double c, void *stream);
+
+/* HyperMLR.forward / _hyper_logits (hyperbolic.py:120-188): x (B,C,hw) f64, P_MLR/A_MLR (O,C) f64,
+ * out (B,O,hw) in out_dtype (F32 fuses the head's .float(), core/models/classifier.py:373,554).
+ * workspace: halo_hypermlr_workspace_bytes(O, C). */
+size_t halo_hypermlr_workspace_bytes(int64_t O, int64_t C);
+int halo_hypermlr_logits(const double *x, const double *P, const double *A, void *out, int out_dtype,
+                         int64_t B, int64_t C, int64_t O, int64_t hw, double c, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* F.interpolate(mode="bilinear", align_corners=True) (core/active/build.py:123-125,133-135;
+ * classifier.py:375-377,556-557): planes x (h,w) -> planes x (H,W), dtype F32|F64. */
+int halo_bilinear_upsample(const void *src, void *dst, int dtype, int64_t planes, int64_t h, int64_t w,
+                           int64_t H, int64_t W, void *stream);
+
+/* ---- scoring: FloatingRegionScore.forward (core/active/floating_region.py:129-217) ----
+ *
+ * logit (B,O,H,W) f32; feat = decoder_out (B,C,H,W) f64|f32, needed for pur HYPER/RADIUS/EUC_NORM
+ * (may be NULL otherwise); gt (B,H,W) i64, needed for UNC_ORACLE_ACC / PUR_ORACLE_RIPU.
+ * ksize  = entropy_conv size (constructor `size`);  pksize = purity_conv size (3 if the module
+ * was built with purity_type=='hyper', floating_region.py:54-55);  K = histogram bins for HYPER.
+ * Outputs (B,H,W): score and impurity are f64 when pur is RADIUS|EUC_NORM and feat is f64,
+ * otherwise f32 (the reference's type promotion, floating_region.py:210); uncertainty is f32.
+ * impurity / uncertainty may be NULL when only the score is wanted.
+ * active (B,H,W) u8, optional: where non-zero the score is written as -inf, fusing
+ * `score[active] = -inf` (core/active/build.py:146); pass NULL for the plain forward.
+ */
+size_t halo_score_workspace_bytes(int64_t B, int64_t H, int64_t W);
+int halo_score_maps(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                    int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                    int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                    int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- selection: select_pixels_to_label (core/active/build.py:27-64) ----
+ *
+ * score (B,H,W) f32|f64 is mutated (windows -> -inf) exactly like the reference; active, selected
+ * (B,H,W) u8 (torch.bool storage) and active_mask (B,H,W) i64 are updated in place; gt (B,H,W) i64.
+ * Up to n_regions picks per image: repeat { argmax with ties -> smallest w, then smallest h
+ * (the reference's two-stage torch.max, build.py:38-43); stop when the max is -inf }.
+ * picks (B,n_regions,3) f64 receives (h, w, value) in selection order (may be NULL);
+ * n_picked (B) i32 receives the count (may be NULL).
+ */
+size_t halo_select_workspace_bytes(int64_t B, int64_t H, int64_t W);
+int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,
+                       int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
+                       int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALO_HIP_H */

@@ -1,0 +1,98 @@
+"""CPU-side checks of the C-ABI boundary and host logic (no GPU, no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "halo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(halo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = _declared_symbols()
+    for must in ("halo_expmap0_project", "halo_hypermlr_logits", "halo_dist0", "halo_pdist", "halo_score_maps",
+                 "halo_greedy_select", "halo_version", "halo_last_error", "halo_bilinear_upsample"):
+        assert must in syms
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from halo_amd import _build, _lib
+    so = _build.build()
+    assert os.path.exists(so)
+    h = ctypes.CDLL(so)
+    for s in _declared_symbols():
+        assert hasattr(h, s), "libhalo_hip.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == _declared_symbols(), "ctypes table out of sync with include/halo_hip.h"
+    assert _lib.lib().halo_version() == 1
+
+
+def test_workspace_queries_are_pure_host_functions():
+    from halo_amd import _lib
+    L = _lib.lib()
+    assert L.halo_score_workspace_bytes(1, 1024, 2048) >= 1024 * 2048 * 18
+    assert L.halo_score_workspace_bytes(0, 4, 4) == 0
+    assert L.halo_hypermlr_workspace_bytes(19, 256) >= (3 * 19 + 2 * 19 * 256) * 8
+    assert L.halo_select_workspace_bytes(4, 1024, 2048) > 0
+
+
+def test_argument_errors_are_reported_not_crashed():
+    from halo_amd import _lib
+    L = _lib.lib()
+    rc = L.halo_score_maps(None, 0, None, 0, 0, None, None, 1, 19, 0, 8, 8, 0, 4, 0, 3, 3, 100, 1.0, None, None, None,
+                           None, 0, None)
+    assert rc == -1 and b"null" in L.halo_last_error()
+    rc = L.halo_greedy_select(None, 1, 1, 8, 8, 1, 1, 5, None, None, None, None, None, None, None, 0, None)
+    assert rc == -1
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must raise: a silent CPU path would void every parity claim."""
+    from halo_amd._lib import HaloHipError
+    from halo_amd.core.active.build import select_pixels_to_label
+    from halo_amd.core.active.floating_region import FloatingRegionScore
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
+    frs = FloatingRegionScore(in_channels=19, size=3, purity_type="radius")
+    with pytest.raises(HaloHipError):
+        frs(torch.zeros(1, 19, 8, 8), torch.zeros(1, 4, 8, 8, dtype=torch.float64), unc_type="entropy", pur_type="radius")
+    with pytest.raises(HaloHipError):
+        HyperMapper().expmap(torch.zeros(2, 3))
+    with pytest.raises(HaloHipError):
+        with torch.no_grad():
+            HyperMLR(4, 3)(torch.zeros(1, 4, 2, 2, dtype=torch.float64))
+    with pytest.raises(HaloHipError):
+        z = torch.zeros(8, 8)
+        select_pixels_to_label(z, 1, 1, 5, z.bool(), z.bool(), z.long(), z.long())
+
+
+def test_reference_error_behaviour():
+    from halo_amd.core.active.floating_region import FloatingRegionScore
+    with pytest.raises(AssertionError, match="error size"):          # floating_region.py:36
+        FloatingRegionScore(size=4)
+    frs = FloatingRegionScore(size=3, purity_type="radius")
+    with pytest.raises(NotImplementedError, match="purity type 'bogus' not implemented"):   # :199-202
+        frs(torch.zeros(1, 19, 4, 4), unc_type="entropy", pur_type="bogus")
+    assert FloatingRegionScore(size=5, purity_type="hyper", K=7).purity_size == 3           # :54-55
+
+
+def test_hypermlr_parameters_match_reference_names_and_dtypes():
+    from halo_amd.core.utils.hyperbolic import HyperMLR
+    m = HyperMLR(64, 19, c=1.0)
+    sd = m.state_dict()
+    assert set(sd) == {"P_MLR", "A_MLR"}
+    assert sd["P_MLR"].shape == (19, 64) and sd["P_MLR"].dtype == torch.float64
+    bound = 1.0 / (64 ** 0.5)      # kaiming_uniform_(a=sqrt(5)) on fan_in 64
+    assert float(sd["P_MLR"].abs().max()) <= bound
+
+
+def test_cfg_standin_has_reference_defaults():
+    from halo_amd.core.configs import cfg
+    assert cfg.MODEL.CURVATURE == 1.0 and cfg.MODEL.NUM_CLASSES == 19 and cfg.MODEL.HYPER is True
+    assert cfg.ACTIVE.RADIUS_K == 1 and cfg.ACTIVE.MASK_RADIUS_K == 5 and cfg.ACTIVE.K == 100
+    assert cfg.ACTIVE.BUDGET == 0.05 and len(cfg.ACTIVE.SELECT_ITER) == 5

@@ -1,0 +1,400 @@
+"""Parity of the HIP path (called through the Python host -> C ABI) on a real MI355X.
+
+Three anchors:
+  * golden vectors produced by the reference's own code (tests/golden/*.npz): float maps within
+    1e-4 (we assert 5e-6), selected indices and masks bit-exact;
+  * the CPU oracle on the same inputs: BIT-EXACT maps and picks (both sides implement the same
+    numeric contract), at fixture sizes, at BASELINE config 1 (256x512, C=64) and at the full
+    1024x2048, C=256 size;
+  * size-independent properties of the selection at full size.
+"""
+import math
+import os
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import COMBOS, all_case_combos, case_files, max_abs_diff
+
+pytestmark = pytest.mark.gpu
+
+TOL = 5e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from halo_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    both_nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all((a == b) | both_nan))
+
+
+# ------------------------------------------------------------------ head pieces
+@pytest.mark.parametrize("case", [f.split("/")[-1][:-4] for f in case_files()])
+def test_head_pieces_vs_reference_and_oracle(golden, case, dev):
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners
+    from oracle import halo_oracle as ho
+    d = golden(case)
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    mapper = HyperMapper(c=1.0)
+    with torch.no_grad():
+        e = mapper.expmap(t(d["z"], dev), dim=1)
+        assert e.dtype == torch.float64
+        assert max_abs_diff(e.cpu().numpy(), d["embed_lr"]) < 1e-14
+        mlr = HyperMLR(C, O, c=1.0).to(dev)
+        mlr.P_MLR.copy_(t(d["P_MLR"], dev))
+        mlr.A_MLR.copy_(t(d["A_MLR"], dev))
+        lg = mlr(t(d["embed_lr"], dev))
+        assert lg.dtype == torch.float64
+        assert max_abs_diff(lg.cpu().numpy(), d["logit_lr64"]) < 1e-10
+        lg32 = mlr._hyper_logits(t(d["embed_lr"], dev), out_dtype=torch.float32)
+        assert np.abs(lg32.cpu().numpy() - d["logit_lr"]).max() < 1e-5
+        r = mapper.poincare_distance_origin(t(d["embed_lr"], dev), dim=1)
+        assert max_abs_diff(r.cpu().numpy(), d["radius_lr"]) < 1e-13
+        assert bits_equal(r.cpu().numpy(), ho.dist0(d["embed_lr"], 1.0, dim=1))
+        up = bilinear_align_corners(t(d["logit_lr"], dev), (H, W))
+        assert max_abs_diff(up.cpu().numpy(), d["logit"]) < 4e-6
+        assert bits_equal(up.cpu().numpy(), ho.bilinear(d["logit_lr"], (H, W)))
+        upe = bilinear_align_corners(t(d["embed_lr"], dev), (H, W))
+        assert bits_equal(upe.cpu().numpy(), ho.bilinear(d["embed_lr"], (H, W)))
+
+
+def test_hypermapper_lastdim_api(golden, dev):
+    from halo_amd.core.utils.hyperbolic import HyperMapper
+    d = golden("hypermapper")
+    for c in (1.0, 0.5):
+        m = HyperMapper(c=c)
+        k = f"c{c}"
+        xh = m.expmap(t(d[k + "__x"], dev))
+        assert max_abs_diff(xh.cpu().numpy(), d[k + "__expmap"]) < 1e-14
+        assert max_abs_diff(m.logmap(t(d[k + "__expmap"], dev)).cpu().numpy(), d[k + "__logmap"]) < 1e-12
+        assert max_abs_diff(m.poincare_distance_origin(t(d[k + "__expmap"], dev)).cpu().numpy(), d[k + "__dist0"]) < 1e-12
+        assert max_abs_diff(m.poincare_distance(t(d[k + "__expmap"], dev), t(d[k + "__y_h"], dev)).cpu().numpy(),
+                            d[k + "__dist"]) < 1e-8
+        assert max_abs_diff(m.expmap2(t(d[k + "__x"], dev).double()).cpu().numpy(), d[k + "__expmap2"]) < 1e-12
+        assert max_abs_diff(m.cosine_distance(t(d[k + "__x"][6:], dev), t(d[k + "__y_h"][6:], dev).float()).cpu().numpy(),
+                            d[k + "__cosine"]) < 1e-5
+
+
+# ------------------------------------------------------------------ score + selection on the golden vectors
+@pytest.mark.parametrize("case,tag", all_case_combos())
+def test_score_and_selection_golden(golden, case, tag, dev):
+    from halo_amd.core.active.build import select_pixels_to_label
+    from halo_amd.core.active.floating_region import FloatingRegionScore
+    from oracle import halo_oracle as ho
+    d = golden(case)
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    n = int(d["meta_n_regions"][0])
+    unc, pur = COMBOS[tag]
+    mrad, K, norm = (int(v) for v in d[tag + "__params"])
+    frs = FloatingRegionScore(in_channels=O, size=3, purity_type=pur, K=K).to(dev)
+    with torch.no_grad():
+        s, i, u = frs(t(d["logit"], dev), decoder_out=t(d["embed"], dev), unc_type=unc, pur_type=pur,
+                      normalize=bool(norm), ground_truth=t(d["gt"], dev))
+    sn, inn, un = s.cpu().numpy(), i.cpu().numpy(), u.cpu().numpy()
+    assert sn.shape == (H, W) and sn.dtype == d[tag + "__score"].dtype and inn.dtype == d[tag + "__impurity"].dtype
+    # (1) bit-exact against the oracle
+    so, io, uo = ho.floating_region_score(d["logit"], d["embed"], unc, pur, bool(norm), d["gt"], size=3,
+                                          purity_type=pur, K=K)
+    assert bits_equal(un, uo), "uncertainty differs from the oracle"
+    assert bits_equal(inn, io), "impurity differs from the oracle"
+    assert bits_equal(sn, so), "score differs from the oracle"
+    # (2) within tolerance of the reference's vectors
+    assert max_abs_diff(un, d[tag + "__uncertainty"]) < TOL
+    flips = pur == "hyper" and (np.abs(inn - d[tag + "__impurity"]) > TOL).any()
+    if pur == "hyper":
+        assert (np.abs(inn - d[tag + "__impurity"]) > TOL).mean() < 0.01      # quantiser bin flips, see oracle test
+    else:
+        assert max_abs_diff(inn, d[tag + "__impurity"]) < TOL
+        assert max_abs_diff(sn, d[tag + "__score"]) < TOL
+    # (3) selection: two rounds, masks bit-exact against the reference
+    act = t(d["prior_active"], dev).clone()
+    sel = torch.zeros((H, W), dtype=torch.bool, device=dev)
+    am = torch.full((H, W), 255, dtype=torch.int64, device=dev)
+    gt = t(d["gt"], dev)
+    for rnd in ("r1", "r2"):
+        sc = s.clone()
+        sc[act] = -float("inf")
+        select_pixels_to_label(sc, n, 1, mrad, act, sel, am, gt)
+        if flips:
+            continue
+        assert np.array_equal(act.cpu().numpy(), d[f"{tag}__{rnd}_active"])
+        assert np.array_equal(sel.cpu().numpy(), d[f"{tag}__{rnd}_selected"])
+        assert np.array_equal(am.cpu().numpy(), d[f"{tag}__{rnd}_active_mask"])
+        if rnd == "r1":
+            assert max_abs_diff(sc.cpu().numpy(), d[f"{tag}__r1_score"]) < TOL
+
+
+@pytest.mark.parametrize("case,tag", all_case_combos())
+def test_selector_on_reference_scores(golden, case, tag, dev):
+    """Integer work only: fed the reference's score map, picks and masks must be identical."""
+    from halo_amd.core.active.build import greedy_select
+    d = golden(case)
+    H, W, _, _ = (int(v) for v in d["meta_HWCO"])
+    n = int(d["meta_n_regions"][0])
+    mrad = int(d[tag + "__params"][0])
+    act = t(d["prior_active"], dev).clone()[None]
+    sel = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
+    am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+    gt = t(d["gt"], dev)[None]
+    for rnd in ("r1", "r2"):
+        sc = t(d[tag + "__score"], dev).clone()[None]
+        sc[act] = -float("inf")
+        picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt)
+        ref = d[f"{tag}__{rnd}_picks"]
+        k = int(npk[0])
+        assert k == len(ref)
+        p = picks[0, :k].cpu().numpy()
+        assert np.array_equal(p[:, :2], ref[:, :2])
+        assert bits_equal(p[:, 2], ref[:, 2])
+        assert np.array_equal(act[0].cpu().numpy(), d[f"{tag}__{rnd}_active"])
+        assert np.array_equal(sel[0].cpu().numpy(), d[f"{tag}__{rnd}_selected"])
+        assert np.array_equal(am[0].cpu().numpy(), d[f"{tag}__{rnd}_active_mask"])
+
+
+def test_select_accepts_cpu_indicators_like_the_reference_call_site(golden, dev):
+    """build.py:115-120: score/active_mask/ground_truth on the device, active/selected on the CPU."""
+    from halo_amd.core.active.build import select_pixels_to_label
+    d = golden("case_b_64x128_c16_o19")
+    sc = t(d["halo__score"], dev).clone()
+    act = torch.from_numpy(d["prior_active"].copy())
+    sel = torch.zeros(64, 128, dtype=torch.bool)
+    am = torch.full((64, 128), 255, dtype=torch.int64, device=dev)
+    sc[act.to(dev)] = -float("inf")
+    out = select_pixels_to_label(sc, 60, 1, 5, act, sel, am, t(d["gt"], dev))
+    assert out[1] is act and out[2] is sel and not act.is_cuda
+    assert np.array_equal(act.numpy(), d["halo__r1_active"])
+    assert np.array_equal(sel.numpy(), d["halo__r1_selected"])
+    assert np.array_equal(am.cpu().numpy(), d["halo__r1_active_mask"])
+
+
+# ------------------------------------------------------------------ seeded inputs vs the oracle at BASELINE sizes
+def _synthetic(H, W, C, O, seed, dtype=np.float64):
+    """Smooth maps like the real pipeline's: low-res latent -> oracle head -> x4 upsample."""
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(seed)
+    z = (rng.standard_normal((1, C, H // 4, W // 4)) * 0.1).astype(np.float32)
+    emb_lr = ho.expmap(z, 1.0, dim=1)
+    bound = 1.0 / math.sqrt(C)
+    P = rng.uniform(-bound, bound, (O, C))
+    A = rng.uniform(-bound, bound, (O, C))
+    logit_lr = ho.hypermlr(emb_lr, P, A, 1.0).astype(np.float32)
+    logit = ho.bilinear(logit_lr, (H, W))
+    emb = ho.bilinear(emb_lr, (H, W)).astype(dtype)
+    gt = rng.integers(0, O, (H, W)).astype(np.int64)
+    gt[rng.random((H, W)) < 0.05] = 255
+    return logit, emb, gt
+
+
+def _run_vs_oracle(dev, H, W, C, O, seed, unc, pur, norm, n, mrad, fdtype=np.float64, K=100):
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    logit, emb, gt = _synthetic(H, W, C, O, seed, fdtype)
+    so, io, uo = ho.floating_region_score(logit, emb, unc, pur, norm, gt, size=3, purity_type=pur, K=K)
+    with torch.no_grad():
+        s, i, u = score_maps(t(logit, dev), t(emb, dev), unc, pur, norm, t(gt, dev)[None], size=3, K=K)
+    assert bits_equal(u[0].cpu().numpy(), uo)
+    assert bits_equal(i[0].cpu().numpy(), io)
+    assert bits_equal(s[0].cpu().numpy(), so)
+    act_o = np.zeros((H, W), bool); sel_o = np.zeros((H, W), bool); am_o = np.full((H, W), 255, np.int64)
+    _, _, _, _, picks_o = ho.select_pixels_to_label(so.copy(), n, 1, mrad, act_o, sel_o, am_o, gt, True)
+    act = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
+    sel = torch.zeros_like(act)
+    am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+    picks, npk = greedy_select(s.clone(), n, 1, mrad, act, sel, am, t(gt, dev)[None])
+    k = int(npk[0])
+    assert k == len(picks_o)
+    assert bits_equal(picks[0, :k].cpu().numpy(), picks_o), "selection order differs from the oracle"
+    assert np.array_equal(act[0].cpu().numpy(), act_o)
+    assert np.array_equal(sel[0].cpu().numpy(), sel_o)
+    assert np.array_equal(am[0].cpu().numpy(), am_o)
+    return picks[0, :k].cpu().numpy(), act[0].cpu().numpy(), sel[0].cpu().numpy()
+
+
+@pytest.mark.parametrize("unc,pur,norm,mrad", [("entropy", "radius", True, 5), ("entropy", "ripu", False, 3),
+                                               ("entropy", "hyper", True, 5), ("pixel_entropy", "euc_norm", True, 5),
+                                               ("oracle_acc", "oracle_ripu", False, 3)])
+def test_config1_256x512_c64_bit_exact_vs_oracle(dev, unc, pur, norm, mrad):
+    """BASELINE.json configs[0]: 256x512, C=64, 19 classes; n = ceil(131072*0.01/9) = 146."""
+    _run_vs_oracle(dev, 256, 512, 64, 19, 1234, unc, pur, norm, 146, mrad)
+
+
+def test_config1_float32_features(dev):
+    _run_vs_oracle(dev, 256, 512, 64, 19, 77, "entropy", "radius", True, 146, 5, fdtype=np.float32)
+
+
+def test_odd_sizes_take_the_scalar_paths(dev):
+    """H*W not a multiple of the vector width, class count without a specialised kernel."""
+    _run_vs_oracle(dev, 36, 52, 5, 7, 5, "entropy", "radius", True, 12, 5)                   # hw % 4 == 0 only
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(3)
+    H, W, C, O = 33, 47, 6, 11                                                               # hw odd
+    logit = rng.standard_normal((1, O, H, W)).astype(np.float32)
+    emb = (rng.standard_normal((1, C, H, W)) * 0.2)
+    gt = rng.integers(0, O, (H, W)).astype(np.int64)
+    for unc, pur in (("entropy", "radius"), ("entropy", "ripu"), ("oracle_acc", "hyper")):
+        so, io, uo = ho.floating_region_score(logit, emb, unc, pur, True, gt, size=3, purity_type=pur, K=13)
+        s, i, u = score_maps(t(logit, dev), t(emb, dev), unc, pur, True, t(gt, dev)[None], size=3, K=13)
+        assert bits_equal(s[0].cpu().numpy(), so) and bits_equal(i[0].cpu().numpy(), io) and bits_equal(u[0].cpu().numpy(), uo)
+
+
+def test_wider_windows(dev):
+    """RADIUS_K = 2 (5x5 windows) and a 7x7 entropy window: the generic window paths."""
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    logit, emb, gt = _synthetic(64, 96, 8, 19, 9)
+    for size in (5, 7):
+        for unc, pur in (("entropy", "ripu"), ("entropy", "radius")):
+            so, io, uo = ho.floating_region_score(logit, emb, unc, pur, True, gt, size=size, purity_type=pur)
+            s, i, u = score_maps(t(logit, dev), t(emb, dev), unc, pur, True, t(gt, dev)[None], size=size)
+            assert bits_equal(s[0].cpu().numpy(), so) and bits_equal(i[0].cpu().numpy(), io) and bits_equal(u[0].cpu().numpy(), uo)
+
+
+def test_full_size_1024x2048_c256(dev):
+    """BASELINE.json configs[1] shape, one image: bit-exact vs the oracle, plus properties."""
+    H, W, n, mrad = 1024, 2048, 2331, 5
+    picks, act, sel = _run_vs_oracle(dev, H, W, 256, 19, 1234, "entropy", "radius", True, n, mrad)
+    assert len(picks) == n == math.ceil(H * W * 0.01 / 9)                     # build.py:148-150
+    v = picks[:, 2]
+    assert np.all(v[:-1] >= v[1:]), "greedy picks must be non-increasing in score"
+    hw_ = picks[:, :2].astype(np.int64)
+    # no two picks within the suppression window of each other
+    order = np.lexsort((hw_[:, 1], hw_[:, 0]))
+    p = hw_[order]
+    for j in range(1, 12):
+        dh = np.abs(p[j:, 0] - p[:-j, 0]); dw = np.abs(p[j:, 1] - p[:-j, 1])
+        assert not np.any((dh <= mrad) & (dw <= mrad))
+    assert sel.sum() <= 9 * n and sel.sum() >= 4 * n
+    assert np.all(act[sel]), "selected pixels lie inside suppressed windows"
+    assert act.sum() <= 121 * n
+
+
+def test_batched_equals_per_image_and_is_deterministic(dev):
+    from halo_amd.core.active.build import acquire_batch
+    B, H, W, C, O = 3, 128, 256, 16, 19
+    data = [_synthetic(H, W, C, O, 100 + b) for b in range(B)]
+    logit = torch.cat([t(d[0], dev) for d in data]); emb = torch.cat([t(d[1], dev) for d in data])
+    gt = torch.stack([t(d[2], dev) for d in data])
+
+    def run(lo, em, g):
+        b = lo.shape[0]
+        act = torch.zeros((b, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((b, H, W), 255, dtype=torch.int64, device=dev)
+        picks, npk = acquire_batch(lo, em, g, act, sel, am, unc_type="entropy", pur_type="radius", normalize=True,
+                                   n_regions=37, active_radius=1, mask_radius=5)
+        return picks.cpu().numpy(), npk.cpu().numpy(), act.cpu().numpy(), am.cpu().numpy()
+
+    full = run(logit, emb, gt)
+    again = run(logit, emb, gt)
+    for a, b_ in zip(full, again):
+        assert np.array_equal(a, b_), "two runs on the same input differ"
+    for b in range(B):
+        one = run(logit[b:b + 1], emb[b:b + 1], gt[b:b + 1])
+        assert np.array_equal(one[0][0], full[0][b]) and np.array_equal(one[2][0], full[2][b])
+
+
+def test_exhaustion_nan_and_prior_mask_edge_cases(dev):
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    H, W = 24, 40
+    rng = np.random.default_rng(0)
+    for kind in ("ties", "nan", "all_masked", "neg_zero"):
+        sc = rng.standard_normal((H, W))
+        if kind == "ties":
+            sc = np.round(sc * 2) / 2                       # many exact ties -> (min w, then min h) rule
+        if kind == "nan":
+            sc[5, 7] = np.nan; sc[3, 30] = np.nan           # NaN wins torch.max; first column first
+        if kind == "all_masked":
+            sc[:] = -np.inf
+        if kind == "neg_zero":
+            sc = np.where(rng.random((H, W)) < 0.5, -0.0, 0.0)
+        for dt in (np.float64, np.float32):
+            s0 = sc.astype(dt)
+            act_o = np.zeros((H, W), bool); sel_o = np.zeros((H, W), bool); am_o = np.full((H, W), 255, np.int64)
+            gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+            so = s0.copy()
+            _, _, _, _, po = ho.select_pixels_to_label(so, 500, 1, 5, act_o, sel_o, am_o, gt, True)
+            s = t(s0, dev)[None].clone()
+            act = torch.zeros((1, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+            am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+            picks, npk = greedy_select(s, 500, 1, 5, act, sel, am, t(gt, dev)[None])
+            k = int(npk[0])
+            assert k == len(po), kind
+            assert bits_equal(picks[0, :k].cpu().numpy(), po), kind
+            assert bits_equal(s[0].cpu().numpy(), so), kind
+            assert np.array_equal(act[0].cpu().numpy(), act_o) and np.array_equal(am[0].cpu().numpy(), am_o)
+
+
+# ------------------------------------------------------------------ the driver
+class _Fake(torch.nn.Module):
+    def __init__(self, outs=None):
+        super().__init__()
+        self.outs, self.i = outs, 0
+
+    def forward(self, x, size=None):
+        if self.outs is None:
+            return x
+        o = self.outs[self.i % len(self.outs)]
+        self.i += 1
+        return o
+
+
+def test_region_selection_driver_two_rounds(golden, dev):
+    """RegionSelection (build.py:71-186) through its PNG / torch.save persistence, two rounds."""
+    from PIL import Image
+    from halo_amd.core.active.build import RegionSelection
+    d = golden("region_selection")
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=O, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+    tmp = tempfile.mkdtemp(prefix="halo_rs_")
+    for i in range(3):
+        Image.fromarray(np.full((H, W), 255, dtype=np.uint8)).save(os.path.join(tmp, f"m{i}.png"))
+        torch.save({"active": torch.tensor([0], dtype=torch.bool), "selected": torch.tensor([0], dtype=torch.bool)},
+                   os.path.join(tmp, f"i{i}.pth"))
+
+    def loader():
+        out = []
+        for i in range(3):
+            ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+            a, s = ind["active"], ind["selected"]
+            mask = torch.from_numpy(np.array(Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8)).long()
+            if a.size() == (1,):
+                a = torch.zeros(H, W, dtype=torch.bool); s = torch.zeros(H, W, dtype=torch.bool)
+            out.append({"img": torch.zeros(1, 3, H // 2, W // 2), "path_to_mask": [os.path.join(tmp, f"m{i}.png")],
+                        "origin_mask": mask[None], "origin_label": torch.from_numpy(d[f"img{i}__gt"])[None],
+                        "size": torch.tensor([[H, W]]), "active": a[None], "selected": s[None],
+                        "path_to_indicator": [os.path.join(tmp, f"i{i}.pth")], "name": [f"img{i}"]})
+        return out
+
+    for rnd in (1, 2):
+        clf = _Fake([(t(d[f"img{i}__logit_lr"], dev), t(d[f"img{i}__embed_lr"], dev)) for i in range(3)])
+        RegionSelection(cfg, _Fake(), clf, loader(), rnd)
+        for i in range(3):
+            ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+            assert not ind["active"].is_cuda and ind["active"].dtype == torch.bool
+            png = Image.open(os.path.join(tmp, f"m{i}.png"))
+            assert png.mode == "L"
+            assert np.array_equal(np.array(png, dtype=np.uint8), d[f"r{rnd}_img{i}__mask_png"])
+            assert np.array_equal(ind["active"].numpy(), d[f"r{rnd}_img{i}__active"])
+            assert np.array_equal(ind["selected"].numpy(), d[f"r{rnd}_img{i}__selected"])
