@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- acquisition-scored images/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* = one batch of B synthetic Cityscapes-shaped images (1024x2048, C=256 float64 embedding,
+19 classes) through the whole unit of work of SURVEY.md 8(d): FloatingRegionScore.forward (HALO
+branch: entropy x radius, normalised, 3x3) + `score[active] = -inf` + select_pixels_to_label
+(2331 regions, radius 1, mask radius 5), inputs resident in HBM.  Scoring of batch s+1 (HBM-bound)
+overlaps the latency-bound greedy selection of batch s on a second HIP stream.
+
+Workload at N=1: BASELINE.json configs[1] -- a pool of `steps*B` image evaluations drawn from a
+ring of R distinct resident images (the 500-image pool does not fit in HBM at 4.3 GB/image).
+N>1: the pool is sharded image-wise, every rank runs the same per-rank workload (weak scaling)
+and the per-image pick tables are all-gathered (RCCL) once per step.
+
+Prints ONE JSON line (rank 0).  roofline: the feature-reduction kernel's algorithmic bytes / its
+average duration measured live with HIP events on its own stream.  cpu_baseline: the CPU oracle
+(OpenMP, all host cores) on a bounded sample of the same images (kind "port").
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+H, W, O = 1024, 2048, 19
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per step and rank")
+    ap.add_argument("--ring", type=int, default=16, help="distinct resident images per rank")
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--feat-dtype", choices=["f64", "f32"], default="f64",
+                    help="f64 = what the reference's hyperbolic head hands over (hyperbolic.py:37)")
+    ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    return ap.parse_args()
+
+
+def make_ring(dev, R, C, Hh, Ww, fdtype, rank):
+    """Synthetic pool per SURVEY.md 8(d): low-res latent z ~ N(0, 0.1^2), seed 1234+image index;
+    embed = expmap0_project(z); logit = HyperMLR(embed), P/A ~ kaiming_uniform(a=sqrt 5) seed 7;
+    both upsampled x4 (align_corners) -- all by this package's own kernels, untimed."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners
+    h, w = Hh // 4, Ww // 4
+    mapper = HyperMapper(c=1.0)
+    torch.manual_seed(7)
+    mlr = HyperMLR(C, O, c=1.0).to(dev)
+    feat = torch.empty((R, C, Hh, Ww), dtype=fdtype, device=dev)
+    logit = torch.empty((R, O, Hh, Ww), dtype=torch.float32, device=dev)
+    gt = torch.empty((R, Hh, Ww), dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        for r in range(R):
+            g = torch.Generator(device=dev).manual_seed(1234 + rank * R + r)
+            z = torch.randn((1, C, h, w), generator=g, device=dev, dtype=torch.float32) * 0.1
+            emb = mapper.expmap(z, dim=1)
+            lg = mlr._hyper_logits(emb, out_dtype=torch.float32)
+            logit[r:r + 1] = bilinear_align_corners(lg, (Hh, Ww))
+            up = bilinear_align_corners(emb, (Hh, Ww))
+            feat[r:r + 1] = up if fdtype == torch.float64 else up.float()
+            del up
+            lab = torch.randint(0, O, (Hh, Ww), generator=g, device=dev, dtype=torch.int64)
+            lab[torch.rand((Hh, Ww), generator=g, device=dev) < 0.05] = 255
+            gt[r] = lab
+    torch.cuda.synchronize(dev)
+    return feat, logit, gt
+
+
+class Pipeline:
+    """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
+
+    def __init__(self, dev, feat, logit, gt, B, n_regions, world):
+        from halo_amd import _lib
+        self.lib = _lib.lib()
+        self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
+        self.R = feat.shape[0]
+        Hh, Ww = feat.shape[-2:]
+        self.s_score = torch.cuda.Stream(dev)
+        self.s_sel = torch.cuda.Stream(dev)
+        sdt = torch.float64 if feat.dtype == torch.float64 else torch.float32
+        self.score = [torch.empty((B, Hh, Ww), dtype=sdt, device=dev) for _ in range(2)]
+        self.active = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(2)]
+        self.selected = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(2)]
+        self.amask = [torch.full((B, Hh, Ww), 255, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.scored = [torch.cuda.Event() for _ in range(2)]
+        self.selected_done = [torch.cuda.Event() for _ in range(2)]
+        self.ev = []                       # (start, stop) HIP events around k_feat_reduce
+        self.world = world
+        self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.gathered = [torch.zeros((world * B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(2)] \
+            if world > 1 else None
+        self.step_no = 0
+        self.last = None
+
+    def step(self, timed):
+        from halo_amd.core.active.build import greedy_select
+        from halo_amd.core.active.floating_region import score_maps
+        B, R = self.B, self.R
+        k = self.step_no % 2
+        lo = (self.step_no * B) % R
+        if lo + B > R:
+            lo = 0
+        fb, lb, gb = self.feat[lo:lo + B], self.logit[lo:lo + B], self.gt[lo:lo + B]
+        evs = None
+        if timed:
+            evs = (self.lib.halo_event_create(), self.lib.halo_event_create())
+            self.ev.append(evs)
+        with torch.cuda.stream(self.s_score):
+            self.s_score.wait_event(self.selected_done[k])          # buffers k free again
+            # round-1 state for this batch (the loader's job in the reference, cityscapes.py:245-251)
+            self.active[k].zero_()
+            self.selected[k].zero_()
+            self.amask[k].fill_(255)
+            score_maps(lb, fb, "entropy", "radius", True, None, size=3, c=1.0, active=self.active[k],
+                       want_maps=False, out=self.score[k], events=evs)
+            self.scored[k].record(self.s_score)
+        with torch.cuda.stream(self.s_sel):
+            self.s_sel.wait_event(self.scored[k])
+            picks, npk = greedy_select(self.score[k], self.n, 1, 5, self.active[k], self.selected[k], self.amask[k], gb)
+            self.tables[k].copy_(picks)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.gathered[k], self.tables[k])
+            self.selected_done[k].record(self.s_sel)
+        self.last = (k, lo, npk)
+        self.step_no += 1
+
+    def drain(self):
+        self.s_score.synchronize()
+        self.s_sel.synchronize()
+
+    def feat_kernel_ms(self):
+        import ctypes
+        out = []
+        for a, b in self.ev:
+            ms = ctypes.c_float(0)
+            if self.lib.halo_event_elapsed_ms(a, b, ctypes.byref(ms)) == 0:
+                out.append(ms.value)
+            self.lib.halo_event_destroy(a)
+            self.lib.halo_event_destroy(b)
+        self.ev = []
+        return out
+
+
+def cpu_baseline(feat, logit, gt, n_images, n_regions):
+    """The CPU oracle (kind 'port': C restatement, OpenMP over all host cores) on the first
+    `n_images` ring images: score + mask + select, s/image -> images/s.  Also returns its picks so
+    the caller can compare them with the GPU's (same inputs)."""
+    from oracle import halo_oracle as ho
+    ho.lib()
+    cores = os.cpu_count() or 1
+    times, picks = [], []
+    for i in range(n_images):
+        lg = logit[i].cpu().numpy()
+        ft = feat[i].cpu().numpy()
+        g = gt[i].cpu().numpy()
+        Hh, Ww = g.shape
+        t0 = time.perf_counter()
+        s, _, _ = ho.floating_region_score(lg, ft, "entropy", "radius", True, g, size=3, purity_type="radius")
+        act = np.zeros((Hh, Ww), bool); sel = np.zeros((Hh, Ww), bool); am = np.full((Hh, Ww), 255, np.int64)
+        s[act] = -np.inf
+        _, _, _, _, pk = ho.select_pixels_to_label(s, n_regions, 1, 5, act, sel, am, g, True)
+        times.append(time.perf_counter() - t0)
+        picks.append(pk)
+    return float(np.median(times)), cores, picks
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs ROCm devices"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    fdtype = torch.float64 if a.feat_dtype == "f64" else torch.float32
+    Hh, Ww, C, B = a.height, a.width, a.channels, a.batch
+    R = max(B, (a.ring // B) * B)
+    n_regions = math.ceil(Hh * Ww * (0.05 / 5) / 9)                    # build.py:148-150 -> 2331
+
+    feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world)
+
+    for _ in range(a.warmup):
+        pipe.step(False)
+    pipe.drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pipe.step(True)
+    pipe.drain()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    feat_ms = pipe.feat_kernel_ms()
+    k, lo, npk = pipe.last
+    assert int(npk.min()) == n_regions, "selection stopped early"
+
+    if rank == 0:
+        esz = 8 if fdtype == torch.float64 else 4
+        images = world * a.steps * B
+        value = images / dt
+        launch_bytes = B * Hh * Ww * (C * esz + esz)                   # features read + radius map written
+        avg_ms = float(np.mean(feat_ms)) if feat_ms else float("nan")
+        achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
+        path_bytes_per_image = Hh * Ww * (C * esz + O * 4 + esz)
+        out = {
+            "metric": "acquisition-scored images/sec (1024x2048, C=256, 19 cls)",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.feat_dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic pool, %dx%d, C=%d %s embedding, %d classes, HALO branch "
+                                   "(entropy x radius, normalised, 3x3), %d regions/image, radius 1, mask radius 5"
+                                   % (Hh, Ww, C, a.feat_dtype, O, n_regions),
+                       "images_per_step_per_gpu": B, "resident_ring": R, "image_evaluations": images,
+                       "sharding": "image-wise, %d rank(s)%s" % (world, ", all-gather of pick tables per step" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms)},
+            "path_algorithmic_GBps": round(path_bytes_per_image * value / world / 1e9, 1),
+        }
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("batch") == B and rec.get("dtype") == a.feat_dtype:
+                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json"
+            except Exception:
+                pass
+        if a.cpu_images > 0 and world == 1:
+            s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, min(a.cpu_images, R), n_regions)
+            out["cpu_baseline"] = {"value": round(1.0 / s_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
+                                   "sample": "%d of the same ring images, oracle/halo_oracle.c (OpenMP), median s/image = %.2f"
+                                             % (min(a.cpu_images, R), s_img)}
+            # same inputs -> the GPU picks of the last step's images can be checked when they overlap
+            from halo_amd.core.active.build import acquire_batch
+            act = torch.zeros((1, Hh, Ww), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+            am = torch.full((1, Hh, Ww), 255, dtype=torch.int64, device=dev)
+            with torch.no_grad():
+                pk, nk = acquire_batch(logit[0:1], feat[0:1], gt[0:1], act, sel, am, unc_type="entropy",
+                                       pur_type="radius", normalize=True, n_regions=n_regions, active_radius=1, mask_radius=5)
+            out["parity_vs_cpu"] = bool(np.array_equal(pk[0, :int(nk[0])].cpu().numpy(), picks_cpu[0]))
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

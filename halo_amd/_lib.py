@@ -31,6 +31,12 @@ SIGNATURES = {
     "halo_score_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "halo_score_maps": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
                                _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "halo_score_maps_timed": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
+                                     _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "halo_event_create": (_vp, []),
+    "halo_event_record": (_int, [_vp, _vp]),
+    "halo_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "halo_event_destroy": (_int, [_vp]),
     "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "halo_greedy_select": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _sz, _vp]),
@@ -48,6 +54,19 @@ def library_path():
     return _build.SO
 
 
+def _preload_torch_hip_runtime():
+    """Device pointers and streams come from torch, so the kernels must be launched through the
+    SAME HIP runtime instance torch uses.  PyTorch-ROCm wheels bundle their own libamdhip64.so;
+    loading it first (RTLD_GLOBAL) makes libhalo_hip.so's NEEDED libamdhip64.so.N resolve to it
+    instead of a second copy from /opt/rocm (two runtimes = "no ROCm-capable device")."""
+    import torch
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    for name in ("libamdhip64.so",):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load (building first if the in-tree .so is missing or stale) and type the library."""
     global _handle
@@ -63,6 +82,7 @@ def lib():
                 path = _build.SO
             else:
                 raise HaloHipError("libhalo_hip.so is missing and could not be built: %s" % exc) from exc
+        _preload_torch_hip_runtime()
         h = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name, None)

@@ -36,11 +36,14 @@ def score_dtype(pur_type, decoder_out):
 
 
 def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
-               size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True):
+               size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, out=None, events=None):
     """Batched FloatingRegionScore.forward.
 
     logit (B,O,H,W) float32; decoder_out (B,C,H,W) float64|float32; ground_truth (B,H,W) int64;
     active (B,H,W) bool, optional: fuses `score[active] = -inf` (core/active/build.py:146).
+    out: optional pre-allocated (B,H,W) score tensor to write into (pipelined callers own their
+    buffers); events: optional (start, stop) handles from halo_event_create, recorded around the
+    feature-reduction kernel.
     Returns (score, impurity, uncertainty), each (B,H,W); the last two are None if not want_maps.
     """
     if pur_type not in _lib.PUR:
@@ -77,18 +80,23 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
         act = active.reshape(B, H, W).contiguous()
         act = act.view(torch.uint8) if act.dtype == torch.bool else act.to(torch.uint8)
     odt = score_dtype(pur_type, feat)
-    score = torch.empty((B, H, W), dtype=odt, device=dev)
+    if out is not None:
+        assert out.shape == (B, H, W) and out.dtype == odt and out.is_contiguous() and out.device == dev
+        score = out
+    else:
+        score = torch.empty((B, H, W), dtype=odt, device=dev)
     imp = torch.empty((B, H, W), dtype=odt, device=dev) if want_maps else None
     unc = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_maps else None
     L = _lib.lib()
     nws = L.halo_score_workspace_bytes(B, H, W)
     ws = _workspace(dev, nws, "score")
     psize = size if purity_size is None else purity_size
-    rc = L.halo_score_maps(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt), _lib.ptr(act),
-                           B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS), _lib.PUR[pur_type],
-                           1 if normalize else 0, int(size), int(psize), int(K), float(c),
-                           _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
-                           _lib.stream_ptr(dev))
+    ev0, ev1 = events if events is not None else (None, None)
+    rc = L.halo_score_maps_timed(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt),
+                                 _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
+                                 _lib.PUR[pur_type], 1 if normalize else 0, int(size), int(psize), int(K), float(c),
+                                 _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
+                                 _lib.stream_ptr(dev), ev0, ev1)
     _lib.check(rc, "halo_score_maps")
     return score, imp, unc
 

@@ -459,6 +459,18 @@ extern "C" int halo_score_maps(const float *logit, int64_t logit_bstride, const 
                                int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                                void *workspace, size_t workspace_bytes, void *stream)
 {
+    return halo_score_maps_timed(logit, logit_bstride, feat, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type,
+                                 pur_type, normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace,
+                                 workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                                     int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                                     int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                                     int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                                     void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
+                                     void *ev_feat_stop)
+{
     hipStream_t st = (hipStream_t)stream;
     if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
     if (unc_type < 0 || unc_type > HALO_UNC_ZEROS) return fail(HALO_E_ARG, "halo_score_maps: bad unc_type %d", unc_type);
@@ -512,6 +524,7 @@ extern "C" int halo_score_maps(const float *logit, int64_t logit_bstride, const 
     // ---- features -> radius / norm  (+ min/max partials)
     int nblk_imp = nblk1;
     if (need_feat) {
+        if (ev_feat_start) (void)hipEventRecord((hipEvent_t)ev_feat_start, st);
         const int mode = pur_type == HALO_PUR_EUC_NORM ? 1 : 0;
         if (feat_dtype == HALO_F64) {
             const bool v2 = (hw % 2 == 0) && (feat_bstride % 2 == 0) && aligned16(feat) && aligned16(imp_raw);
@@ -522,6 +535,7 @@ extern "C" int halo_score_maps(const float *logit, int64_t logit_bstride, const 
             if (v4) { nblk_imp = (int)cdiv(hw, TPB * 4); launch_feat<float, 4>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
             else { nblk_imp = nblk1; launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
         }
+        if (ev_feat_stop) (void)hipEventRecord((hipEvent_t)ev_feat_stop, st);
     }
     dim3 grid1((unsigned)nblk1, (unsigned)B);
     if (pur_type == HALO_PUR_HYPER) {

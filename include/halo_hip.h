@@ -97,6 +97,16 @@ int halo_score_maps(const float *logit, int64_t logit_bstride, const void *feat,
                     int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same call with two optional hipEvent_t (as void*, from halo_event_create) recorded on `stream`
+ * immediately before and after the feature-reduction kernel (k_feat_reduce, the HBM-roofline
+ * kernel) -- used by bench.py to time that kernel live inside the pipelined run. */
+int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                          int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                          int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                          int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                          void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
+                          void *ev_feat_stop);
+
 /* ---- selection: select_pixels_to_label (core/active/build.py:27-64) ----
  *
  * score (B,H,W) f32|f64 is mutated (windows -> -inf) exactly like the reference; active, selected
@@ -111,6 +121,12 @@ int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, 
                        int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
                        int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- measurement helpers (HIP events in the same runtime the kernels are launched through) ---- */
+void *halo_event_create(void);
+int halo_event_record(void *event, void *stream);
+int halo_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on `stop` */
+int halo_event_destroy(void *event);
 
 #ifdef __cplusplus
 }
