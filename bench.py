@@ -42,9 +42,10 @@ H, W, O = 1024, 2048, 19
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="images per step and rank")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=16, help="images per step and rank")
+    ap.add_argument("--depth", type=int, default=4, help="batches in flight (selection slots)")
     ap.add_argument("--ring", type=int, default=16, help="distinct resident images per rank")
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--feat-dtype", choices=["f64", "f32"], default="f64",
@@ -87,25 +88,29 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, rank):
 class Pipeline:
     """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
 
-    def __init__(self, dev, feat, logit, gt, B, n_regions, world):
+    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
         self.R = feat.shape[0]
         Hh, Ww = feat.shape[-2:]
+        # The greedy selector is latency-bound (2331 dependent steps per image, one workgroup per
+        # image, ~20 ms per batch) while scoring is bandwidth-bound (~6 ms per batch): keep `depth`
+        # batches in flight, each slot selecting on its own stream, so selection hides behind scoring.
+        D = self.D = depth
         self.s_score = torch.cuda.Stream(dev)
-        self.s_sel = torch.cuda.Stream(dev)
+        self.s_sel = [torch.cuda.Stream(dev, priority=-1) for _ in range(D)]   # dispatch ahead of scoring
         sdt = torch.float64 if feat.dtype == torch.float64 else torch.float32
-        self.score = [torch.empty((B, Hh, Ww), dtype=sdt, device=dev) for _ in range(2)]
-        self.active = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(2)]
-        self.selected = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(2)]
-        self.amask = [torch.full((B, Hh, Ww), 255, dtype=torch.int64, device=dev) for _ in range(2)]
-        self.scored = [torch.cuda.Event() for _ in range(2)]
-        self.selected_done = [torch.cuda.Event() for _ in range(2)]
+        self.score = [torch.empty((B, Hh, Ww), dtype=sdt, device=dev) for _ in range(D)]
+        self.active = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
+        self.selected = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
+        self.amask = [torch.full((B, Hh, Ww), 255, dtype=torch.int64, device=dev) for _ in range(D)]
+        self.scored = [torch.cuda.Event() for _ in range(D)]
+        self.selected_done = [torch.cuda.Event() for _ in range(D)]
         self.ev = []                       # (start, stop) HIP events around k_feat_reduce
         self.world = world
-        self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(2)]
-        self.gathered = [torch.zeros((world * B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(2)] \
+        self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]
+        self.gathered = [torch.zeros((world * B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)] \
             if world > 1 else None
         self.step_no = 0
         self.last = None
@@ -114,7 +119,7 @@ class Pipeline:
         from halo_amd.core.active.build import greedy_select
         from halo_amd.core.active.floating_region import score_maps
         B, R = self.B, self.R
-        k = self.step_no % 2
+        k = self.step_no % self.D
         lo = (self.step_no * B) % R
         if lo + B > R:
             lo = 0
@@ -132,19 +137,20 @@ class Pipeline:
             score_maps(lb, fb, "entropy", "radius", True, None, size=3, c=1.0, active=self.active[k],
                        want_maps=False, out=self.score[k], events=evs)
             self.scored[k].record(self.s_score)
-        with torch.cuda.stream(self.s_sel):
-            self.s_sel.wait_event(self.scored[k])
+        with torch.cuda.stream(self.s_sel[k]):
+            self.s_sel[k].wait_event(self.scored[k])
             picks, npk = greedy_select(self.score[k], self.n, 1, 5, self.active[k], self.selected[k], self.amask[k], gb)
             self.tables[k].copy_(picks)
             if self.world > 1:
                 dist.all_gather_into_tensor(self.gathered[k], self.tables[k])
-            self.selected_done[k].record(self.s_sel)
+            self.selected_done[k].record(self.s_sel[k])
         self.last = (k, lo, npk)
         self.step_no += 1
 
     def drain(self):
         self.s_score.synchronize()
-        self.s_sel.synchronize()
+        for st in self.s_sel:
+            st.synchronize()
 
     def feat_kernel_ms(self):
         import ctypes
@@ -199,7 +205,7 @@ def main():
     n_regions = math.ceil(Hh * Ww * (0.05 / 5) / 9)                    # build.py:148-150 -> 2331
 
     feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth)
 
     for _ in range(a.warmup):
         pipe.step(False)
@@ -240,7 +246,7 @@ def main():
             "config": {"workload": "configs[1]: synthetic pool, %dx%d, C=%d %s embedding, %d classes, HALO branch "
                                    "(entropy x radius, normalised, 3x3), %d regions/image, radius 1, mask radius 5"
                                    % (Hh, Ww, C, a.feat_dtype, O, n_regions),
-                       "images_per_step_per_gpu": B, "resident_ring": R, "image_evaluations": images,
+                       "images_per_step_per_gpu": B, "batches_in_flight": a.depth, "resident_ring": R, "image_evaluations": images,
                        "sharding": "image-wise, %d rank(s)%s" % (world, ", all-gather of pick tables per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

@@ -59,31 +59,41 @@ struct SelGeom { int H, W, th_shift, tw_shift, nty, ntx, nt; };
 
 // Reduce one tile (cooperatively, one wave) -> lane-uniform Cand.  Pixels inside the window
 // [wy0,wy1] x [wx0,wx1] count as -inf (the suppression being applied in this same step).
-template <typename T>
+// The tile shape is a compile-time constant so that all of a lane's loads are issued
+// back to back (one memory round trip per tile instead of one per pixel row).
+template <typename T, int TSH, int TSW>
 __device__ __forceinline__ Cand tile_reduce(const T *__restrict__ sc, const SelGeom &g, int tile, int lane,
                                             int wy0, int wy1, int wx0, int wx1)
 {
+    constexpr int TW = 1 << TSW, NPL = (1 << (TSH + TSW)) / 64;
+    static_assert(NPL >= 1, "tile smaller than a wave");
     const int ty = tile / g.ntx, tx = tile % g.ntx;
-    const int TH = 1 << g.th_shift, TW = 1 << g.tw_shift;
-    const int y0 = ty << g.th_shift, x0 = tx << g.tw_shift;
+    const int y0 = ty << TSH, x0 = tx << TSW;
+    double v[NPL];
+    bool inb[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int e = lane + 64 * i;
+        const int y = y0 + (e >> TSW), x = x0 + (e & (TW - 1));
+        inb[i] = y < g.H && x < g.W;
+        v[i] = inb[i] ? (double)sc[(size_t)y * g.W + x] : 0.0;
+    }
     Cand best;
     best.key = 0ull;            // below every real key (real keys are >= KEY_NEG_INF > 0)
     best.pos = 0xffffffffu;
-    const int npx = TH * TW;
-    for (int e = lane; e < npx; e += 64) {
-        const int y = y0 + (e >> g.tw_shift), x = x0 + (e & (TW - 1));
-        if (y < g.H && x < g.W) {
-            double v = (double)sc[(size_t)y * g.W + x];
-            Cand c;
-            c.key = (y >= wy0 && y <= wy1 && x >= wx0 && x <= wx1) ? KEY_NEG_INF : order_key(v);
-            c.pos = (unsigned)x * (unsigned)g.H + (unsigned)y;
-            if (better(c, best)) best = c;
-        }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int e = lane + 64 * i;
+        const int y = y0 + (e >> TSW), x = x0 + (e & (TW - 1));
+        Cand c;
+        c.key = (y >= wy0 && y <= wy1 && x >= wx0 && x <= wx1) ? KEY_NEG_INF : order_key(v[i]);
+        c.pos = (unsigned)x * (unsigned)g.H + (unsigned)y;
+        if (inb[i] && better(c, best)) best = c;
     }
     return wave_best(best);
 }
 
-template <typename T>
+template <typename T, int TSH, int TSW>
 __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score, SelGeom g, int n_regions, int arad,
                                                            int mrad, unsigned char *__restrict__ active,
                                                            unsigned char *__restrict__ selected,
@@ -98,6 +108,9 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
     unsigned long long *wkey = reinterpret_cast<unsigned long long *>(smem + (size_t)g.nt * 12 + ((16 - ((size_t)g.nt * 12) % 16) % 16));
     unsigned *wpos = reinterpret_cast<unsigned *>(wkey + 2 * SEL_WAVES);
 
+    // Latency-bound serial loop sharing CUs with bandwidth-bound streaming kernels: take issue
+    // priority over them (they only wait on memory anyway).
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t hw = (size_t)g.H * g.W;
     T *sc = score + (size_t)b * hw;
@@ -108,7 +121,7 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
 
     // ---- build the tile table
     for (int t = wave; t < g.nt; t += SEL_WAVES) {
-        const Cand c = tile_reduce<T>(sc, g, t, lane, 1, 0, 1, 0);
+        const Cand c = tile_reduce<T, TSH, TSW>(sc, g, t, lane, 1, 0, 1, 0);
         if (lane == 0) { tkey[t] = c.key; tpos[t] = c.pos; }
     }
     __syncthreads();
@@ -176,11 +189,11 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
             }
         }
         // ---- re-reduce the tiles the mask window touches (one wave per tile)
-        const int ty0 = my0 >> g.th_shift, ty1 = my1 >> g.th_shift, tx0 = mx0 >> g.tw_shift, tx1 = mx1 >> g.tw_shift;
+        const int ty0 = my0 >> TSH, ty1 = my1 >> TSH, tx0 = mx0 >> TSW, tx1 = mx1 >> TSW;
         const int ntx_w = tx1 - tx0 + 1, ntouch = ntx_w * (ty1 - ty0 + 1);
         for (int q = wave; q < ntouch; q += SEL_WAVES) {
             const int t = (ty0 + q / ntx_w) * g.ntx + (tx0 + q % ntx_w);
-            const Cand c = tile_reduce<T>(sc, g, t, lane, my0, my1, mx0, mx1);
+            const Cand c = tile_reduce<T, TSH, TSW>(sc, g, t, lane, my0, my1, mx0, mx1);
             if (lane == 0) { tkey[t] = c.key; tpos[t] = c.pos; }
         }
         __syncthreads();
@@ -204,14 +217,15 @@ static SelGeom make_geom(int64_t H, int64_t W)
     SelGeom g;
     g.H = (int)H;
     g.W = (int)W;
-    g.th_shift = 4;    // 16 x 32 tiles: 4096 tiles (48 KiB of LDS) at 1024 x 2048
-    g.tw_shift = 5;
-    while (true) {
+    // 16 x 32 tiles: 4096 tiles (48 KiB of LDS) at 1024 x 2048; larger maps use 32 x 64 / 64 x 128
+    static const int shapes[3][2] = {{4, 5}, {5, 6}, {6, 7}};
+    for (int i = 0; i < 3; ++i) {
+        g.th_shift = shapes[i][0];
+        g.tw_shift = shapes[i][1];
         g.nty = (int)cdiv(H, 1 << g.th_shift);
         g.ntx = (int)cdiv(W, 1 << g.tw_shift);
         g.nt = g.nty * g.ntx;
         if ((size_t)g.nt * 12 <= 96 * 1024) break;
-        if (g.th_shift <= g.tw_shift) ++g.th_shift; else ++g.tw_shift;
     }
     return g;
 }
@@ -236,13 +250,21 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
     if ((uint64_t)H * (uint64_t)W >= 0xffffffffull) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image too large");
     if (n_regions > 0x7fffffff) n_regions = 0x7fffffff;
     const SelGeom g = make_geom(H, W);
+    if ((size_t)g.nt * 12 > 96 * 1024) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image too large for the tile table");
     const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * SEL_WAVES * 12 + 64;
     dim3 grid((unsigned)B), block(SEL_TPB);
-    if (dtype == HALO_F64)
-        hipLaunchKernelGGL((k_greedy_select<double>), grid, block, lds, st, (double *)score, g, (int)n_regions, (int)active_radius,
-                           (int)mask_radius, active, selected, (long long *)active_mask, (const long long *)gt, picks, n_picked);
-    else
-        hipLaunchKernelGGL((k_greedy_select<float>), grid, block, lds, st, (float *)score, g, (int)n_regions, (int)active_radius,
-                           (int)mask_radius, active, selected, (long long *)active_mask, (const long long *)gt, picks, n_picked);
+#define HALO_SEL_LAUNCH(T, A, B_)                                                                                          \
+    hipLaunchKernelGGL((k_greedy_select<T, A, B_>), grid, block, lds, st, (T *)score, g, (int)n_regions, (int)active_radius, \
+                       (int)mask_radius, active, selected, (long long *)active_mask, (const long long *)gt, picks, n_picked)
+    if (dtype == HALO_F64) {
+        if (g.th_shift == 4) HALO_SEL_LAUNCH(double, 4, 5);
+        else if (g.th_shift == 5) HALO_SEL_LAUNCH(double, 5, 6);
+        else HALO_SEL_LAUNCH(double, 6, 7);
+    } else {
+        if (g.th_shift == 4) HALO_SEL_LAUNCH(float, 4, 5);
+        else if (g.th_shift == 5) HALO_SEL_LAUNCH(float, 5, 6);
+        else HALO_SEL_LAUNCH(float, 6, 7);
+    }
+#undef HALO_SEL_LAUNCH
     return check_launch("halo_greedy_select");
 }
