@@ -33,6 +33,9 @@ SIGNATURES = {
                                _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_score_maps_timed": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
                                      _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "halo_region_uncertainty": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
+    "halo_region_impurity": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp]),
+    "halo_quantize_radius": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _sz, _vp]),
     "halo_event_create": (_vp, []),
     "halo_event_record": (_int, [_vp, _vp]),
     "halo_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),

@@ -132,6 +132,60 @@ class FloatingRegionScore(nn.Module):
         if pur_type == "hyper" and self.purity_channels != self.K:
             raise RuntimeError("purity window channel mismatch")
 
+    # ---- helper methods the reference exposes by convention (floating_region.py:70-127) ----
+    def _uncertainty(self, x, is_prob, unc_type, ground_truth, do_box):
+        dev = _lib.require_device(x, ground_truth)
+        x = x.float().contiguous()
+        O, H, W = x.shape
+        out = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
+        gt = None if ground_truth is None else ground_truth.to(torch.int64).contiguous()
+        ws = _workspace(dev, H * W * 4 + 256, "unc")
+        rc = _lib.lib().halo_region_uncertainty(_lib.ptr(x), x.numel(), 1 if is_prob else 0, _lib.ptr(gt), 1, O, H, W,
+                                                _lib.UNC.get(unc_type, _lib.UNC_ZEROS), int(self.size),
+                                                1 if do_box else 0, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                                _lib.stream_ptr(dev))
+        _lib.check(rc, "halo_region_uncertainty")
+        return out
+
+    def compute_region_uncertainty(self, unc_type, logit, p, ground_truth=None):
+        """p (O,H,W) softmax probabilities -> (1,1,H,W); box-summed unless unc_type == 'none'
+        (floating_region.py:70-92)."""
+        return self._uncertainty(p, True, unc_type, ground_truth, do_box=(unc_type != "none"))
+
+    def compute_pixel_entropy(self, p):
+        """(floating_region.py:123-127)"""
+        return self._uncertainty(p, True, "pixel_entropy", None, do_box=False)
+
+    def quantize_uncert_map(self, decoder_out):
+        """decoder_out (1,C,H,W) -> (H,W) int64 bins in [0, K-1] (floating_region.py:94-110)."""
+        dev = _lib.require_device(decoder_out)
+        feat = decoder_out if decoder_out.dtype in (torch.float32, torch.float64) else decoder_out.float()
+        feat = feat.contiguous()
+        B, Cc, H, W = feat.shape
+        assert B == 1
+        pred = torch.empty((H, W), dtype=torch.int64, device=dev)
+        L = _lib.lib()
+        nws = L.halo_score_workspace_bytes(1, H, W)
+        ws = _workspace(dev, nws, "score")
+        rc = L.halo_quantize_radius(_lib.ptr(feat), _lib.dtype_code(feat), feat.stride(0), 1, Cc, H, W, int(self.K),
+                                    float(self.mapper.c), _lib.ptr(pred), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "halo_quantize_radius")
+        return pred
+
+    def compute_region_impurity(self, predict, K):
+        """predict (H,W) int64 -> (region_impurity, count), each (1,1,H,W) float32 (floating_region.py:112-121)."""
+        dev = _lib.require_device(predict)
+        if K != self.purity_channels:
+            raise RuntimeError("purity window was built for %d channels, got K=%d" % (self.purity_channels, K))
+        pred = predict.to(torch.int64).contiguous()
+        H, W = pred.shape
+        imp = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
+        cnt = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
+        rc = _lib.lib().halo_region_impurity(_lib.ptr(pred), 1, H, W, int(self.purity_size), int(K), _lib.ptr(imp),
+                                             _lib.ptr(cnt), _lib.stream_ptr(dev))
+        _lib.check(rc, "halo_region_impurity")
+        return imp, cnt
+
     def forward(self, logit: torch.Tensor, decoder_out: torch.Tensor = None, unc_type: str = None,
                 pur_type: str = None, normalize: bool = False, ground_truth=None):
         """

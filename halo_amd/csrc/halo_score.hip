@@ -142,23 +142,26 @@ __global__ void __launch_bounds__(TPB) k_logit_maps(const float *__restrict__ lo
 // Any class count: three passes over the O planes (coalesced scalar loads, L2-resident tile).
 __global__ void __launch_bounds__(TPB) k_logit_maps_generic(const float *__restrict__ logit, long long bstride,
                                                             const long long *__restrict__ gt, int O, long long hw,
-                                                            int unc_type, int pur_type, float *__restrict__ ent,
-                                                            short *__restrict__ pred)
+                                                            int unc_type, int pur_type, int is_prob,
+                                                            float *__restrict__ ent, short *__restrict__ pred)
 {
     const int b = blockIdx.y;
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= hw) return;
     const float *lp = logit + (size_t)b * bstride + i;
-    float m = lp[0];
-    for (int c = 1; c < O; ++c) { float x = lp[(size_t)c * hw]; m = x > m ? x : m; }
-    float s = 0.0f;
-    for (int c = 0; c < O; ++c) s = s + det_expf(lp[(size_t)c * hw] - m);
+    float m = 0.0f, s = 1.0f;
+    if (!is_prob) {      // is_prob: the tensor already holds softmax probabilities (helper-method API)
+        m = lp[0];
+        for (int c = 1; c < O; ++c) { float x = lp[(size_t)c * hw]; m = x > m ? x : m; }
+        s = 0.0f;
+        for (int c = 0; c < O; ++c) s = s + det_expf(lp[(size_t)c * hw] - m);
+    }
     const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
     const long long g = need_gt ? gt[(size_t)b * hw + i] : 0;
     float a = 0.0f, best = 0.0f, pg = 0.0f;
     int am = 0;
     for (int c = 0; c < O; ++c) {
-        const float p = det_expf(lp[(size_t)c * hw] - m) / s;
+        const float p = is_prob ? lp[(size_t)c * hw] : det_expf(lp[(size_t)c * hw] - m) / s;
         if (c == 0 || p > best) { best = p; am = c; }
         if (c == (int)g) pg = p;
         a = a + (-p) * det_logf(p + 1e-6f);
@@ -258,9 +261,9 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce(const T *__restrict__ feat,
 
 // ---------------------------------------------------------------- quantize_uncert_map (floating_region.py:94-110)
 // r -> (r-min)/(max-min) -> 1-x -> (second min-max: exact no-op, min 0 / max 1) -> x*K-0.5 -> clamp -> round-half-even
-template <typename T>
+template <typename T, typename TO>
 __global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const double *__restrict__ stats,
-                                                  long long hw, int K, short *__restrict__ pred)
+                                                  long long hw, int K, TO *__restrict__ pred)
 {
     const int b = blockIdx.y;
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const
         const double lo = -0.5 + 1e-5, hi = (double)K - 0.5 - 1e-5;
         p = p < lo ? lo : p;
         p = p > hi ? hi : p;
-        pred[(size_t)b * hw + i] = (short)__builtin_rint(p);
+        pred[(size_t)b * hw + i] = (TO)__builtin_rint(p);
     } else {
         const float den = (float)((double)mx - (double)mn);
         x = (r[(size_t)b * hw + i] - mn) / den;
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const
         const float lo = (float)(-0.5 + 1e-5), hi = (float)((double)K - 0.5 - 1e-5);
         p = p < lo ? lo : p;
         p = p > hi ? hi : p;
-        pred[(size_t)b * hw + i] = (short)__builtin_rintf(p);
+        pred[(size_t)b * hw + i] = (TO)__builtin_rintf(p);
     }
 }
 
@@ -291,8 +294,9 @@ __global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const
 // Window class histogram -> sum_c -d*log(d+1e-6) / log(K), classes visited in ascending order
 // (= the reference's sum over the one-hot channel axis; empty classes contribute exactly 0).
 // No one-hot tensor: the <= k*k window labels are re-scanned once per distinct class.
-__global__ void __launch_bounds__(TPB) k_region_impurity(const short *__restrict__ pred, int H, int W, int k,
-                                                         float logK, float *__restrict__ imp)
+template <typename TL>
+__global__ void __launch_bounds__(TPB) k_region_impurity(const TL *__restrict__ pred, int H, int W, int k,
+                                                         float logK, float *__restrict__ imp, float *__restrict__ count)
 {
     const int b = blockIdx.y;
     const long long hw = (long long)H * W;
@@ -301,7 +305,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const short *__restrict
     const int y = (int)(i / W), x = (int)(i % W), r = k / 2;
     const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
     const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
-    const short *pp = pred + (size_t)b * hw;
+    const TL *pp = pred + (size_t)b * hw;
     const float cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
     float a = 0.0f;
     int cur = -1;
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const short *__restrict
         int nxt = 0x7fffffff, n = 0;
         for (int yy = y0; yy <= y1; ++yy)
             for (int xx = x0; xx <= x1; ++xx) {
-                const int v = pp[(size_t)yy * W + xx];
+                const int v = (int)pp[(size_t)yy * W + xx];
                 if (v > cur) {
                     if (v < nxt) { nxt = v; n = 1; }
                     else if (v == nxt) ++n;
@@ -321,6 +325,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const short *__restrict
         cur = nxt;
     }
     imp[(size_t)b * hw + i] = a / logK;
+    if (count) count[(size_t)b * hw + i] = cnt;
 }
 
 // ---------------------------------------------------------------- entropy_conv + /count (floating_region.py:42-51,90,204)
@@ -361,6 +366,7 @@ __global__ void __launch_bounds__(TPB) k_box_unc(const float *__restrict__ ent, 
         unc[(size_t)b * hw + i] = a;
         mn = mx = (double)a;
     }
+    if (!partials) return;
     __shared__ double seed[2];
     if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
     __syncthreads();
@@ -515,7 +521,7 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
             hipLaunchKernelGGL((k_logit_maps<16, 4>), grid, block, 0, st, logit, (long long)logit_bstride, (const long long *)gt, hw, unc_type, pur_type, ent, pred_from_logits);
         } else {
             dim3 grid((unsigned)nblk1, (unsigned)B);
-            hipLaunchKernelGGL(k_logit_maps_generic, grid, block, 0, st, logit, (long long)logit_bstride, (const long long *)gt, (int)O, hw, unc_type, pur_type, ent, pred_from_logits);
+            hipLaunchKernelGGL(k_logit_maps_generic, grid, block, 0, st, logit, (long long)logit_bstride, (const long long *)gt, (int)O, hw, unc_type, pur_type, 0, ent, pred_from_logits);
         }
     } else {
         hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(B * hw, TPB)), block, 0, st, ent, (long long)(B * hw), 0.0f);
@@ -540,12 +546,12 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     dim3 grid1((unsigned)nblk1, (unsigned)B);
     if (pur_type == HALO_PUR_HYPER) {
         hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_imp, nblk_imp, stats, 0);
-        if (feat_dtype == HALO_F64) hipLaunchKernelGGL((k_quantize<double>), grid1, block, 0, st, (const double *)imp_raw, stats, hw, (int)K, pred);
-        else hipLaunchKernelGGL((k_quantize<float>), grid1, block, 0, st, (const float *)imp_raw, stats, hw, (int)K, pred);
+        if (feat_dtype == HALO_F64) hipLaunchKernelGGL((k_quantize<double, short>), grid1, block, 0, st, (const double *)imp_raw, stats, hw, (int)K, pred);
+        else hipLaunchKernelGGL((k_quantize<float, short>), grid1, block, 0, st, (const float *)imp_raw, stats, hw, (int)K, pred);
     }
     if (hist) {
         const float logK = (float)log((double)(pur_type == HALO_PUR_HYPER ? K : O));
-        hipLaunchKernelGGL(k_region_impurity, grid1, block, 0, st, pred, (int)H, (int)W, pksize, logK, (float *)imp_raw);
+        hipLaunchKernelGGL((k_region_impurity<short>), grid1, block, 0, st, (const short *)pred, (int)H, (int)W, pksize, logK, (float *)imp_raw, (float *)nullptr);
         hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
         nblk_imp = nblk1;
     } else if (pur_type == HALO_PUR_NONE) {
@@ -564,4 +570,73 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
     return check_launch("halo_score_maps");
+}
+
+// ---------------------------------------------------------------- helper-method entry points
+// FloatingRegionScore.compute_region_uncertainty / compute_pixel_entropy (floating_region.py:70-92,123-127)
+extern "C" int halo_region_uncertainty(const float *x, int64_t bstride, int is_prob, const int64_t *gt, int64_t B, int64_t O,
+                                       int64_t H, int64_t W, int unc_type, int ksize, int do_box, float *out,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !out || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_region_uncertainty: null/empty argument");
+    if (unc_type < 0 || unc_type > HALO_UNC_ZEROS) return fail(HALO_E_ARG, "halo_region_uncertainty: bad unc_type");
+    if (unc_type == HALO_UNC_ORACLE_ACC && !gt) return fail(HALO_E_ARG, "halo_region_uncertainty: ground_truth required");
+    if (ksize < 1 || !(ksize & 1)) return fail(HALO_E_ARG, "halo_region_uncertainty: window size must be odd");
+    const long long hw = (long long)H * W;
+    if (!workspace || workspace_bytes < (size_t)B * hw * 4 + 256) return fail(HALO_E_WORKSPACE, "halo_region_uncertainty: workspace too small");
+    float *ent = (float *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    dim3 block(TPB), grid1((unsigned)cdiv(hw, TPB), (unsigned)B);
+    float *dst = do_box ? ent : out;
+    if (unc_type == HALO_UNC_ZEROS)
+        hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(B * hw, TPB)), block, 0, st, dst, (long long)(B * hw), 0.0f);
+    else
+        hipLaunchKernelGGL(k_logit_maps_generic, grid1, block, 0, st, x, (long long)bstride, (const long long *)gt, (int)O, hw,
+                           unc_type, HALO_PUR_NONE, is_prob, dst, (short *)nullptr);
+    if (do_box)
+        hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, (const float *)ent, (int)H, (int)W, ksize, 1, 0, out, (double *)nullptr);
+    return check_launch("halo_region_uncertainty");
+}
+
+// FloatingRegionScore.compute_region_impurity(predict, K) (floating_region.py:112-121)
+extern "C" int halo_region_impurity(const int64_t *pred, int64_t B, int64_t H, int64_t W, int ksize, int64_t K, float *impurity,
+                                    float *count, void *stream)
+{
+    if (!pred || !impurity || B <= 0 || H <= 0 || W <= 0 || K < 1) return fail(HALO_E_ARG, "halo_region_impurity: null/empty argument");
+    if (ksize < 1 || !(ksize & 1)) return fail(HALO_E_ARG, "halo_region_impurity: window size must be odd");
+    const long long hw = (long long)H * W;
+    dim3 block(TPB), grid1((unsigned)cdiv(hw, TPB), (unsigned)B);
+    hipLaunchKernelGGL((k_region_impurity<long long>), grid1, block, 0, (hipStream_t)stream, (const long long *)pred, (int)H, (int)W,
+                       ksize, (float)log((double)K), impurity, count);
+    return check_launch("halo_region_impurity");
+}
+
+// FloatingRegionScore.quantize_uncert_map(decoder_out) (floating_region.py:94-110) -> int64 bins
+extern "C" int halo_quantize_radius(const void *feat, int feat_dtype, int64_t feat_bstride, int64_t B, int64_t C, int64_t H,
+                                    int64_t W, int64_t K, double c, int64_t *pred, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!feat || !pred || B <= 0 || C <= 0 || H <= 0 || W <= 0 || K < 1) return fail(HALO_E_ARG, "halo_quantize_radius: null/empty argument");
+    if (feat_dtype != HALO_F32 && feat_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_quantize_radius: bad dtype");
+    if (!workspace || workspace_bytes < halo_score_workspace_bytes(B, H, W)) return fail(HALO_E_WORKSPACE, "halo_quantize_radius: workspace too small");
+    const long long hw = (long long)H * W;
+    const int nblk1 = (int)cdiv(hw, TPB);
+    Arena ar(workspace, workspace_bytes);
+    double *imp_raw = ar.take<double>((size_t)B * hw);
+    double *part = ar.take<double>((size_t)B * nblk1 * 2);
+    double *stats = ar.take<double>((size_t)B * 4);
+    if (!ar.ok()) return fail(HALO_E_WORKSPACE, "halo_quantize_radius: workspace too small");
+    const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks;
+    dim3 block(TPB), grid1((unsigned)nblk1, (unsigned)B);
+    if (feat_dtype == HALO_F64) {
+        launch_feat<double, 1>((const double *)feat, feat_bstride, (int)C, hw, (int)B, 0, ks, rks, imp_raw, part, nblk1, st);
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, (const double *)part, nblk1, stats, 0);
+        hipLaunchKernelGGL((k_quantize<double, long long>), grid1, block, 0, st, (const double *)imp_raw, (const double *)stats, hw, (int)K, (long long *)pred);
+    } else {
+        launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, 0, ks, rks, (float *)imp_raw, part, nblk1, st);
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, (const double *)part, nblk1, stats, 0);
+        hipLaunchKernelGGL((k_quantize<float, long long>), grid1, block, 0, st, (const float *)imp_raw, (const double *)stats, hw, (int)K, (long long *)pred);
+    }
+    return check_launch("halo_quantize_radius");
 }

@@ -107,6 +107,24 @@ int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void 
                           void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
                           void *ev_feat_stop);
 
+/* Helper methods of FloatingRegionScore that are public by convention:
+ *  - compute_region_uncertainty(unc_type, logit, p, ground_truth) / compute_pixel_entropy(p)
+ *    (floating_region.py:70-92,123-127): x (B,O,H,W) f32 holds logits (is_prob=0) or softmax
+ *    probabilities (is_prob=1); do_box applies the k x k box sum; out (B,H,W) f32.
+ *    workspace: B*H*W*4 + 256 bytes.
+ *  - compute_region_impurity(predict, K) (floating_region.py:112-121): pred (B,H,W) i64 ->
+ *    impurity, count (B,H,W) f32 (count may be NULL).
+ *  - quantize_uncert_map(decoder_out) (floating_region.py:94-110): -> pred (B,H,W) i64 in [0,K-1].
+ *    workspace: halo_score_workspace_bytes(B,H,W). */
+int halo_region_uncertainty(const float *x, int64_t bstride, int is_prob, const int64_t *gt, int64_t B, int64_t O,
+                            int64_t H, int64_t W, int unc_type, int ksize, int do_box, float *out, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int halo_region_impurity(const int64_t *pred, int64_t B, int64_t H, int64_t W, int ksize, int64_t K, float *impurity,
+                         float *count, void *stream);
+int halo_quantize_radius(const void *feat, int feat_dtype, int64_t feat_bstride, int64_t B, int64_t C, int64_t H,
+                         int64_t W, int64_t K, double c, int64_t *pred, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
 /* ---- selection: select_pixels_to_label (core/active/build.py:27-64) ----
  *
  * score (B,H,W) f32|f64 is mutated (windows -> -inf) exactly like the reference; active, selected

@@ -508,6 +508,66 @@ int halo_o_floating_region_score(const float *logit, const void *feat, int feat_
     return 0;
 }
 
+/* ---- helper methods the reference exposes by convention (floating_region.py:70-127) ---- */
+
+/* compute_region_uncertainty / compute_pixel_entropy on softmax probabilities p (O,H,W) */
+void halo_o_uncertainty_from_probs(const float *p, const i64 *gt, i64 O, i64 H, i64 W, int unc_type, int ksize,
+                                   int do_box, float *out)
+{
+    const i64 hw = H * W;
+    float *ent = (float *)malloc(sizeof(float) * hw);
+#pragma omp parallel
+    {
+        float *q = (float *)malloc(sizeof(float) * (size_t)O);
+#pragma omp for schedule(static)
+        for (i64 i = 0; i < hw; ++i) {
+            for (i64 c = 0; c < O; ++c) q[c] = p[c * hw + i];
+            if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) ent[i] = entropy_px(q, O);
+            else if (unc_type == HALO_UNC_ORACLE_ACC) { i64 g = gt[i] == 255 ? argmax_px(q, O) : gt[i]; ent[i] = 1.0f - q[g]; }
+            else ent[i] = 0.0f;
+        }
+        free(q);
+    }
+    if (do_box) box_sum_f32(ent, out, H, W, ksize);
+    else for (i64 i = 0; i < hw; ++i) out[i] = ent[i];
+    free(ent);
+}
+
+/* torch.softmax(logit, dim=0) as the contract computes it */
+void halo_o_softmax(const float *logit, i64 O, i64 H, i64 W, float *p)
+{
+    const i64 hw = H * W;
+#pragma omp parallel
+    {
+        float *q = (float *)malloc(sizeof(float) * (size_t)O);
+#pragma omp for schedule(static)
+        for (i64 i = 0; i < hw; ++i) { softmax_px(logit, O, hw, i, q); for (i64 c = 0; c < O; ++c) p[c * hw + i] = q[c]; }
+        free(q);
+    }
+}
+
+void halo_o_region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *imp, float *count)
+{
+    region_impurity(pred, K, k, H, W, imp, count);
+}
+
+void halo_o_quantize(const void *feat, int feat_dtype, i64 C, i64 H, i64 W, i64 K, double c, i64 *pred)
+{
+    const i64 hw = H * W;
+    const double ks = k_sqrt(c), rks = 1.0 / ks;
+    if (feat_dtype == HALO_F64) {
+        double *r = (double *)malloc(sizeof(double) * hw);
+        for (i64 i = 0; i < hw; ++i) r[i] = dist0_from_ssq_f64(ssq_f64((const double *)feat + i, C, hw), ks, rks);
+        quantize_f64(r, hw, K, pred);
+        free(r);
+    } else {
+        float *r = (float *)malloc(sizeof(float) * hw);
+        for (i64 i = 0; i < hw; ++i) r[i] = dist0_from_ssq_f32(ssq_f32((const float *)feat + i, C, hw), ks, rks);
+        quantize_f32(r, hw, K, pred);
+        free(r);
+    }
+}
+
 /* ------------------------------------------------------------------------- *
  * select_pixels_to_label (core/active/build.py:27-64)
  * torch.max ordering: NaN beats everything; ties keep the FIRST occurrence, so the

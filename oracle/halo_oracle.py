@@ -161,6 +161,46 @@ def floating_region_score(logit, decoder_out=None, unc_type=None, pur_type=None,
     return score, imp, unc
 
 
+def softmax(logit):
+    logit = np.ascontiguousarray(logit, dtype=np.float32)
+    O, H, W = logit.shape
+    p = np.empty_like(logit)
+    lib().halo_o_softmax(_p(logit), _i64(O), _i64(H), _i64(W), _p(p))
+    return p
+
+
+def uncertainty_from_probs(p, unc_type, ground_truth=None, size=3, do_box=True):
+    """compute_region_uncertainty / compute_pixel_entropy (floating_region.py:70-92,123-127) -> (1,1,H,W)."""
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    O, H, W = p.shape
+    gt = None if ground_truth is None else np.ascontiguousarray(ground_truth, dtype=np.int64)
+    out = np.empty((1, 1, H, W), np.float32)
+    lib().halo_o_uncertainty_from_probs(_p(p), _p(gt), _i64(O), _i64(H), _i64(W), _int(UNC.get(unc_type, 3)),
+                                        _int(size), _int(1 if do_box else 0), _p(out))
+    return out
+
+
+def region_impurity(predict, K, size=3):
+    """compute_region_impurity (floating_region.py:112-121) -> (imp, count), each (1,1,H,W)."""
+    pred = np.ascontiguousarray(predict, dtype=np.int64)
+    H, W = pred.shape
+    imp = np.empty((1, 1, H, W), np.float32)
+    cnt = np.empty((1, 1, H, W), np.float32)
+    lib().halo_o_region_impurity(_p(pred), _i64(K), _int(size), _i64(H), _i64(W), _p(imp), _p(cnt))
+    return imp, cnt
+
+
+def quantize_uncert_map(decoder_out, K, c=1.0):
+    """quantize_uncert_map (floating_region.py:94-110) -> (H,W) int64."""
+    feat = np.ascontiguousarray(decoder_out)
+    if feat.ndim == 4:
+        feat = feat[0]
+    Cc, H, W = feat.shape
+    pred = np.empty((H, W), np.int64)
+    lib().halo_o_quantize(_p(feat), _int(_dt(feat)), _i64(Cc), _i64(H), _i64(W), _i64(K), _dbl(c), _p(pred))
+    return pred
+
+
 def select_pixels_to_label(score, active_regions, active_radius, mask_radius, active, selected,
                            active_mask, ground_truth, return_picks=False):
     """In-place on its numpy arguments like the reference (build.py:27-64)."""

@@ -216,6 +216,35 @@ def gen_hypermapper(hyp):
     np.savez_compressed(os.path.join(HERE, "hypermapper.npz"), **out)
 
 
+def gen_helpers(cfg, hyp, fr):
+    """FloatingRegionScore's helper methods (floating_region.py:70-127) called directly."""
+    H, W, C, O = 48, 80, 8, 19
+    cfg.MODEL.NUM_CLASSES = O
+    inp = make_inputs(hyp, H, W, C, O, seed=77)
+    out = {"meta_HWCO": np.array([H, W, C, O], dtype=np.int64)}
+    with torch.no_grad():
+        logit = inp["logit"][0]
+        p = torch.softmax(logit, dim=0)
+        out["logit"] = logit.numpy(); out["p"] = p.numpy(); out["gt"] = inp["gt"].numpy()
+        out["embed"] = inp["embed"].numpy()
+        f_hyp = fr.FloatingRegionScore(in_channels=O, size=3, purity_type="hyper", K=100)
+        f_rip = fr.FloatingRegionScore(in_channels=O, size=5, purity_type="ripu")
+        out["pixel_entropy"] = f_hyp.compute_pixel_entropy(p).numpy()
+        out["ru_entropy_k3"] = f_hyp.compute_region_uncertainty("entropy", logit, p).numpy()
+        out["ru_entropy_k5"] = f_rip.compute_region_uncertainty("entropy", logit, p).numpy()
+        out["ru_oracle_acc"] = f_hyp.compute_region_uncertainty("oracle_acc", logit, p, ground_truth=inp["gt"]).numpy()
+        out["ru_none"] = f_hyp.compute_region_uncertainty("none", logit, p).numpy()
+        out["ru_hyperbolic"] = f_hyp.compute_region_uncertainty("hyperbolic", logit, p).numpy()
+        q = f_hyp.quantize_uncert_map(inp["embed"])
+        out["quantized"] = q.numpy()
+        imp, cnt = f_hyp.compute_region_impurity(q, 100)
+        out["imp_hyper"] = imp.numpy(); out["cnt_hyper"] = cnt.numpy()
+        am = torch.argmax(p, dim=0)
+        imp, cnt = f_rip.compute_region_impurity(am, O)
+        out["argmax"] = am.numpy(); out["imp_ripu_k5"] = imp.numpy(); out["cnt_ripu_k5"] = cnt.numpy()
+    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
+
+
 class _FakeExtractor(torch.nn.Module):
     def forward(self, x):
         return x
@@ -297,9 +326,13 @@ def gen_region_selection(cfg, hyp, fr, ab):
 
 def main():
     torch.set_num_threads(4)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     cfg, hyp, fr, ab = import_reference()
     cfg.MODEL.CURVATURE = 1.0
     print("torch", torch.__version__)
+    if only == "helpers":            # add-on vectors without regenerating the rest
+        gen_helpers(cfg, hyp, fr)
+        return
     print("case A 32x64 C8 O19 (selection runs to exhaustion)")
     gen_case(cfg, hyp, fr, ab, "case_a_32x64_c8_o19", 32, 64, 8, 19, 11, 200, COMBOS)
     print("case B 64x128 C16 O19")
@@ -312,6 +345,8 @@ def main():
              [c for c in COMBOS if c[0] in ("halo", "hyper", "pixent_euc")], f32_embed=True)
     print("hypermapper last-dim API")
     gen_hypermapper(hyp)
+    print("helper methods")
+    gen_helpers(cfg, hyp, fr)
     print("RegionSelection driver, 2 rounds")
     gen_region_selection(cfg, hyp, fr, ab)
 

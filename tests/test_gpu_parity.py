@@ -398,3 +398,58 @@ def test_region_selection_driver_two_rounds(golden, dev):
             assert np.array_equal(np.array(png, dtype=np.uint8), d[f"r{rnd}_img{i}__mask_png"])
             assert np.array_equal(ind["active"].numpy(), d[f"r{rnd}_img{i}__active"])
             assert np.array_equal(ind["selected"].numpy(), d[f"r{rnd}_img{i}__selected"])
+
+
+# ------------------------------------------------------------------ helper methods and head tails
+def test_helper_methods_vs_reference_and_oracle(golden, dev):
+    from halo_amd.core.active.floating_region import FloatingRegionScore
+    from oracle import halo_oracle as ho
+    d = golden("helpers")
+    f_hyp = FloatingRegionScore(in_channels=19, size=3, purity_type="hyper", K=100)
+    f_rip = FloatingRegionScore(in_channels=19, size=5, purity_type="ripu")
+    p, logit, gt = t(d["p"], dev), t(d["logit"], dev), t(d["gt"], dev)
+    cases = {"pixel_entropy": lambda: f_hyp.compute_pixel_entropy(p),
+             "ru_entropy_k3": lambda: f_hyp.compute_region_uncertainty("entropy", logit, p),
+             "ru_entropy_k5": lambda: f_rip.compute_region_uncertainty("entropy", logit, p),
+             "ru_oracle_acc": lambda: f_hyp.compute_region_uncertainty("oracle_acc", logit, p, ground_truth=gt),
+             "ru_none": lambda: f_hyp.compute_region_uncertainty("none", logit, p),
+             "ru_hyperbolic": lambda: f_hyp.compute_region_uncertainty("hyperbolic", logit, p)}
+    ora = {"pixel_entropy": ("pixel_entropy", 3, False), "ru_entropy_k3": ("entropy", 3, True),
+           "ru_entropy_k5": ("entropy", 5, True), "ru_oracle_acc": ("oracle_acc", 3, True),
+           "ru_none": ("none", 3, False), "ru_hyperbolic": ("hyperbolic", 3, True)}
+    for key, fn in cases.items():
+        out = fn().cpu().numpy()
+        assert out.shape == d[key].shape and out.dtype == np.float32
+        assert max_abs_diff(out, d[key]) < TOL, key
+        u, size, box = ora[key]
+        assert bits_equal(out, ho.uncertainty_from_probs(d["p"], u, d["gt"], size, box)), key
+    q = f_hyp.quantize_uncert_map(t(d["embed"], dev))
+    assert q.dtype == torch.int64 and np.array_equal(q.cpu().numpy(), d["quantized"])
+    imp, cnt = f_hyp.compute_region_impurity(q, 100)
+    assert max_abs_diff(imp.cpu().numpy(), d["imp_hyper"]) < 1e-6 and np.array_equal(cnt.cpu().numpy(), d["cnt_hyper"])
+    assert bits_equal(imp.cpu().numpy(), ho.region_impurity(d["quantized"], 100, 3)[0])
+    imp, cnt = f_rip.compute_region_impurity(t(d["argmax"], dev), 19)
+    assert max_abs_diff(imp.cpu().numpy(), d["imp_ripu_k5"]) < 1e-6 and np.array_equal(cnt.cpu().numpy(), d["cnt_ripu_k5"])
+    with pytest.raises(RuntimeError):
+        f_hyp.compute_region_impurity(t(d["argmax"], dev), 19)      # 100-channel purity window, 19-class labels
+
+
+def test_head_tails(golden, dev):
+    """classifier.py:364-379 (v2: resize logits AND embedding) and :552-558 (v3+: logits only)."""
+    from halo_amd.core.models.classifier import hyper_head_tail
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
+    d = golden("case_b_64x128_c16_o19")
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    mlr = HyperMLR(C, O, c=1.0).to(dev)
+    with torch.no_grad():
+        mlr.P_MLR.copy_(t(d["P_MLR"], dev)); mlr.A_MLR.copy_(t(d["A_MLR"], dev))
+    out, emb = hyper_head_tail(t(d["z"], dev), HyperMapper(1.0), mlr, size=(H, W), resize_embed=True)
+    assert out.dtype == torch.float32 and emb.dtype == torch.float64
+    assert max_abs_diff(out.cpu().numpy(), d["logit"]) < 1e-5
+    assert max_abs_diff(emb.cpu().numpy(), d["embed"]) < 1e-14
+    out3, emb3 = hyper_head_tail(t(d["z"], dev), HyperMapper(1.0), mlr, size=(H, W))
+    assert emb3.shape[-2:] == (H // 4, W // 4) and max_abs_diff(emb3.cpu().numpy(), d["embed_lr"]) < 1e-14
+    assert np.array_equal(out3.cpu().numpy(), out.cpu().numpy())
+    mlr.P_MLR.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        mlr(t(d["embed_lr"], dev))                                   # autograd is not provided (N3)

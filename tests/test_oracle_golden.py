@@ -132,3 +132,20 @@ def test_region_selection_driver(golden):
             assert np.array_equal(act, d[f"r{rnd}_img{i}__active"])
             assert np.array_equal(sel, d[f"r{rnd}_img{i}__selected"])
             state[i] = dict(active=act, selected=sel, origin_mask=mask.astype(np.int64))
+
+
+def test_helper_methods(golden):
+    """compute_pixel_entropy / compute_region_uncertainty / quantize_uncert_map /
+    compute_region_impurity (floating_region.py:70-127) against the reference's direct outputs."""
+    d = golden("helpers")
+    assert max_abs_diff(ho.softmax(d["logit"]), d["p"]) < 1e-7
+    for key, (unc, size, box) in {"pixel_entropy": ("pixel_entropy", 3, False), "ru_entropy_k3": ("entropy", 3, True),
+                                  "ru_entropy_k5": ("entropy", 5, True), "ru_oracle_acc": ("oracle_acc", 3, True),
+                                  "ru_none": ("none", 3, False), "ru_hyperbolic": ("hyperbolic", 3, True)}.items():
+        o = ho.uncertainty_from_probs(d["p"], unc, d["gt"], size, box)
+        assert o.shape == d[key].shape and max_abs_diff(o, d[key]) < 5e-6, key
+    assert np.array_equal(ho.quantize_uncert_map(d["embed"], 100), d["quantized"])
+    i, c = ho.region_impurity(d["quantized"], 100, 3)
+    assert max_abs_diff(i, d["imp_hyper"]) < 1e-6 and np.array_equal(c, d["cnt_hyper"])
+    i, c = ho.region_impurity(d["argmax"], 19, 5)
+    assert max_abs_diff(i, d["imp_ripu_k5"]) < 1e-6 and np.array_equal(c, d["cnt_ripu_k5"])
