@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=16, help="images per step and rank")
-    ap.add_argument("--depth", type=int, default=4, help="batches in flight (selection slots)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight (selection slots)")
     ap.add_argument("--ring", type=int, default=16, help="distinct resident images per rank")
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--feat-dtype", choices=["f64", "f32"], default="f64",
@@ -88,7 +88,7 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, rank):
 class Pipeline:
     """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
 
-    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth):
+    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
@@ -109,9 +109,10 @@ class Pipeline:
         self.selected_done = [torch.cuda.Event() for _ in range(D)]
         self.ev = []                       # (start, stop) HIP events around k_feat_reduce
         self.world = world
+        self.use_dist = use_dist
         self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]
         self.gathered = [torch.zeros((world * B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)] \
-            if world > 1 else None
+            if use_dist else None
         self.step_no = 0
         self.last = None
 
@@ -141,7 +142,7 @@ class Pipeline:
             self.s_sel[k].wait_event(self.scored[k])
             picks, npk = greedy_select(self.score[k], self.n, 1, 5, self.active[k], self.selected[k], self.amask[k], gb)
             self.tables[k].copy_(picks)
-            if self.world > 1:
+            if self.use_dist:      # the path's one exchange step: per-image pick tables to every rank
                 dist.all_gather_into_tensor(self.gathered[k], self.tables[k])
             self.selected_done[k].record(self.s_sel[k])
         self.last = (k, lo, npk)
@@ -196,21 +197,24 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs ROCm devices"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): one process per GPU over RCCL, also at world 1
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world
     fdtype = torch.float64 if a.feat_dtype == "f64" else torch.float32
     Hh, Ww, C, B = a.height, a.width, a.channels, a.batch
     R = max(B, (a.ring // B) * B)
     n_regions = math.ceil(Hh * Ww * (0.05 / 5) / 9)                    # build.py:148-150 -> 2331
 
     feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist)
 
     for _ in range(a.warmup):
         pipe.step(False)
     pipe.drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -218,10 +222,10 @@ def main():
         pipe.step(True)
     pipe.drain()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -234,7 +238,8 @@ def main():
         esz = 8 if fdtype == torch.float64 else 4
         images = world * a.steps * B
         value = images / dt
-        launch_bytes = B * Hh * Ww * (C * esz + esz)                   # features read + radius map written
+        # k_feat_reduce per launch: features read + radius map written + (fused) logits read + entropy map written
+        launch_bytes = B * Hh * Ww * (C * esz + esz + O * 4 + 4)
         avg_ms = float(np.mean(feat_ms)) if feat_ms else float("nan")
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
         path_bytes_per_image = Hh * Ww * (C * esz + O * 4 + esz)
@@ -247,7 +252,7 @@ def main():
                                    "(entropy x radius, normalised, 3x3), %d regions/image, radius 1, mask radius 5"
                                    % (Hh, Ww, C, a.feat_dtype, O, n_regions),
                        "images_per_step_per_gpu": B, "batches_in_flight": a.depth, "resident_ring": R, "image_evaluations": images,
-                       "sharding": "image-wise, %d rank(s)%s" % (world, ", all-gather of pick tables per step" if world > 1 else "")},
+                       "sharding": "image-wise, %d rank(s)%s" % (world, ", RCCL all-gather of pick tables per step" if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms)},
@@ -277,7 +282,10 @@ def main():
             out["parity_vs_cpu"] = bool(np.array_equal(pk[0, :int(nk[0])].cpu().numpy(), picks_cpu[0]))
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if rank == 0 and pipe.gathered is not None:
+            k = pipe.last[0]
+            assert torch.equal(pipe.gathered[k][:B], pipe.tables[k]), "all-gathered table differs from the local one"
         dist.destroy_process_group()
 
 

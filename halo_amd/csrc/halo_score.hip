@@ -16,6 +16,7 @@
 // what ATen's CPU norm(dim=1) computes.  Algorithmic traffic: C*sizeof(T) bytes per pixel.
 #include "halo_common.hpp"
 #include "halo_devmath.hpp"
+#include <stdlib.h>
 
 namespace halo {
 
@@ -72,15 +73,13 @@ __device__ __forceinline__ void softmax_regs(float (&p)[O_T])
 
 // One pixel, classes in registers.  Writes ent (per unc_type) and pred (per pur_type).
 template <int O_T>
-__device__ __forceinline__ void logit_px(float (&p)[O_T], int unc_type, int pur_type, long long g,
-                                         float inv_dummy, float &ent, int &pred)
+__device__ __forceinline__ void logit_px(float (&p)[O_T], int unc_type, int pur_type, long long g, float &ent, int &pred)
 {
     softmax_regs<O_T>(p);
     int am = 0;               // torch.argmax: first maximal class
     float best = p[0];
 #pragma unroll
     for (int c = 1; c < O_T; ++c) { const bool gtb = p[c] > best; am = gtb ? c : am; best = gtb ? p[c] : best; }
-    (void)inv_dummy;
     if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) {
         float a = 0.0f;
 #pragma unroll
@@ -125,7 +124,7 @@ __global__ void __launch_bounds__(TPB) k_logit_maps(const float *__restrict__ lo
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const long long g = need_gt ? gt[(size_t)b * hw + i0 + j] : 0;
-        logit_px<O_T>(v[j], unc_type, pur_type, g, 0.0f, e[j], pr[j]);
+        logit_px<O_T>(v[j], unc_type, pur_type, g, e[j], pr[j]);
     }
     float *ep = ent + (size_t)b * hw + i0;
     if constexpr (VEC == 4) {
@@ -206,10 +205,15 @@ template <typename T> struct VecLoad<T, 1> {
 };
 
 // MODE 0: poincare_distance_origin (pur 'radius' / 'hyper'), MODE 1: decoder_out.norm(dim=1) ('euc_norm')
-template <typename T, int VEC, int MODE, int UNROLL>
+// FO > 0: also compute the per-pixel entropy of the FO-class logits of the same pixels (what
+// k_logit_maps does for unc 'entropy'/'pixel_entropy').  That work is ~1.7k VALU instructions per
+// pixel against 2 KiB of HBM traffic, so it runs in the memory shadow of the other resident waves
+// instead of costing a kernel of its own.
+template <typename T, int VEC, int MODE, int UNROLL, int FO>
 __global__ void __launch_bounds__(TPB) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
                                                      long long hw, double ks, double rks, T *__restrict__ out,
-                                                     double *__restrict__ partials)
+                                                     double *__restrict__ partials, const float *__restrict__ logit,
+                                                     long long lbstride, int unc_type, float *__restrict__ ent)
 {
     const int b = blockIdx.y;
     const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * VEC;
@@ -250,6 +254,29 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce(const T *__restrict__ feat,
         mn = mx = (double)r[0];
 #pragma unroll
         for (int j = 1; j < VEC; ++j) { mn = nan_min(mn, (double)r[j]); mx = nan_max(mx, (double)r[j]); }
+        if constexpr (FO > 0) {
+            const float *lp = logit + (size_t)b * lbstride + i0;
+            float lv[VEC][FO];
+#pragma unroll
+            for (int c2 = 0; c2 < FO; ++c2) {
+                if constexpr (VEC == 2) {
+                    const float2 q = *reinterpret_cast<const float2 *>(lp + (size_t)c2 * hw);
+                    lv[0][c2] = q.x; lv[1][c2] = q.y;
+                } else if constexpr (VEC == 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(lp + (size_t)c2 * hw);
+                    lv[0][c2] = q.x; lv[1][c2] = q.y; lv[2][c2] = q.z; lv[3][c2] = q.w;
+                } else {
+                    lv[0][c2] = lp[(size_t)c2 * hw];
+                }
+            }
+            float e[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { int pr; logit_px<FO>(lv[j], unc_type, HALO_PUR_NONE, 0, e[j], pr); }
+            float *ep = ent + (size_t)b * hw + i0;
+            if constexpr (VEC == 2) *reinterpret_cast<float2 *>(ep) = make_float2(e[0], e[1]);
+            else if constexpr (VEC == 4) *reinterpret_cast<float4 *>(ep) = make_float4(e[0], e[1], e[2], e[3]);
+            else ep[0] = e[0];
+        }
     }
     // dead lanes of the last block take thread 0's value (always live) so they cannot disturb min/max
     __shared__ double seed[2];
@@ -374,6 +401,65 @@ __global__ void __launch_bounds__(TPB) k_box_unc(const float *__restrict__ ent, 
     block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
+// 3 x 3 fast path (the only window the reference's drivers use: RADIUS_K = 1, build.py:83-88):
+// 4 consecutive pixels per lane, three float4 row loads plus the two edge neighbours, same
+// row-major tap order (out-of-image taps add +0) as the generic kernel.
+__global__ void __launch_bounds__(TPB) k_box3_unc(const float *__restrict__ ent, int H, int W, int pk,
+                                                  float *__restrict__ unc, double *__restrict__ partials)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)H * W;
+    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
+    const bool live = i0 < hw;
+    double mn = 0.0, mx = 0.0;
+    if (live) {
+        const int y = (int)(i0 / W), x = (int)(i0 % W);          // W % 4 == 0: the 4 pixels share a row
+        const float *ep = ent + (size_t)b * hw;
+        float r[3][6];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy >= 0 && yy < H) {
+                const float *row = ep + (size_t)yy * W;
+                const float4 q = *reinterpret_cast<const float4 *>(row + x);
+                r[dy][0] = x > 0 ? row[x - 1] : 0.0f;
+                r[dy][1] = q.x; r[dy][2] = q.y; r[dy][3] = q.z; r[dy][4] = q.w;
+                r[dy][5] = x + 4 < W ? row[x + 4] : 0.0f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) r[dy][j] = 0.0f;
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a = a + r[dy][j + dx];
+            float cnt = 1.0f;
+            if (pk > 0) {
+                const int rr = pk / 2, xx = x + j;
+                const int y0 = y - rr < 0 ? 0 : y - rr, y1 = y + rr >= H ? H - 1 : y + rr;
+                const int x0 = xx - rr < 0 ? 0 : xx - rr, x1 = xx + rr >= W ? W - 1 : xx + rr;
+                cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+            }
+            o[j] = a / cnt;
+        }
+        *reinterpret_cast<float4 *>(unc + (size_t)b * hw + i0) = make_float4(o[0], o[1], o[2], o[3]);
+        mn = mx = (double)o[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) { mn = nan_min(mn, (double)o[j]); mx = nan_max(mx, (double)o[j]); }
+    }
+    if (!partials) return;
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
+    __syncthreads();
+    if (!live) { mn = seed[0]; mx = seed[1]; }
+    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
 // per-block min/max of an existing f32 map (impurity of the histogram branches)
 __global__ void __launch_bounds__(TPB) k_minmax_f32(const float *__restrict__ x, long long hw,
                                                     double *__restrict__ partials)
@@ -430,14 +516,24 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
 // ---------------------------------------------------------------- host side
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+struct FusedLogit { const float *logit; long long bstride; int O; int unc_type; float *ent; };
+
 template <typename T, int VEC>
 static void launch_feat(const T *feat, long long bstride, int C, long long hw, int B, int mode, double ks, double rks,
-                        T *out, double *partials, int nblk, hipStream_t st)
+                        T *out, double *partials, int nblk, hipStream_t st, const FusedLogit *fl = nullptr)
 {
     dim3 grid(nblk, B), block(TPB);
     constexpr int UNROLL = 8;
-    if (mode == 0) hipLaunchKernelGGL((k_feat_reduce<T, VEC, 0, UNROLL>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, partials);
-    else hipLaunchKernelGGL((k_feat_reduce<T, VEC, 1, UNROLL>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, partials);
+#define HALO_FEAT(M, FO_)                                                                                               \
+    hipLaunchKernelGGL((k_feat_reduce<T, VEC, M, UNROLL, FO_>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, \
+                       partials, fl ? fl->logit : nullptr, fl ? fl->bstride : 0ll, fl ? fl->unc_type : 0, fl ? fl->ent : nullptr)
+    const int fo = fl ? fl->O : 0;
+    if (mode == 0) {
+        if (fo == 19) HALO_FEAT(0, 19); else if (fo == 16) HALO_FEAT(0, 16); else HALO_FEAT(0, 0);
+    } else {
+        if (fo == 19) HALO_FEAT(1, 19); else if (fo == 16) HALO_FEAT(1, 16); else HALO_FEAT(1, 0);
+    }
+#undef HALO_FEAT
 }
 
 }  // namespace halo
@@ -508,8 +604,17 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks;
     dim3 block(TPB);
 
-    // ---- logits -> ent (+ pred for ripu / oracle_ripu)
-    const bool need_logit_pass = unc_type != HALO_UNC_ZEROS || pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU;
+    // ---- logits -> ent (+ pred for ripu / oracle_ripu); fused into the feature stream when possible
+    const bool ent_only = (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) &&
+                          pur_type != HALO_PUR_RIPU && pur_type != HALO_PUR_ORACLE_RIPU;
+    const int fvec = !need_feat ? 0 : (feat_dtype == HALO_F64
+        ? (((hw % 2 == 0) && (feat_bstride % 2 == 0) && aligned16(feat) && aligned16(imp_raw)) ? 2 : 1)
+        : (((hw % 4 == 0) && (feat_bstride % 4 == 0) && aligned16(feat) && aligned16(imp_raw)) ? 4 : 1));
+    const bool fuse = need_feat && ent_only && (O == 19 || O == 16) && fvec > 1 && (logit_bstride % fvec == 0) &&
+                      (((uintptr_t)logit) % (4 * fvec) == 0) && getenv("HALO_NO_FUSE") == nullptr;
+    FusedLogit fl{logit, (long long)logit_bstride, (int)O, unc_type, ent};
+    const FusedLogit *flp = fuse ? &fl : nullptr;
+    const bool need_logit_pass = !fuse && ( unc_type != HALO_UNC_ZEROS || pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU);
     short *pred_from_logits = (pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU) ? pred : nullptr;
     if (need_logit_pass) {
         const bool vec4 = (hw % 4 == 0) && (logit_bstride % 4 == 0) && aligned16(logit) && aligned16(ent);
@@ -523,7 +628,7 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
             dim3 grid((unsigned)nblk1, (unsigned)B);
             hipLaunchKernelGGL(k_logit_maps_generic, grid, block, 0, st, logit, (long long)logit_bstride, (const long long *)gt, (int)O, hw, unc_type, pur_type, 0, ent, pred_from_logits);
         }
-    } else {
+    } else if (!fuse) {
         hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(B * hw, TPB)), block, 0, st, ent, (long long)(B * hw), 0.0f);
     }
 
@@ -534,11 +639,11 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
         const int mode = pur_type == HALO_PUR_EUC_NORM ? 1 : 0;
         if (feat_dtype == HALO_F64) {
             const bool v2 = (hw % 2 == 0) && (feat_bstride % 2 == 0) && aligned16(feat) && aligned16(imp_raw);
-            if (v2) { nblk_imp = (int)cdiv(hw, TPB * 2); launch_feat<double, 2>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st); }
+            if (v2) { nblk_imp = (int)cdiv(hw, TPB * 2); launch_feat<double, 2>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st, flp); }
             else { nblk_imp = nblk1; launch_feat<double, 1>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st); }
         } else {
             const bool v4 = (hw % 4 == 0) && (feat_bstride % 4 == 0) && aligned16(feat) && aligned16(imp_raw);
-            if (v4) { nblk_imp = (int)cdiv(hw, TPB * 4); launch_feat<float, 4>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
+            if (v4) { nblk_imp = (int)cdiv(hw, TPB * 4); launch_feat<float, 4>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st, flp); }
             else { nblk_imp = nblk1; launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
         }
         if (ev_feat_stop) (void)hipEventRecord((hipEvent_t)ev_feat_stop, st);
@@ -562,11 +667,18 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
 
     // ---- box-sum of the uncertainty, / count
     const int do_box = (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_ORACLE_ACC) ? 1 : 0;
-    hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, ent, (int)H, (int)W, ksize, do_box, hist ? pksize : 0, unc_raw, part_unc);
+    int nblk_unc = nblk1;
+    if (do_box && ksize == 3 && W % 4 == 0 && aligned16(ent) && aligned16(unc_raw)) {
+        nblk_unc = (int)cdiv(hw, TPB * 4);
+        hipLaunchKernelGGL(k_box3_unc, dim3((unsigned)nblk_unc, (unsigned)B), block, 0, st, (const float *)ent, (int)H, (int)W,
+                           hist ? pksize : 0, unc_raw, part_unc);
+    } else {
+        hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, ent, (int)H, (int)W, ksize, do_box, hist ? pksize : 0, unc_raw, part_unc);
+    }
 
     // ---- global min/max, then normalise + product
     hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_imp, nblk_imp, stats, 0);
-    hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_unc, nblk1, stats, 1);
+    hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_unc, nblk_unc, stats, 1);
     if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
     return check_launch("halo_score_maps");
