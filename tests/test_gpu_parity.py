@@ -453,3 +453,77 @@ def test_head_tails(golden, dev):
     mlr.P_MLR.requires_grad_(True)
     with pytest.raises(NotImplementedError):
         mlr(t(d["embed_lr"], dev))                                   # autograd is not provided (N3)
+
+
+def test_select_randomized_shapes_and_radii(dev):
+    """Many small maps: sizes that are not multiples of the 16x32 tile, 1-pixel-wide maps, mask
+    windows spanning many tiles (radius up to 40), active radius up to 3, heavy ties, both dtypes."""
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        H = int(rng.integers(1, 80)); W = int(rng.integers(1, 120))
+        mrad = int(rng.choice([0, 1, 2, 5, 9, 17, 40])); arad = int(rng.integers(0, 4))
+        n = int(rng.integers(1, 60))
+        dt = np.float32 if trial % 2 else np.float64
+        sc = rng.standard_normal((H, W))
+        if trial % 3 == 0:
+            sc = np.round(sc * 3) / 3
+        if trial % 7 == 0:
+            sc[rng.random((H, W)) < 0.3] = -np.inf
+        s0 = sc.astype(dt)
+        gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+        prior = rng.random((H, W)) < 0.05
+        act_o = prior.copy(); sel_o = np.zeros((H, W), bool); am_o = np.full((H, W), 255, np.int64)
+        so = s0.copy()
+        _, _, _, _, po = ho.select_pixels_to_label(so, n, arad, mrad, act_o, sel_o, am_o, gt, True)
+        s = t(s0, dev)[None].clone()
+        act = t(prior, dev)[None].clone(); sel = torch.zeros_like(act)
+        am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+        picks, npk = greedy_select(s, n, arad, mrad, act, sel, am, t(gt, dev)[None])
+        k = int(npk[0])
+        msg = f"trial {trial}: {H}x{W} mrad {mrad} arad {arad} n {n} {dt.__name__}"
+        assert k == len(po), msg
+        assert bits_equal(picks[0, :k].cpu().numpy(), po), msg
+        assert bits_equal(s[0].cpu().numpy(), so), msg
+        assert np.array_equal(act[0].cpu().numpy(), act_o), msg
+        assert np.array_equal(sel[0].cpu().numpy(), sel_o), msg
+        assert np.array_equal(am[0].cpu().numpy(), am_o), msg
+
+
+def test_large_map_uses_bigger_tiles(dev):
+    """2048x4096 exceeds the 16x32 tile table (LDS) and must switch tile shape transparently."""
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(5)
+    H, W, n = 2048, 4096, 300
+    s0 = rng.standard_normal((H, W)).astype(np.float32)
+    gt = np.zeros((H, W), np.int64)
+    act_o = np.zeros((H, W), bool); sel_o = np.zeros((H, W), bool); am_o = np.full((H, W), 255, np.int64)
+    so = s0.copy()
+    _, _, _, _, po = ho.select_pixels_to_label(so, n, 1, 5, act_o, sel_o, am_o, gt, True)
+    s = t(s0, dev)[None].clone()
+    act = torch.zeros((1, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+    am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+    picks, npk = greedy_select(s, n, 1, 5, act, sel, am, t(gt, dev)[None])
+    assert int(npk[0]) == n and bits_equal(picks[0].cpu().numpy(), po)
+    assert np.array_equal(act[0].cpu().numpy(), act_o)
+
+
+def test_views_and_batch_strides(dev):
+    """A batch that is a strided view of a larger resident pool (batch stride != C*H*W)."""
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    H, W, C, O = 32, 64, 8, 19
+    data = [_synthetic(H, W, C, O, 300 + b) for b in range(4)]
+    pool_logit = torch.cat([t(d[0], dev) for d in data]); pool_emb = torch.cat([t(d[1], dev) for d in data])
+    lv, ev = pool_logit[::2], pool_emb[::2]                       # images 0 and 2, batch stride doubled
+    assert not lv.is_contiguous()
+    s, i, u = score_maps(lv, ev, "entropy", "radius", True, None, size=3)
+    for j, b in enumerate((0, 2)):
+        so, io, uo = ho.floating_region_score(data[b][0], data[b][1], "entropy", "radius", True, None, size=3, purity_type="radius")
+        assert bits_equal(s[j].cpu().numpy(), so) and bits_equal(u[j].cpu().numpy(), uo)
+    # channels-last / permuted inputs are made contiguous by the host, results unchanged
+    perm = pool_emb[:1].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    s2, _, _ = score_maps(pool_logit[:1], perm, "entropy", "radius", True, None, size=3)
+    assert bits_equal(s2[0].cpu().numpy(), ho.floating_region_score(data[0][0], data[0][1], "entropy", "radius", True, None, size=3, purity_type="radius")[0])
