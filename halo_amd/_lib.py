@@ -33,6 +33,9 @@ SIGNATURES = {
                                _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_score_maps_timed": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
                                      _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "halo_score_lr_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "halo_score_maps_lr": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                  _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_region_uncertainty": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "halo_region_impurity": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp]),
     "halo_quantize_radius": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _sz, _vp]),
@@ -51,6 +54,10 @@ _handle = None
 
 class HaloHipError(RuntimeError):
     pass
+
+
+class HaloUnsupported(HaloHipError):
+    """The kernel declined this configuration (HALO_E_UNSUPPORTED); the caller may take another HIP route."""
 
 
 def library_path():
@@ -103,6 +110,8 @@ def check(rc, what=""):
     msg = lib().halo_last_error().decode("utf-8", "replace")
     if rc == E_UNSUPPORTED and "not implemented" in msg:
         raise NotImplementedError(msg)
+    if rc == E_UNSUPPORTED:
+        raise HaloUnsupported("%s: %s" % (what or "halo call", msg))
     raise HaloHipError("%s failed (%d): %s" % (what or "halo call", rc, msg))
 
 

@@ -15,7 +15,7 @@ from PIL import Image
 from ... import _lib
 from ..configs import cfg
 from ..utils.hyperbolic import bilinear_align_corners
-from .floating_region import FloatingRegionScore, score_maps, _workspace
+from .floating_region import FloatingRegionScore, score_maps, score_maps_lowres, _workspace
 
 
 def greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth,
@@ -89,6 +89,23 @@ def acquire_batch(logit, decoder_out, ground_truth, active, selected, active_mas
     return greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth)
 
 
+def acquire_batch_lowres(logit_lr, decoder_lr, size, ground_truth, active, selected, active_mask, *, unc_type, pur_type,
+                         normalize, n_regions, active_radius, mask_radius, ksize=None, purity_size=None, K=100, c=1.0):
+    """build.py:122-160 for B images: resize of the head outputs fused into the scorer (the C x H x W
+    embedding is never materialised), then mask + greedy selection.  Falls back to explicit HIP
+    upsampling when the fused kernel declines the geometry (strong downsampling)."""
+    ksize = 2 * active_radius + 1 if ksize is None else ksize
+    try:
+        score, _, _ = score_maps_lowres(logit_lr, decoder_lr, size, unc_type, pur_type, normalize, ground_truth,
+                                        ksize=ksize, purity_size=purity_size, K=K, c=c, active=active, want_maps=False)
+    except _lib.HaloUnsupported:
+        logit = bilinear_align_corners(logit_lr.float(), size)
+        dec = bilinear_align_corners(decoder_lr, size) if pur_type in ("hyper", "radius", "euc_norm") else decoder_lr
+        score, _, _ = score_maps(logit, dec, unc_type, pur_type, normalize, ground_truth, size=ksize,
+                                 purity_size=purity_size, K=K, c=c, active=active, want_maps=False)
+    return greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth)
+
+
 def needs_decoder_out(cfg_, uncertainty_type, purity_type):
     """build.py:127-131."""
     return (uncertainty_type in ["certainty", "hyperbolic"]
@@ -133,7 +150,6 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
             tgt_size = tgt_input.shape[-2:]
             tgt_feat = feature_extractor(tgt_input)
             tgt_out, decoder_out = classifier(tgt_feat, size=tgt_size)
-            use_dec = needs_decoder_out(cfg, uncertainty_type, purity_type)
 
             for i in range(len(origin_mask)):
                 active_mask = origin_mask[i].to(dev, non_blocking=True).long().contiguous()
@@ -143,17 +159,15 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
                 active = active_indicator[i].to(dev).bool().contiguous()
                 selected = selected_indicator[i].to(dev).bool().contiguous()
 
-                output = bilinear_align_corners(tgt_out[i:i + 1].float(), size)            # build.py:122-125
-                dec = decoder_out[i:i + 1]
-                if use_dec:
-                    dec = bilinear_align_corners(dec, size)                               # build.py:132-135
-
                 active_regions = math.ceil(num_pixel_cur * active_budget / per_region_pixels)  # build.py:148-150
-                acquire_batch(output, dec, ground_truth[None], active[None], selected[None], active_mask[None],
-                              unc_type=uncertainty_type, pur_type=purity_type, normalize=cfg.ACTIVE.NORMALIZE,
-                              n_regions=active_regions, active_radius=active_radius, mask_radius=mask_radius,
-                              size=floating_region_score.size, purity_size=floating_region_score.purity_size,
-                              K=K, c=floating_region_score.mapper.c)
+                # build.py:122-144: the two F.interpolate(align_corners=True) calls are fused into the
+                # scorer, so the C x H x W float64 embedding (4.3 GB at C=256) is never written or read
+                acquire_batch_lowres(tgt_out[i:i + 1], decoder_out[i:i + 1], size, ground_truth[None], active[None],
+                                     selected[None], active_mask[None], unc_type=uncertainty_type,
+                                     pur_type=purity_type, normalize=cfg.ACTIVE.NORMALIZE, n_regions=active_regions,
+                                     active_radius=active_radius, mask_radius=mask_radius,
+                                     ksize=floating_region_score.size, purity_size=floating_region_score.purity_size,
+                                     K=K, c=floating_region_score.mapper.c)
 
                 active_mask_np = to_np_array(active_mask)                                  # build.py:162-166
                 Image.fromarray(active_mask_np).save(path2mask[i])

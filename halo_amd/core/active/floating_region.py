@@ -101,6 +101,49 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
     return score, imp, unc
 
 
+def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
+                      ksize=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True):
+    """FloatingRegionScore.forward on the bilinear (align_corners=True) upsampling of LOW-RES sources to
+    `size`, without materialising the upsampled tensors -- core/active/build.py:122-144 in one call.
+    logit_lr (B,O,hl,wl) float32, decoder_lr (B,C,hf,wf) float64|float32.  Bit-identical to
+    bilinear_align_corners(...) followed by score_maps(...)."""
+    if pur_type not in _lib.PUR:
+        raise NotImplementedError("Error: purity type '{}' not implemented".format(pur_type))
+    dev = _lib.require_device(logit_lr, decoder_lr, ground_truth, active)
+    H, W = int(size[0]), int(size[1])
+    logit_lr = logit_lr.float().contiguous()
+    B, O, hl, wl = logit_lr.shape
+    need_feat = pur_type in ("hyper", "radius", "euc_norm")
+    feat, Cc, fdt, fbs, hf, wf = None, 0, _lib.F64, 0, 0, 0
+    if need_feat:
+        feat = decoder_lr if decoder_lr.dtype in (torch.float32, torch.float64) else decoder_lr.float()
+        feat = feat.contiguous()
+        assert feat.shape[0] == B
+        Cc, hf, wf = feat.shape[1:]
+        fdt, fbs = _lib.dtype_code(feat), feat.stride(0)
+    need_gt = unc_type == "oracle_acc" or pur_type == "oracle_ripu"
+    gt = ground_truth.reshape(B, H, W).to(torch.int64).contiguous() if need_gt else None
+    act = None
+    if active is not None:
+        act = active.reshape(B, H, W).contiguous()
+        act = act.view(torch.uint8) if act.dtype == torch.bool else act.to(torch.uint8)
+    odt = score_dtype(pur_type, feat)
+    score = torch.empty((B, H, W), dtype=odt, device=dev)
+    imp = torch.empty((B, H, W), dtype=odt, device=dev) if want_maps else None
+    unc = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_maps else None
+    L = _lib.lib()
+    nws = L.halo_score_lr_workspace_bytes(B, O, H, W)
+    ws = _workspace(dev, nws, "score")
+    psize = ksize if purity_size is None else purity_size
+    rc = L.halo_score_maps_lr(_lib.ptr(logit_lr), logit_lr.stride(0), hl, wl, _lib.ptr(feat), fdt, fbs, hf, wf,
+                              _lib.ptr(gt), _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
+                              _lib.PUR[pur_type], 1 if normalize else 0, int(ksize), int(psize), int(K), float(c),
+                              _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
+                              _lib.stream_ptr(dev))
+    _lib.check(rc, "halo_score_maps_lr")
+    return score, imp, unc
+
+
 class FloatingRegionScore(nn.Module):
     def __init__(self, in_channels=19, padding_mode="zeros", size=33, purity_type=None, K=100):
         """

@@ -21,15 +21,17 @@
 namespace halo {
 
 constexpr int TPB = 256;
+constexpr int FTPB = 128;   // k_feat_reduce: 128-thread blocks stream ~3 % faster than 256 (tools/feat_microbench.hip)
 
 // ---------------------------------------------------------------- reductions
 // torch .min()/.max() propagate NaN: once a NaN is seen the result is NaN.
 __device__ __forceinline__ double nan_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
 __device__ __forceinline__ double nan_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
 
+template <int NT = TPB>
 __device__ __forceinline__ void block_minmax(double mn, double mx, double *out2)
 {
-    __shared__ double smn[TPB / 64], smx[TPB / 64];
+    __shared__ double smn[NT / 64], smx[NT / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         mn = nan_min(mn, __shfl_xor(mn, off));
@@ -40,7 +42,7 @@ __device__ __forceinline__ void block_minmax(double mn, double mx, double *out2)
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 1; i < TPB / 64; ++i) { mn = nan_min(mn, smn[i]); mx = nan_max(mx, smx[i]); }
+        for (int i = 1; i < NT / 64; ++i) { mn = nan_min(mn, smn[i]); mx = nan_max(mx, smx[i]); }
         out2[0] = mn;
         out2[1] = mx;
     }
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_finalize(const double *__restric
     const double *p = partials + (size_t)b * nblk * 2;
     double mn = p[0], mx = p[1];
     for (int i = threadIdx.x; i < nblk; i += TPB) { mn = nan_min(mn, p[2 * i]); mx = nan_max(mx, p[2 * i + 1]); }
-    block_minmax(mn, mx, stats + b * 4 + slot * 2);
+    block_minmax<TPB>(mn, mx, stats + b * 4 + slot * 2);
 }
 
 // ---------------------------------------------------------------- logits -> entropy / prediction
@@ -210,13 +212,13 @@ template <typename T> struct VecLoad<T, 1> {
 // pixel against 2 KiB of HBM traffic, so it runs in the memory shadow of the other resident waves
 // instead of costing a kernel of its own.
 template <typename T, int VEC, int MODE, int UNROLL, int FO>
-__global__ void __launch_bounds__(TPB) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
+__global__ void __launch_bounds__(FTPB) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
                                                      long long hw, double ks, double rks, T *__restrict__ out,
                                                      double *__restrict__ partials, const float *__restrict__ logit,
                                                      long long lbstride, int unc_type, float *__restrict__ ent)
 {
     const int b = blockIdx.y;
-    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * VEC;
+    const long long i0 = ((long long)blockIdx.x * FTPB + threadIdx.x) * VEC;
     const bool live = i0 < hw;
     T acc[VEC];
 #pragma unroll
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce(const T *__restrict__ feat,
     if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
     __syncthreads();
     if (!live) { mn = seed[0]; mx = seed[1]; }
-    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    block_minmax<FTPB>(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
 // ---------------------------------------------------------------- quantize_uncert_map (floating_region.py:94-110)
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(TPB) k_box_unc(const float *__restrict__ ent, 
     if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
     __syncthreads();
     if (!live) { mn = seed[0]; mx = seed[1]; }
-    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    block_minmax<TPB>(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
 // 3 x 3 fast path (the only window the reference's drivers use: RADIUS_K = 1, build.py:83-88):
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(TPB) k_box3_unc(const float *__restrict__ ent,
     if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
     __syncthreads();
     if (!live) { mn = seed[0]; mx = seed[1]; }
-    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    block_minmax<TPB>(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
 // per-block min/max of an existing f32 map (impurity of the histogram branches)
@@ -473,7 +475,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_f32(const float *__restrict__ x,
     if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
     __syncthreads();
     if (!live) { mn = seed[0]; mx = seed[1]; }
-    block_minmax(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    block_minmax<TPB>(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
 __global__ void __launch_bounds__(TPB) k_fill_f32(float *__restrict__ x, long long n, float v)
@@ -513,6 +515,164 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
     if (unc_out) unc_out[o] = un;
 }
 
+
+// ================================================================ low-resolution sources
+// RegionSelection upsamples the head's low-resolution outputs to label size before scoring
+// (core/active/build.py:122-135): the float64 embedding becomes a C x H x W tensor (4.3 GB at C=256)
+// that is written once and read once.  These kernels consume the LOW-RES tensors directly and
+// interpolate on the fly with exactly the arithmetic of k_bilinear (halo_hyperbolic.hip), so their
+// outputs are bit-identical to "upsample, then score" while the full-resolution tensor never exists.
+
+// bilinear taps of one output coordinate, weights in the tensor's dtype (align_corners=True)
+template <typename T> struct Taps { int i0, i1; T l0, l1; };
+template <typename T>
+__device__ __forceinline__ Taps<T> make_taps(int o, T scale, int in_size)
+{
+    Taps<T> t;
+    const T f = scale * (T)o;
+    int i0 = (int)f;
+    i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+    t.i0 = i0;
+    t.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    t.l1 = f - (T)i0;
+    t.l0 = (T)1 - t.l1;
+    return t;
+}
+template <typename T>
+__device__ __forceinline__ T lerp4(T v00, T v01, T v10, T v11, T w00, T w01, T w10, T w11)
+{
+    T a = v01 * w01;
+    a = fma_t(v00, w00, a);
+    a = fma_t(v10, w10, a);
+    return fma_t(v11, w11, a);
+}
+
+constexpr int LR_TW = 64, LR_TH = 16, LR_PPT = 4;   // 64 x 16 output pixels per 256-thread block, 4 rows per thread
+
+// Features: per output pixel  sum_c (interp_c)^2  with the low-res taps of a channel chunk staged in LDS.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ feat, long long bstride, int C, int h, int w,
+                                                        int H, int W, T sh, T sw, int max_rows, int max_cols, int CC,
+                                                        double ks, double rks, T *__restrict__ out,
+                                                        double *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+    T *tile = reinterpret_cast<T *>(lr_smem);                    // [CC][max_rows][max_cols]
+    const int b = blockIdx.z;
+    const int X0 = blockIdx.x * LR_TW, Y0 = blockIdx.y * LR_TH;
+    const int lx = threadIdx.x & (LR_TW - 1), ly = threadIdx.x / LR_TW;      // ly in 0..3
+    const int x = X0 + lx;
+    // tap window of this block in the low-res grid
+    const int ylast = (Y0 + LR_TH - 1 < H ? Y0 + LR_TH - 1 : H - 1), xlast = (X0 + LR_TW - 1 < W ? X0 + LR_TW - 1 : W - 1);
+    const int ty_lo = make_taps<T>(Y0, sh, h).i0, ty_hi = make_taps<T>(ylast, sh, h).i1;
+    const int tx_lo = make_taps<T>(X0, sw, w).i0, tx_hi = make_taps<T>(xlast, sw, w).i1;
+    const int rows = ty_hi - ty_lo + 1, cols = tx_hi - tx_lo + 1;            // <= max_rows / max_cols by construction
+    const bool xin = x < W;
+    const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
+    T acc[LR_PPT], w00[LR_PPT], w01[LR_PPT], w10[LR_PPT], w11[LR_PPT];
+    int o00[LR_PPT], o10[LR_PPT];
+    bool live[LR_PPT];
+#pragma unroll
+    for (int j = 0; j < LR_PPT; ++j) {
+        const int y = Y0 + ly + j * (LR_TH / LR_PPT);
+        live[j] = xin && y < H;
+        const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
+        w00[j] = ty.l0 * tx.l0; w01[j] = ty.l0 * tx.l1; w10[j] = ty.l1 * tx.l0; w11[j] = ty.l1 * tx.l1;
+        o00[j] = (ty.i0 - ty_lo) * max_cols + (tx.i0 - tx_lo);
+        o10[j] = (ty.i1 - ty_lo) * max_cols + (tx.i0 - tx_lo);
+        acc[j] = (T)0;
+    }
+    const int dx1 = tx.i1 - tx.i0;
+    const T *fb = feat + (size_t)b * bstride;
+    const int plane = max_rows * max_cols;
+    for (int c0 = 0; c0 < C; c0 += CC) {
+        const int cc = C - c0 < CC ? C - c0 : CC;
+        __syncthreads();                                          // previous chunk fully consumed
+        for (int e = threadIdx.x; e < cc * rows * cols; e += TPB) {
+            const int ch = e / (rows * cols), r = (e / cols) % rows, q = e % cols;
+            tile[ch * plane + r * max_cols + q] = fb[((size_t)(c0 + ch) * h + (ty_lo + r)) * w + (tx_lo + q)];
+        }
+        __syncthreads();
+        for (int ch = 0; ch < cc; ++ch) {
+            const T *tp = tile + ch * plane;
+#pragma unroll
+            for (int j = 0; j < LR_PPT; ++j) {
+                const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
+                acc[j] = fma_t(v, v, acc[j]);
+            }
+        }
+    }
+    double mn = 0.0, mx = 0.0;
+    bool have = false;
+#pragma unroll
+    for (int j = 0; j < LR_PPT; ++j) {
+        if (!live[j]) continue;
+        const int y = Y0 + ly + j * (LR_TH / LR_PPT);
+        T r;
+        if constexpr (MODE == 0) r = dist0_from_ssq(acc[j], ks, rks);
+        else if constexpr (sizeof(T) == 8) r = __builtin_sqrt(acc[j]);
+        else r = __builtin_sqrtf(acc[j]);
+        out[(size_t)b * H * W + (size_t)y * W + x] = r;
+        if (!have) { mn = mx = (double)r; have = true; }
+        else { mn = nan_min(mn, (double)r); mx = nan_max(mx, (double)r); }
+    }
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }         // thread 0 (pixel X0,Y0) is always live
+    __syncthreads();
+    if (!have) { mn = seed[0]; mx = seed[1]; }
+    const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_minmax<TPB>(mn, mx, partials + blk * 2);
+}
+
+// Logits: interpolate the O class planes at one output pixel, then the same entropy / prediction code.
+template <int O_T>
+__global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__ logit, long long bstride, int h, int w, int H, int W,
+                                                       float sh, float sw, const long long *__restrict__ gt, int unc_type,
+                                                       int pur_type, float *__restrict__ ent, short *__restrict__ pred)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)H * W;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= hw) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const Taps<float> ty = make_taps<float>(y, sh, h), tx = make_taps<float>(x, sw, w);
+    const float w00 = ty.l0 * tx.l0, w01 = ty.l0 * tx.l1, w10 = ty.l1 * tx.l0, w11 = ty.l1 * tx.l1;
+    const float *lb = logit + (size_t)b * bstride;
+    const size_t a00 = (size_t)ty.i0 * w + tx.i0, a01 = (size_t)ty.i0 * w + tx.i1, a10 = (size_t)ty.i1 * w + tx.i0, a11 = (size_t)ty.i1 * w + tx.i1;
+    float p[O_T];
+#pragma unroll
+    for (int c = 0; c < O_T; ++c) {
+        const float *pl = lb + (size_t)c * h * w;
+        p[c] = lerp4<float>(pl[a00], pl[a01], pl[a10], pl[a11], w00, w01, w10, w11);
+    }
+    const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
+    const long long g = need_gt ? gt[(size_t)b * hw + i] : 0;
+    float e;
+    int pr;
+    logit_px<O_T>(p, unc_type, pur_type, g, e, pr);
+    ent[(size_t)b * hw + i] = e;
+    if (pred) pred[(size_t)b * hw + i] = (short)pr;
+}
+
+// any class count: materialise the interpolated logits of a strip into scratch, then the generic kernel
+__global__ void __launch_bounds__(TPB) k_logit_interp_lr(const float *__restrict__ logit, long long bstride, int O, int h, int w, int H,
+                                                         int W, float sh, float sw, float *__restrict__ dst)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)H * W;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= hw) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const Taps<float> ty = make_taps<float>(y, sh, h), tx = make_taps<float>(x, sw, w);
+    const float w00 = ty.l0 * tx.l0, w01 = ty.l0 * tx.l1, w10 = ty.l1 * tx.l0, w11 = ty.l1 * tx.l1;
+    const float *lb = logit + (size_t)b * bstride;
+    for (int c = 0; c < O; ++c) {
+        const float *pl = lb + (size_t)c * h * w;
+        dst[((size_t)b * O + c) * hw + i] = lerp4<float>(pl[(size_t)ty.i0 * w + tx.i0], pl[(size_t)ty.i0 * w + tx.i1],
+                                                         pl[(size_t)ty.i1 * w + tx.i0], pl[(size_t)ty.i1 * w + tx.i1], w00, w01, w10, w11);
+    }
+}
+
 // ---------------------------------------------------------------- host side
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -522,7 +682,7 @@ template <typename T, int VEC>
 static void launch_feat(const T *feat, long long bstride, int C, long long hw, int B, int mode, double ks, double rks,
                         T *out, double *partials, int nblk, hipStream_t st, const FusedLogit *fl = nullptr)
 {
-    dim3 grid(nblk, B), block(TPB);
+    dim3 grid(nblk, B), block(FTPB);
     constexpr int UNROLL = 8;
 #define HALO_FEAT(M, FO_)                                                                                               \
     hipLaunchKernelGGL((k_feat_reduce<T, VEC, M, UNROLL, FO_>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, \
@@ -544,7 +704,7 @@ extern "C" size_t halo_score_workspace_bytes(int64_t B, int64_t H, int64_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t n = (size_t)B * H * W;
-    const size_t nblk = (size_t)cdiv(H * W, TPB);
+    const size_t nblk = (size_t)cdiv(H * W, FTPB);
     size_t s = 0;
     s += align_up(n * 4, 256);                   // ent
     s += align_up(n * 4, 256);                   // unc_raw
@@ -566,12 +726,55 @@ extern "C" int halo_score_maps(const float *logit, int64_t logit_bstride, const 
                                  workspace_bytes, stream, nullptr, nullptr);
 }
 
-extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
-                                     int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
-                                     int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
-                                     int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
-                                     void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
-                                     void *ev_feat_stop)
+extern "C" size_t halo_score_lr_workspace_bytes(int64_t B, int64_t O, int64_t H, int64_t W)
+{
+    const size_t base = halo_score_workspace_bytes(B, H, W);
+    if (base == 0 || O <= 0) return 0;
+    return base + ((O == 19 || O == 16) ? 0 : (size_t)B * O * H * W * 4 + 512);
+}
+
+// low-res source geometry (halo_score_maps_lr); hl == 0 means "inputs are already full resolution"
+struct LrDims { int hl, wl, hf, wf; };
+
+template <typename T>
+static void lr_window(int out_size, int in_size, int tile, int &max_span)
+{
+    const T sc = out_size > 1 ? (T)(in_size - 1) / (T)(out_size - 1) : (T)0;
+    max_span = 1;
+    for (int o0 = 0; o0 < out_size; o0 += tile) {
+        const int ol = o0 + tile - 1 < out_size ? o0 + tile - 1 : out_size - 1;
+        T f = sc * (T)o0; int lo = (int)f; lo = lo > in_size - 1 ? in_size - 1 : lo;
+        f = sc * (T)ol; int hi = (int)f; hi = hi > in_size - 1 ? in_size - 1 : hi; hi = hi + (hi < in_size - 1 ? 1 : 0);
+        if (hi - lo + 1 > max_span) max_span = hi - lo + 1;
+    }
+}
+
+template <typename T>
+static int launch_feat_lr(const T *feat, long long bstride, int C, const LrDims &lr, int H, int W, int B, int mode, double ks,
+                          double rks, T *out, double *partials, int &nblk, hipStream_t st)
+{
+    int max_rows, max_cols;
+    lr_window<T>(H, lr.hf, LR_TH, max_rows);
+    lr_window<T>(W, lr.wf, LR_TW, max_cols);
+    const size_t plane_bytes = (size_t)max_rows * max_cols * sizeof(T);
+    if (plane_bytes > 48 * 1024) return fail(HALO_E_UNSUPPORTED, "halo_score_maps_lr: source window too large for LDS (downsampling?)");
+    int CC = (int)((48 * 1024) / plane_bytes);
+    CC = CC > C ? C : CC;
+    const T sh = H > 1 ? (T)(lr.hf - 1) / (T)(H - 1) : (T)0, sw = W > 1 ? (T)(lr.wf - 1) / (T)(W - 1) : (T)0;
+    dim3 grid((unsigned)cdiv(W, LR_TW), (unsigned)cdiv(H, LR_TH), (unsigned)B), block(TPB);
+    nblk = (int)(grid.x * grid.y);
+    const size_t lds = (size_t)CC * plane_bytes;
+    if (mode == 0) hipLaunchKernelGGL((k_feat_reduce_lr<T, 0>), grid, block, lds, st, feat, bstride, C, lr.hf, lr.wf, H, W, sh, sw, max_rows, max_cols, CC, ks, rks, out, partials);
+    else hipLaunchKernelGGL((k_feat_reduce_lr<T, 1>), grid, block, lds, st, feat, bstride, C, lr.hf, lr.wf, H, W, sh, sw, max_rows, max_cols, CC, ks, rks, out, partials);
+    return HALO_OK;
+}
+
+static int score_impl(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                      int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                      int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                      int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                      void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
+                      void *ev_feat_stop, const LrDims *lr)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
@@ -586,6 +789,9 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     if (pur_type == HALO_PUR_HYPER && (K < 1 || K > 32767)) return fail(HALO_E_UNSUPPORTED, "halo_score_maps: K out of range");
     if (O > 32767) return fail(HALO_E_UNSUPPORTED, "halo_score_maps: too many classes");
     if (workspace_bytes < halo_score_workspace_bytes(B, H, W) || !workspace) return fail(HALO_E_WORKSPACE, "halo_score_maps: workspace too small");
+    const bool lr_generic_O = lr && !(O == 19 || O == 16);
+    if (lr_generic_O && workspace_bytes < halo_score_workspace_bytes(B, H, W) + (size_t)B * O * H * W * 4 + 256)
+        return fail(HALO_E_WORKSPACE, "halo_score_maps_lr: workspace too small for %d classes", (int)O);
 
     const long long hw = (long long)H * W;
     const int nblk1 = (int)cdiv(hw, TPB);
@@ -594,9 +800,10 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     float *unc_raw = ar.take<float>((size_t)B * hw);
     double *imp_raw = ar.take<double>((size_t)B * hw);
     short *pred = ar.take<short>((size_t)B * hw);
-    double *part_imp = ar.take<double>((size_t)B * nblk1 * 2);
+    double *part_imp = ar.take<double>((size_t)B * cdiv(hw, FTPB) * 2);
     double *part_unc = ar.take<double>((size_t)B * nblk1 * 2);
     double *stats = ar.take<double>((size_t)B * 4);
+    float *lr_logit_full = lr_generic_O ? ar.take<float>((size_t)B * O * hw) : nullptr;
     if (!ar.ok()) return fail(HALO_E_WORKSPACE, "halo_score_maps: workspace too small");
 
     const bool f64out = (pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM) && feat_dtype == HALO_F64;
@@ -610,13 +817,24 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     const int fvec = !need_feat ? 0 : (feat_dtype == HALO_F64
         ? (((hw % 2 == 0) && (feat_bstride % 2 == 0) && aligned16(feat) && aligned16(imp_raw)) ? 2 : 1)
         : (((hw % 4 == 0) && (feat_bstride % 4 == 0) && aligned16(feat) && aligned16(imp_raw)) ? 4 : 1));
-    const bool fuse = need_feat && ent_only && (O == 19 || O == 16) && fvec > 1 && (logit_bstride % fvec == 0) &&
+    const bool fuse = !lr && need_feat && ent_only && (O == 19 || O == 16) && fvec > 1 && (logit_bstride % fvec == 0) &&
                       (((uintptr_t)logit) % (4 * fvec) == 0) && getenv("HALO_NO_FUSE") == nullptr;
     FusedLogit fl{logit, (long long)logit_bstride, (int)O, unc_type, ent};
     const FusedLogit *flp = fuse ? &fl : nullptr;
     const bool need_logit_pass = !fuse && ( unc_type != HALO_UNC_ZEROS || pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU);
     short *pred_from_logits = (pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU) ? pred : nullptr;
-    if (need_logit_pass) {
+    if (need_logit_pass && lr) {
+        const float shl = H > 1 ? (float)(lr->hl - 1) / (float)(H - 1) : 0.0f, swl = W > 1 ? (float)(lr->wl - 1) / (float)(W - 1) : 0.0f;
+        dim3 grid((unsigned)nblk1, (unsigned)B);
+        if (O == 19)
+            hipLaunchKernelGGL((k_logit_maps_lr<19>), grid, block, 0, st, logit, (long long)logit_bstride, lr->hl, lr->wl, (int)H, (int)W, shl, swl, (const long long *)gt, unc_type, pur_type, ent, pred_from_logits);
+        else if (O == 16)
+            hipLaunchKernelGGL((k_logit_maps_lr<16>), grid, block, 0, st, logit, (long long)logit_bstride, lr->hl, lr->wl, (int)H, (int)W, shl, swl, (const long long *)gt, unc_type, pur_type, ent, pred_from_logits);
+        else {
+            hipLaunchKernelGGL(k_logit_interp_lr, grid, block, 0, st, logit, (long long)logit_bstride, (int)O, lr->hl, lr->wl, (int)H, (int)W, shl, swl, lr_logit_full);
+            hipLaunchKernelGGL(k_logit_maps_generic, grid, block, 0, st, (const float *)lr_logit_full, (long long)(O * hw), (const long long *)gt, (int)O, hw, unc_type, pur_type, 0, ent, pred_from_logits);
+        }
+    } else if (need_logit_pass) {
         const bool vec4 = (hw % 4 == 0) && (logit_bstride % 4 == 0) && aligned16(logit) && aligned16(ent);
         if (O == 19 && vec4) {
             dim3 grid((unsigned)cdiv(hw, TPB * 4), (unsigned)B);
@@ -637,14 +855,19 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     if (need_feat) {
         if (ev_feat_start) (void)hipEventRecord((hipEvent_t)ev_feat_start, st);
         const int mode = pur_type == HALO_PUR_EUC_NORM ? 1 : 0;
-        if (feat_dtype == HALO_F64) {
+        if (lr) {
+            const int rc = feat_dtype == HALO_F64
+                ? launch_feat_lr<double>((const double *)feat, feat_bstride, (int)C, *lr, (int)H, (int)W, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st)
+                : launch_feat_lr<float>((const float *)feat, feat_bstride, (int)C, *lr, (int)H, (int)W, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st);
+            if (rc != HALO_OK) return rc;
+        } else if (feat_dtype == HALO_F64) {
             const bool v2 = (hw % 2 == 0) && (feat_bstride % 2 == 0) && aligned16(feat) && aligned16(imp_raw);
-            if (v2) { nblk_imp = (int)cdiv(hw, TPB * 2); launch_feat<double, 2>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st, flp); }
-            else { nblk_imp = nblk1; launch_feat<double, 1>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st); }
+            if (v2) { nblk_imp = (int)cdiv(hw, FTPB * 2); launch_feat<double, 2>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st, flp); }
+            else { nblk_imp = (int)cdiv(hw, FTPB); launch_feat<double, 1>((const double *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st); }
         } else {
             const bool v4 = (hw % 4 == 0) && (feat_bstride % 4 == 0) && aligned16(feat) && aligned16(imp_raw);
-            if (v4) { nblk_imp = (int)cdiv(hw, TPB * 4); launch_feat<float, 4>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st, flp); }
-            else { nblk_imp = nblk1; launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
+            if (v4) { nblk_imp = (int)cdiv(hw, FTPB * 4); launch_feat<float, 4>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st, flp); }
+            else { nblk_imp = (int)cdiv(hw, FTPB); launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
         }
         if (ev_feat_stop) (void)hipEventRecord((hipEvent_t)ev_feat_stop, st);
     }
@@ -733,22 +956,52 @@ extern "C" int halo_quantize_radius(const void *feat, int feat_dtype, int64_t fe
     if (feat_dtype != HALO_F32 && feat_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_quantize_radius: bad dtype");
     if (!workspace || workspace_bytes < halo_score_workspace_bytes(B, H, W)) return fail(HALO_E_WORKSPACE, "halo_quantize_radius: workspace too small");
     const long long hw = (long long)H * W;
-    const int nblk1 = (int)cdiv(hw, TPB);
+    const int nblk1 = (int)cdiv(hw, TPB), nblkf = (int)cdiv(hw, FTPB);
     Arena ar(workspace, workspace_bytes);
     double *imp_raw = ar.take<double>((size_t)B * hw);
-    double *part = ar.take<double>((size_t)B * nblk1 * 2);
+    double *part = ar.take<double>((size_t)B * nblkf * 2);
     double *stats = ar.take<double>((size_t)B * 4);
     if (!ar.ok()) return fail(HALO_E_WORKSPACE, "halo_quantize_radius: workspace too small");
     const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks;
     dim3 block(TPB), grid1((unsigned)nblk1, (unsigned)B);
     if (feat_dtype == HALO_F64) {
-        launch_feat<double, 1>((const double *)feat, feat_bstride, (int)C, hw, (int)B, 0, ks, rks, imp_raw, part, nblk1, st);
-        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, (const double *)part, nblk1, stats, 0);
+        launch_feat<double, 1>((const double *)feat, feat_bstride, (int)C, hw, (int)B, 0, ks, rks, imp_raw, part, nblkf, st);
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, (const double *)part, nblkf, stats, 0);
         hipLaunchKernelGGL((k_quantize<double, long long>), grid1, block, 0, st, (const double *)imp_raw, (const double *)stats, hw, (int)K, (long long *)pred);
     } else {
-        launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, 0, ks, rks, (float *)imp_raw, part, nblk1, st);
-        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, (const double *)part, nblk1, stats, 0);
+        launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, 0, ks, rks, (float *)imp_raw, part, nblkf, st);
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, (const double *)part, nblkf, stats, 0);
         hipLaunchKernelGGL((k_quantize<float, long long>), grid1, block, 0, st, (const float *)imp_raw, (const double *)stats, hw, (int)K, (long long *)pred);
     }
     return check_launch("halo_quantize_radius");
+}
+
+extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                                     int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                                     int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                                     int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                                     void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
+                                     void *ev_feat_stop)
+{
+    return score_impl(logit, logit_bstride, feat, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
+                      normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream,
+                      ev_feat_start, ev_feat_stop, nullptr);
+}
+
+// FloatingRegionScore.forward on bilinearly upsampled (align_corners=True) low-resolution sources
+// without materialising them: logit_lr (B,O,hl,wl) f32, feat_lr (B,C,hf,wf) f64|f32 -> maps (B,H,W).
+// = core/active/build.py:122-144 for B images (resize of output and decoder_out + the scorer).
+extern "C" int halo_score_maps_lr(const float *logit_lr, int64_t logit_bstride, int64_t hl, int64_t wl, const void *feat_lr,
+                                  int feat_dtype, int64_t feat_bstride, int64_t hf, int64_t wf, const int64_t *gt,
+                                  const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
+                                  int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
+                                  void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (hl <= 0 || wl <= 0) return fail(HALO_E_ARG, "halo_score_maps_lr: bad low-res logit size");
+    const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
+    if (need_feat && (hf <= 0 || wf <= 0)) return fail(HALO_E_ARG, "halo_score_maps_lr: bad low-res embedding size");
+    LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf};
+    return score_impl(logit_lr, logit_bstride, feat_lr, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
+                      normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream, nullptr,
+                      nullptr, &lr);
 }

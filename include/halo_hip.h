@@ -107,6 +107,19 @@ int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void 
                           void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
                           void *ev_feat_stop);
 
+/* The same forward on LOW-RESOLUTION sources, fusing RegionSelection's two F.interpolate calls
+ * (core/active/build.py:122-135) into the scorer: logit_lr (B,O,hl,wl) f32 and feat_lr (B,C,hf,wf)
+ * f64|f32 are interpolated on the fly (bilinear, align_corners=True) to (H,W); the C x H x W tensor is
+ * never materialised.  Results are bit-identical to halo_bilinear_upsample + halo_score_maps.
+ * Returns HALO_E_UNSUPPORTED when a source window does not fit LDS (strong downsampling): the caller
+ * then upsamples explicitly.  workspace: halo_score_lr_workspace_bytes(B, O, H, W). */
+size_t halo_score_lr_workspace_bytes(int64_t B, int64_t O, int64_t H, int64_t W);
+int halo_score_maps_lr(const float *logit_lr, int64_t logit_bstride, int64_t hl, int64_t wl, const void *feat_lr,
+                       int feat_dtype, int64_t feat_bstride, int64_t hf, int64_t wf, const int64_t *gt,
+                       const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
+                       int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
+                       void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Helper methods of FloatingRegionScore that are public by convention:
  *  - compute_region_uncertainty(unc_type, logit, p, ground_truth) / compute_pixel_entropy(p)
  *    (floating_region.py:70-92,123-127): x (B,O,H,W) f32 holds logits (is_prob=0) or softmax

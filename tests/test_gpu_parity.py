@@ -527,3 +527,74 @@ def test_views_and_batch_strides(dev):
     perm = pool_emb[:1].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     s2, _, _ = score_maps(pool_logit[:1], perm, "entropy", "radius", True, None, size=3)
     assert bits_equal(s2[0].cpu().numpy(), ho.floating_region_score(data[0][0], data[0][1], "entropy", "radius", True, None, size=3, purity_type="radius")[0])
+
+
+# ------------------------------------------------------------------ fused upsample -> score (low-res sources)
+@pytest.mark.parametrize("geom", [((16, 32), (16, 32), (64, 128)),        # x4, same grid for logits and embedding
+                                  ((40, 80), (10, 20), (64, 128)),        # the real pipeline's ratios: x1.6 and x6.4
+                                  ((23, 37), (9, 14), (50, 77)),          # odd everything
+                                  ((64, 128), (64, 128), (64, 128)),      # identity resize
+                                  ((5, 7), (3, 4), (96, 130))])           # large magnification
+@pytest.mark.parametrize("unc,pur", [("entropy", "radius"), ("entropy", "hyper"), ("entropy", "ripu"),
+                                      ("oracle_acc", "euc_norm")])
+def test_lowres_sources_equal_upsample_then_score(dev, geom, unc, pur):
+    from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
+    from halo_amd.core.utils.hyperbolic import bilinear_align_corners
+    from oracle import halo_oracle as ho
+    (hl, wl), (hf, wf), (H, W) = geom
+    rng = np.random.default_rng(hl * 1000 + hf)
+    B, C, O = 2, 12, 19
+    logit_lr = rng.standard_normal((B, O, hl, wl)).astype(np.float32)
+    emb_lr = ho.expmap((rng.standard_normal((B, C, hf, wf)) * 0.3).astype(np.float32), 1.0, dim=1)
+    gt = rng.integers(0, O, (B, H, W)).astype(np.int64)
+    act = rng.random((B, H, W)) < 0.03
+    lg, em = t(logit_lr, dev), t(emb_lr, dev)
+    a = score_maps_lowres(lg, em, (H, W), unc, pur, True, t(gt, dev), ksize=3, K=50, active=t(act, dev))
+    b = score_maps(bilinear_align_corners(lg, (H, W)), bilinear_align_corners(em, (H, W)), unc, pur, True, t(gt, dev),
+                   size=3, K=50, active=t(act, dev))
+    for x, y in zip(a, b):
+        assert bits_equal(x.cpu().numpy(), y.cpu().numpy())
+    # and against the oracle's upsample + score for image 0
+    so, io, uo = ho.floating_region_score(ho.bilinear(logit_lr[:1], (H, W)), ho.bilinear(emb_lr[:1], (H, W)), unc, pur, True,
+                                          gt[0], size=3, purity_type=pur, K=50)
+    so[act[0]] = -np.inf
+    assert bits_equal(a[0][0].cpu().numpy(), so) and bits_equal(a[1][0].cpu().numpy(), io) and bits_equal(a[2][0].cpu().numpy(), uo)
+
+
+def test_lowres_sources_f32_embedding_and_other_class_counts(dev):
+    from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
+    from halo_amd.core.utils.hyperbolic import bilinear_align_corners
+    rng = np.random.default_rng(8)
+    for O in (16, 7):
+        lg = t(rng.standard_normal((1, O, 20, 30)).astype(np.float32), dev)
+        em = t((rng.standard_normal((1, 10, 12, 18)) * 0.2).astype(np.float32), dev)
+        a = score_maps_lowres(lg, em, (60, 92), "entropy", "radius", True, None, ksize=3)
+        b = score_maps(bilinear_align_corners(lg, (60, 92)), bilinear_align_corners(em, (60, 92)), "entropy", "radius", True, None, size=3)
+        assert a[0].dtype == torch.float32
+        for x, y in zip(a, b):
+            assert bits_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
+def test_lowres_downsampling_falls_back_to_explicit_upsample(dev):
+    """A source far larger than the target does not fit the LDS window: HaloUnsupported -> explicit path."""
+    from halo_amd._lib import HaloUnsupported
+    from halo_amd.core.active.build import acquire_batch, acquire_batch_lowres
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from halo_amd.core.utils.hyperbolic import bilinear_align_corners
+    rng = np.random.default_rng(9)
+    lg = t(rng.standard_normal((1, 19, 24, 40)).astype(np.float32), dev)
+    em = t(rng.standard_normal((1, 4, 700, 1100)) * 0.05, dev)
+    with pytest.raises(HaloUnsupported):
+        score_maps_lowres(lg, em, (24, 40), "entropy", "radius", True, None)
+    gt = t(rng.integers(0, 19, (1, 24, 40)).astype(np.int64), dev)
+
+    def fresh():
+        a = torch.zeros((1, 24, 40), dtype=torch.bool, device=dev)
+        return a, torch.zeros_like(a), torch.full((1, 24, 40), 255, dtype=torch.int64, device=dev)
+    a1, s1, m1 = fresh()
+    p1, n1 = acquire_batch_lowres(lg, em, (24, 40), gt, a1, s1, m1, unc_type="entropy", pur_type="radius", normalize=True,
+                                  n_regions=5, active_radius=1, mask_radius=5)
+    a2, s2, m2 = fresh()
+    p2, n2 = acquire_batch(lg, bilinear_align_corners(em, (24, 40)), gt, a2, s2, m2, unc_type="entropy", pur_type="radius",
+                           normalize=True, n_regions=5, active_radius=1, mask_radius=5)
+    assert torch.equal(p1, p2) and torch.equal(a1, a2) and torch.equal(m1, m2)
