@@ -43,17 +43,42 @@ __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
 {
     return a.key > b.key || (a.key == b.key && a.pos < b.pos);
 }
+// Wave-wide unsigned max via DPP row shifts / row broadcasts (no LDS crossbar traffic): 6 dependent
+// VALU+DPP steps instead of 6 ds_bpermute round trips.  Result is wave-uniform (read from lane 63).
+__device__ __forceinline__ unsigned wave_umax(unsigned x)
+{
+#define HALO_DPP_MAX(ctrl, rmask)                                                                    \
+    {                                                                                                \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, true); \
+        x = o > x ? o : x;                                                                           \
+    }
+    HALO_DPP_MAX(0x111, 0xf)   // row_shr:1
+    HALO_DPP_MAX(0x112, 0xf)   // row_shr:2
+    HALO_DPP_MAX(0x114, 0xf)   // row_shr:4
+    HALO_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds its row's max
+    HALO_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    HALO_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
+#undef HALO_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// arg-max over a wave under `better`: high word, low word, then the smallest position among ties
 __device__ __forceinline__ Cand wave_best(Cand c)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Cand o;
-        o.key = __shfl_xor(c.key, off);
-        o.pos = __shfl_xor(c.pos, off);
-        if (better(o, c)) c = o;
-    }
-    return c;
+    const unsigned hi = (unsigned)(c.key >> 32), lo = (unsigned)c.key;
+    const unsigned mh = wave_umax(hi);
+    const unsigned ml = wave_umax(hi == mh ? lo : 0u);
+    const bool tie = hi == mh && lo == ml;
+    const unsigned mp = ~wave_umax(tie ? ~c.pos : 0u);
+    Cand r;
+    r.key = ((unsigned long long)mh << 32) | ml;
+    r.pos = mp;
+    return r;
 }
+
+// LDS-only barrier: orders LDS traffic between the waves of the workgroup without draining the
+// vector-memory counter (a __syncthreads() would wait for the writer wave's window stores).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct SelGeom { int H, W, th_shift, tw_shift, nty, ntx, nt; };
 
@@ -63,7 +88,8 @@ struct SelGeom { int H, W, th_shift, tw_shift, nty, ntx, nt; };
 // back to back (one memory round trip per tile instead of one per pixel row).
 template <typename T, int TSH, int TSW>
 __device__ __forceinline__ Cand tile_reduce(const T *__restrict__ sc, const SelGeom &g, int tile, int lane,
-                                            int wy0, int wy1, int wx0, int wx1)
+                                            int wy0, int wy1, int wx0, int wx1, int py0 = 1, int py1 = 0, int px0 = 1,
+                                            int px1 = 0)
 {
     constexpr int TW = 1 << TSW, NPL = (1 << (TSH + TSW)) / 64;
     static_assert(NPL >= 1, "tile smaller than a wave");
@@ -86,7 +112,8 @@ __device__ __forceinline__ Cand tile_reduce(const T *__restrict__ sc, const SelG
         const int e = lane + 64 * i;
         const int y = y0 + (e >> TSW), x = x0 + (e & (TW - 1));
         Cand c;
-        c.key = (y >= wy0 && y <= wy1 && x >= wx0 && x <= wx1) ? KEY_NEG_INF : order_key(v[i]);
+        const bool masked = (y >= wy0 && y <= wy1 && x >= wx0 && x <= wx1) || (y >= py0 && y <= py1 && x >= px0 && x <= px1);
+        c.key = masked ? KEY_NEG_INF : order_key(v[i]);
         c.pos = (unsigned)x * (unsigned)g.H + (unsigned)y;
         if (inb[i] && better(c, best)) best = c;
     }
@@ -140,13 +167,20 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
     };
     rescan();
 
+    // Per step: [A] workgroup arg-max -> [B] wave 7 writes the windows while waves 0..6 re-reduce the
+    // touched tiles -> [C] owners refresh.  Window stores are NOT waited for inside the step: the
+    // writer wave drains them at the start of the NEXT step's phase B (they had a whole step to
+    // land), and tile re-reductions mask the current AND the previous window analytically, so a
+    // tile load never depends on a store younger than two steps (memory-model argument in DESIGN.md).
     int np = 0;
+    int py0 = 1, py1 = 0, px0 = 1, px1 = 0;                              // previous window (empty)
+    const T neg_inf = sizeof(T) == 8 ? (T)__longlong_as_double(0xfff0000000000000ll) : (T)__uint_as_float(0xff800000u);
     for (int it = 0; it < n_regions; ++it) {
-        // ---- workgroup argmax
+        // ---- [A] workgroup argmax
         const Cand wb = wave_best(mine);
         const int par = (it & 1) * SEL_WAVES;
         if (lane == 0) { wkey[par + wave] = wb.key; wpos[par + wave] = wb.pos; }
-        __syncthreads();
+        lds_barrier();
         Cand top;
         top.key = wkey[par];
         top.pos = wpos[par];
@@ -160,50 +194,58 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
         if (top.key == KEY_NEG_INF || top.key == 0ull) break;            // build.py:40-41
         const int w = (int)(top.pos / (unsigned)g.H), h = (int)(top.pos % (unsigned)g.H);
 
-        // ---- windows (build.py:45-53): low side clipped at 0, high side by the slice
+        // windows (build.py:45-53): low side clipped at 0, high side by the slice
         const int my0 = h - mrad < 0 ? 0 : h - mrad, my1 = h + mrad >= g.H ? g.H - 1 : h + mrad;
         const int mx0 = w - mrad < 0 ? 0 : w - mrad, mx1 = w + mrad >= g.W ? g.W - 1 : w + mrad;
-        const int ay0 = h - arad < 0 ? 0 : h - arad, ay1 = h + arad >= g.H ? g.H - 1 : h + arad;
-        const int ax0 = w - arad < 0 ? 0 : w - arad, ax1 = w + arad >= g.W ? g.W - 1 : w + arad;
-        if (tid == 0 && picks) {
-            double *pk = picks + ((size_t)b * n_regions + np) * 3;
-            pk[0] = (double)h;
-            pk[1] = (double)w;
-            pk[2] = key_value(top.key);
-        }
-        ++np;
-        {   // score[...] = -inf ; active[...] = True   (build.py:56-57)
-            const int mw = mx1 - mx0 + 1, mn = mw * (my1 - my0 + 1);
-            for (int e = tid; e < mn; e += SEL_TPB) {
-                const size_t o = (size_t)(my0 + e / mw) * g.W + (mx0 + e % mw);
-                if constexpr (sizeof(T) == 8) sc[o] = (T)__longlong_as_double(0xfff0000000000000ll);
-                else sc[o] = (T)__uint_as_float(0xff800000u);
-                act[o] = 1;
-            }
-            // selected[...] = True ; active_mask[...] = ground_truth[...]   (build.py:58-62)
-            const int aw = ax1 - ax0 + 1, an = aw * (ay1 - ay0 + 1);
-            for (int e = tid; e < an; e += SEL_TPB) {
-                const size_t o = (size_t)(ay0 + e / aw) * g.W + (ax0 + e % aw);
-                sel[o] = 1;
-                am[o] = gtb[o];
-            }
-        }
-        // ---- re-reduce the tiles the mask window touches (one wave per tile)
         const int ty0 = my0 >> TSH, ty1 = my1 >> TSH, tx0 = mx0 >> TSW, tx1 = mx1 >> TSW;
         const int ntx_w = tx1 - tx0 + 1, ntouch = ntx_w * (ty1 - ty0 + 1);
-        for (int q = wave; q < ntouch; q += SEL_WAVES) {
-            const int t = (ty0 + q / ntx_w) * g.ntx + (tx0 + q % ntx_w);
-            const Cand c = tile_reduce<T, TSH, TSW>(sc, g, t, lane, my0, my1, mx0, mx1);
-            if (lane == 0) { tkey[t] = c.key; tpos[t] = c.pos; }
+
+        // ---- [B]
+        if (wave == SEL_WAVES - 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the previous step's stores have landed
+            const int ay0 = h - arad < 0 ? 0 : h - arad, ay1 = h + arad >= g.H ? g.H - 1 : h + arad;
+            const int ax0 = w - arad < 0 ? 0 : w - arad, ax1 = w + arad >= g.W ? g.W - 1 : w + arad;
+            const int aw = ax1 - ax0 + 1, an = aw * (ay1 - ay0 + 1);
+            const int mw = mx1 - mx0 + 1, mn = mw * (my1 - my0 + 1);
+            // selected[...] = True ; active_mask[...] = ground_truth[...]   (build.py:58-62): loads first
+            for (int e0 = 0; e0 < an; e0 += 64) {
+                const int e = e0 + lane;
+                if (e < an) {
+                    const size_t o = (size_t)(ay0 + e / aw) * g.W + (ax0 + e % aw);
+                    const long long gv = gtb[o];
+                    sel[o] = 1;
+                    am[o] = gv;
+                }
+            }
+            // score[...] = -inf ; active[...] = True   (build.py:56-57)
+            for (int e = lane; e < mn; e += 64) {
+                const size_t o = (size_t)(my0 + e / mw) * g.W + (mx0 + e % mw);
+                sc[o] = neg_inf;
+                act[o] = 1;
+            }
+            if (lane == 0 && picks) {
+                double *pk = picks + ((size_t)b * n_regions + np) * 3;
+                pk[0] = (double)h;
+                pk[1] = (double)w;
+                pk[2] = key_value(top.key);
+            }
+        } else {
+            for (int q = wave; q < ntouch; q += SEL_WAVES - 1) {
+                const int t = (ty0 + q / ntx_w) * g.ntx + (tx0 + q % ntx_w);
+                const Cand c = tile_reduce<T, TSH, TSW>(sc, g, t, lane, my0, my1, mx0, mx1, py0, py1, px0, px1);
+                if (lane == 0) { tkey[t] = c.key; tpos[t] = c.pos; }
+            }
         }
-        __syncthreads();
-        // owners of touched tiles refresh their cached best
+        ++np;
+        lds_barrier();
+        // ---- [C] owners of touched tiles refresh their cached best
         bool own = false;
         for (int q = 0; q < ntouch; ++q) {
             const int t = (ty0 + q / ntx_w) * g.ntx + (tx0 + q % ntx_w);
             own |= (t % SEL_TPB) == tid;
         }
         if (own) rescan();
+        py0 = my0; py1 = my1; px0 = mx0; px1 = mx1;
     }
     if (tid == 0 && n_picked) n_picked[b] = np;
 }
