@@ -31,6 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# more hardware queues than ROCm's default 4: the score stream and the selection streams of the
+# batches in flight must not serialise behind each other (read by the HIP runtime at initialisation)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -45,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=16, help="images per step and rank")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight (selection slots)")
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight (selection slots); 0 = 3 for f64, 6 for f32")
     ap.add_argument("--ring", type=int, default=16, help="distinct resident images per rank")
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--feat-dtype", choices=["f64", "f32"], default="f64",
@@ -204,6 +208,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == world
     fdtype = torch.float64 if a.feat_dtype == "f64" else torch.float32
+    if a.depth <= 0:
+        a.depth = 3 if a.feat_dtype == "f64" else 6
     Hh, Ww, C, B = a.height, a.width, a.channels, a.batch
     R = max(B, (a.ring // B) * B)
     n_regions = math.ceil(Hh * Ww * (0.05 / 5) / 9)                    # build.py:148-150 -> 2331

@@ -223,8 +223,39 @@ __global__ void __launch_bounds__(FTPB) k_feat_reduce(const T *__restrict__ feat
     T acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = (T)0;
+    // fused entropy of this lane's pixels (FO > 0).  Odd blocks run it BEFORE the channel loop, even
+    // blocks after it, so that at any moment about half of a CU's resident waves are in their VALU
+    // phase and half are streaming -- identical blocks launched together would otherwise move
+    // through the two phases in lockstep and the VALU work would not hide behind the loads.
+    auto entropy_part = [&]() {
+        if constexpr (FO > 0) {
+            const float *lp = logit + (size_t)b * lbstride + i0;
+            float lv[VEC][FO];
+#pragma unroll
+            for (int c2 = 0; c2 < FO; ++c2) {
+                if constexpr (VEC == 2) {
+                    const float2 q = *reinterpret_cast<const float2 *>(lp + (size_t)c2 * hw);
+                    lv[0][c2] = q.x; lv[1][c2] = q.y;
+                } else if constexpr (VEC == 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(lp + (size_t)c2 * hw);
+                    lv[0][c2] = q.x; lv[1][c2] = q.y; lv[2][c2] = q.z; lv[3][c2] = q.w;
+                } else {
+                    lv[0][c2] = lp[(size_t)c2 * hw];
+                }
+            }
+            float e[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { int pr; logit_px<FO>(lv[j], unc_type, HALO_PUR_NONE, 0, e[j], pr); }
+            float *ep = ent + (size_t)b * hw + i0;
+            if constexpr (VEC == 2) *reinterpret_cast<float2 *>(ep) = make_float2(e[0], e[1]);
+            else if constexpr (VEC == 4) *reinterpret_cast<float4 *>(ep) = make_float4(e[0], e[1], e[2], e[3]);
+            else ep[0] = e[0];
+        }
+    };
+    const bool ent_first = (blockIdx.x & 1) != 0;
     double mn = 0.0, mx = 0.0;
     if (live) {
+        if (ent_first) entropy_part();
         const T *p = feat + (size_t)b * bstride + i0;
         int c = 0;
         for (; c + UNROLL <= C; c += UNROLL) {
@@ -256,29 +287,7 @@ __global__ void __launch_bounds__(FTPB) k_feat_reduce(const T *__restrict__ feat
         mn = mx = (double)r[0];
 #pragma unroll
         for (int j = 1; j < VEC; ++j) { mn = nan_min(mn, (double)r[j]); mx = nan_max(mx, (double)r[j]); }
-        if constexpr (FO > 0) {
-            const float *lp = logit + (size_t)b * lbstride + i0;
-            float lv[VEC][FO];
-#pragma unroll
-            for (int c2 = 0; c2 < FO; ++c2) {
-                if constexpr (VEC == 2) {
-                    const float2 q = *reinterpret_cast<const float2 *>(lp + (size_t)c2 * hw);
-                    lv[0][c2] = q.x; lv[1][c2] = q.y;
-                } else if constexpr (VEC == 4) {
-                    const float4 q = *reinterpret_cast<const float4 *>(lp + (size_t)c2 * hw);
-                    lv[0][c2] = q.x; lv[1][c2] = q.y; lv[2][c2] = q.z; lv[3][c2] = q.w;
-                } else {
-                    lv[0][c2] = lp[(size_t)c2 * hw];
-                }
-            }
-            float e[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) { int pr; logit_px<FO>(lv[j], unc_type, HALO_PUR_NONE, 0, e[j], pr); }
-            float *ep = ent + (size_t)b * hw + i0;
-            if constexpr (VEC == 2) *reinterpret_cast<float2 *>(ep) = make_float2(e[0], e[1]);
-            else if constexpr (VEC == 4) *reinterpret_cast<float4 *>(ep) = make_float4(e[0], e[1], e[2], e[3]);
-            else ep[0] = e[0];
-        }
+        if (!ent_first) entropy_part();
     }
     // dead lanes of the last block take thread 0's value (always live) so they cannot disturb min/max
     __shared__ double seed[2];
