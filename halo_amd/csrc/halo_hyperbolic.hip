@@ -8,6 +8,7 @@
 // the last-dim case (inner = 1) share one kernel.
 #include "halo_common.hpp"
 #include "halo_devmath.hpp"
+#include <stdlib.h>
 
 namespace halo {
 
@@ -184,6 +185,116 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr(const double *__restrict__ x,
     }
 }
 
+
+// ---------------------------------------------------------------- HyperMLR on the f64 matrix cores
+// The two feature x prototype contractions  px = <x,-P>  and  xa = <x,A^>  ([Npix x C] . [C x 2O]) and
+// the squared norm <x,x> run on v_mfma_f64_16x16x4_f64:
+//   A operand (16 pixels x 4 channels): lane l holds x[channel 4s + (l>>4)][pixel (l&15)]
+//   B operand (4 channels x 16 columns): lane l holds Wt[channel 4s + (l>>4)][column (l&15)]
+//   D (16 x 16): lane l holds column (l&15), rows (l>>4) + 4r, r = 0..3
+// Columns are laid out in four 16-wide tiles  [-P 0..15 | -P 16..31 | A^ 0..15 | A^ 16..31]  so that the
+// P and A columns of one class sit in the same lane; a fifth MFMA per step with B := A yields the
+// Gram matrix whose diagonal is ||x||^2.  Weight chunks (MLR_KC channels) are staged in LDS; x is
+// read once, straight from its NCHW planes (16 consecutive pixels = one 128-byte line per 16 lanes).
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+constexpr int MLR_KC = 32, MLR_MT = 2, MLR_NT = 4, MLR_WPAD = 1;
+
+template <typename TOUT>
+__global__ void __launch_bounds__(HTPB) k_hypermlr_mfma(const double *__restrict__ x, const double *__restrict__ consts, int O,
+                                                        int C, long long hw, double K, TOUT *__restrict__ out)
+{
+    __shared__ double wts[MLR_NT * 16][MLR_KC + MLR_WPAD];
+    __shared__ double xx_s[HTPB / 64][MLR_MT][16];
+    __shared__ TOUT out_s[HTPB / 64][32][MLR_MT * 16 + 1];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    const long long p_base = ((long long)blockIdx.x * (HTPB / 64) + wave) * (MLR_MT * 16);
+    const double *xb = x + (size_t)b * C * hw;
+    const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    v4d_t acc[MLR_MT][MLR_NT], gram[MLR_MT];
+#pragma unroll
+    for (int m = 0; m < MLR_MT; ++m) {
+        gram[m] = (v4d_t){0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < MLR_NT; ++n) acc[m][n] = (v4d_t){0, 0, 0, 0};
+    }
+    long long pix[MLR_MT];
+#pragma unroll
+    for (int m = 0; m < MLR_MT; ++m) pix[m] = p_base + m * 16 + lc;
+    for (int c0 = 0; c0 < C; c0 += MLR_KC) {
+        __syncthreads();
+        for (int e = tid; e < MLR_NT * 16 * MLR_KC; e += HTPB) {
+            const int j = e / MLR_KC, k = e % MLR_KC, c = c0 + k;
+            const int cls = (j & 31);                             // class of this column (both halves: 0..31)
+            double v = 0.0;
+            if (cls < O && c < C) v = j < 32 ? nP[(size_t)cls * C + c] : An[(size_t)cls * C + c];
+            wts[j][k] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int kk = 0; kk < MLR_KC / 4; ++kk) {
+            const int c = c0 + kk * 4 + lk;
+            double a[MLR_MT];
+#pragma unroll
+            for (int m = 0; m < MLR_MT; ++m) a[m] = (c < C && pix[m] < hw) ? xb[(size_t)c * hw + pix[m]] : 0.0;
+#pragma unroll
+            for (int n = 0; n < MLR_NT; ++n) {
+                const double bf = wts[n * 16 + lc][kk * 4 + lk];
+#pragma unroll
+                for (int m = 0; m < MLR_MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bf, acc[m][n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < MLR_MT; ++m) gram[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], a[m], gram[m], 0, 0, 0);
+        }
+    }
+    // ||x||^2 of pixel i = Gram diagonal: lane i + 16*(i & 3), register i >> 2
+#pragma unroll
+    for (int m = 0; m < MLR_MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lk + 4 * r == lc) xx_s[wave][m][lc] = gram[m][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own-wave LDS writes visible to own-wave reads
+    __builtin_amdgcn_wave_barrier();
+    const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int o = half * 16 + lc;                             // class handled by this lane in tiles half / half+2
+        if (o < O) {
+            const double ppo = pp[o], ano = anorm[o], pao = pa[o];
+#pragma unroll
+            for (int m = 0; m < MLR_MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lk + 4 * r;
+                    const double ssq = xx_s[wave][m][row];
+                    const double nx = __builtin_sqrt(ssq), xx = nx * nx;          // torch.norm(x)**2, hyperbolic.py:136
+                    const double px = acc[m][half][r], xa = acc[m][half + 2][r];
+                    const double sqsq = ((K * xx) * K) * ppo;
+                    const double Aa = (1.0 + (2.0 * K) * px) + K * xx;
+                    const double Bb = 1.0 - K * ppo;
+                    const double D = clamp_min_nanprop((1.0 + (2.0 * K) * px) + sqsq, 1e-12);
+                    const double al = Aa / D, be = Bb / D;
+                    const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
+                    const double sq = __builtin_sqrt(mob);
+                    const double pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;
+                    const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
+                    const double md = (be * xa + al * pao) * pn;
+                    const double lamb = 2.0 / clamp_min_nanprop(1.0 - K * mp, 1e-12);
+                    const double sine = (sqK * md) * lamb;
+                    out_s[wave][o][m * 16 + row] = (TOUT)(((2.0 / sqK) * ano) * asinh(sine));
+                }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // coalesced store: each class row of this wave's 32 pixels is contiguous in the (B,O,hw) output
+    for (int e = lane; e < O * (MLR_MT * 16); e += 64) {
+        const int o = e / (MLR_MT * 16), q = e % (MLR_MT * 16);
+        const long long p = p_base + q;
+        if (p < hw) out[((size_t)b * O + o) * hw + p] = out_s[wave][o][q];
+    }
+}
+
 // ---------------------------------------------------------------- bilinear, align_corners=True
 // out = fma(v11,w11, fma(v10,w10, fma(v00,w00, v01*w01))), w_ij = ly_i*lx_j, weights in the tensor's dtype
 template <typename T>
@@ -284,6 +395,16 @@ extern "C" int halo_hypermlr_logits(const double *x, const double *P, const doub
     hipStream_t st = (hipStream_t)stream;
     double *consts = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)cdiv(O, 64)), dim3(64), 0, st, P, A, (int)O, (int)C, consts);
+    // matrix-core path: up to 32 classes (two 16-column tiles per operand); anything else takes the VALU kernel
+    if (O <= 32 && getenv("HALO_MLR_VALU") == nullptr) {
+        dim3 gridm((unsigned)cdiv(hw, (HTPB / 64) * MLR_MT * 16), (unsigned)B);
+        if (out_dtype == HALO_F32)
+            hipLaunchKernelGGL((k_hypermlr_mfma<float>), gridm, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (float *)out);
+        else if (out_dtype == HALO_F64)
+            hipLaunchKernelGGL((k_hypermlr_mfma<double>), gridm, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (double *)out);
+        else return fail(HALO_E_ARG, "halo_hypermlr_logits: bad out dtype");
+        return check_launch("halo_hypermlr_logits");
+    }
     dim3 grid(nblocks(hw), (unsigned)B);
     constexpr int OB = 10;
     if (out_dtype == HALO_F32)

@@ -598,3 +598,35 @@ def test_lowres_downsampling_falls_back_to_explicit_upsample(dev):
     p2, n2 = acquire_batch(lg, bilinear_align_corners(em, (24, 40)), gt, a2, s2, m2, unc_type="entropy", pur_type="radius",
                            normalize=True, n_regions=5, active_radius=1, mask_radius=5)
     assert torch.equal(p1, p2) and torch.equal(a1, a2) and torch.equal(m1, m2)
+
+
+def test_hypermlr_matrix_core_path_matches_valu_path(golden, dev):
+    """halo_hypermlr_logits runs its contractions on v_mfma_f64_16x16x4_f64 (<= 32 classes); the VALU
+    kernel (one fma chain per pixel/class, HALO_MLR_VALU=1) is the in-library cross-check."""
+    import os
+    from halo_amd.core.utils.hyperbolic import HyperMLR
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(21)
+    for (B, C, O, h, w) in ((1, 64, 19, 20, 36), (2, 256, 19, 16, 24), (1, 10, 16, 7, 9), (1, 33, 3, 5, 5), (1, 8, 32, 4, 13)):
+        x = ho.expmap((rng.standard_normal((B, C, h, w)) * 0.2).astype(np.float32), 1.0, dim=1)
+        x[0, :, 0, 0] = 0.0
+        mlr = HyperMLR(C, O, c=1.0).to(dev)
+        want = ho.hypermlr(x, mlr.P_MLR.detach().cpu().numpy(), mlr.A_MLR.detach().cpu().numpy(), 1.0)
+        with torch.no_grad():
+            os.environ.pop("HALO_MLR_VALU", None)
+            a = mlr(t(x, dev)).cpu().numpy()
+            a32 = mlr._hyper_logits(t(x, dev), out_dtype=torch.float32).cpu().numpy()
+            os.environ["HALO_MLR_VALU"] = "1"
+            try:
+                v = mlr(t(x, dev)).cpu().numpy()
+            finally:
+                os.environ.pop("HALO_MLR_VALU", None)
+        assert max_abs_diff(a, want) < 1e-11 and max_abs_diff(v, want) < 1e-11
+        assert max_abs_diff(a, v) < 1e-12
+        assert np.abs(a32 - want.astype(np.float32)).max() < 1e-5
+    # 33 classes: more than two column tiles -> VALU kernel
+    mlr = HyperMLR(8, 33, c=1.0).to(dev)
+    x = ho.expmap((rng.standard_normal((1, 8, 6, 6)) * 0.2).astype(np.float32), 1.0, dim=1)
+    with torch.no_grad():
+        got = mlr(t(x, dev)).cpu().numpy()
+    assert max_abs_diff(got, ho.hypermlr(x, mlr.P_MLR.detach().cpu().numpy(), mlr.A_MLR.detach().cpu().numpy(), 1.0)) < 1e-11
