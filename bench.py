@@ -54,13 +54,16 @@ def parse():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--feat-dtype", choices=["f64", "f32"], default="f64",
                     help="f64 = what the reference's hyperbolic head hands over (hyperbolic.py:37)")
+    ap.add_argument("--source", choices=["fullres", "lowres"], default="fullres",
+                    help="fullres = SURVEY 8(d) unit of work (default, the BASELINE metric); lowres = the "
+                         "RegionSelection boundary: x4 low-res head outputs, upsampling fused into the scorer (N1)")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
 
 
-def make_ring(dev, R, C, Hh, Ww, fdtype, rank):
+def make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres=False):
     """Synthetic pool per SURVEY.md 8(d): low-res latent z ~ N(0, 0.1^2), seed 1234+image index;
     embed = expmap0_project(z); logit = HyperMLR(embed), P/A ~ kaiming_uniform(a=sqrt 5) seed 7;
     both upsampled x4 (align_corners) -- all by this package's own kernels, untimed."""
@@ -69,8 +72,9 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, rank):
     mapper = HyperMapper(c=1.0)
     torch.manual_seed(7)
     mlr = HyperMLR(C, O, c=1.0).to(dev)
-    feat = torch.empty((R, C, Hh, Ww), dtype=fdtype, device=dev)
-    logit = torch.empty((R, O, Hh, Ww), dtype=torch.float32, device=dev)
+    fs, ls = ((h, w), (h, w)) if lowres else ((Hh, Ww), (Hh, Ww))
+    feat = torch.empty((R, C) + fs, dtype=fdtype, device=dev)
+    logit = torch.empty((R, O) + ls, dtype=torch.float32, device=dev)
     gt = torch.empty((R, Hh, Ww), dtype=torch.int64, device=dev)
     with torch.no_grad():
         for r in range(R):
@@ -78,10 +82,14 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, rank):
             z = torch.randn((1, C, h, w), generator=g, device=dev, dtype=torch.float32) * 0.1
             emb = mapper.expmap(z, dim=1)
             lg = mlr._hyper_logits(emb, out_dtype=torch.float32)
-            logit[r:r + 1] = bilinear_align_corners(lg, (Hh, Ww))
-            up = bilinear_align_corners(emb, (Hh, Ww))
-            feat[r:r + 1] = up if fdtype == torch.float64 else up.float()
-            del up
+            if lowres:
+                logit[r:r + 1] = lg
+                feat[r:r + 1] = emb if fdtype == torch.float64 else emb.float()
+            else:
+                logit[r:r + 1] = bilinear_align_corners(lg, (Hh, Ww))
+                up = bilinear_align_corners(emb, (Hh, Ww))
+                feat[r:r + 1] = up if fdtype == torch.float64 else up.float()
+                del up
             lab = torch.randint(0, O, (Hh, Ww), generator=g, device=dev, dtype=torch.int64)
             lab[torch.rand((Hh, Ww), generator=g, device=dev) < 0.05] = 255
             gt[r] = lab
@@ -92,12 +100,14 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, rank):
 class Pipeline:
     """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
 
-    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False):
+    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
         self.R = feat.shape[0]
-        Hh, Ww = feat.shape[-2:]
+        self.lowres = lowres
+        Hh, Ww = gt.shape[-2:]
+        self.size = (Hh, Ww)
         # The greedy selector is latency-bound (2331 dependent steps per image, one workgroup per
         # image, ~20 ms per batch) while scoring is bandwidth-bound (~6 ms per batch): keep `depth`
         # batches in flight, each slot selecting on its own stream, so selection hides behind scoring.
@@ -122,7 +132,7 @@ class Pipeline:
 
     def step(self, timed):
         from halo_amd.core.active.build import greedy_select
-        from halo_amd.core.active.floating_region import score_maps
+        from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
         B, R = self.B, self.R
         k = self.step_no % self.D
         lo = (self.step_no * B) % R
@@ -139,8 +149,13 @@ class Pipeline:
             self.active[k].zero_()
             self.selected[k].zero_()
             self.amask[k].fill_(255)
-            score_maps(lb, fb, "entropy", "radius", True, None, size=3, c=1.0, active=self.active[k],
-                       want_maps=False, out=self.score[k], events=evs)
+            if self.lowres:
+                sc, _, _ = score_maps_lowres(lb, fb, self.size, "entropy", "radius", True, None, ksize=3, c=1.0,
+                                             active=self.active[k], want_maps=False)
+                self.score[k].copy_(sc)
+            else:
+                score_maps(lb, fb, "entropy", "radius", True, None, size=3, c=1.0, active=self.active[k],
+                           want_maps=False, out=self.score[k], events=evs)
             self.scored[k].record(self.s_score)
         with torch.cuda.stream(self.s_sel[k]):
             self.s_sel[k].wait_event(self.scored[k])
@@ -214,8 +229,11 @@ def main():
     R = max(B, (a.ring // B) * B)
     n_regions = math.ceil(Hh * Ww * (0.05 / 5) / 9)                    # build.py:148-150 -> 2331
 
-    feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist)
+    lowres = a.source == "lowres"
+    if lowres:
+        a.cpu_images = 0
+    feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres)
 
     for _ in range(a.warmup):
         pipe.step(False)
@@ -247,7 +265,7 @@ def main():
         # k_feat_reduce per launch: features read + radius map written + (fused) logits read + entropy map written
         launch_bytes = B * Hh * Ww * (C * esz + esz + O * 4 + 4)
         avg_ms = float(np.mean(feat_ms)) if feat_ms else float("nan")
-        achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
+        achieved = launch_bytes / (avg_ms * 1e-3) / 1e9 if feat_ms else float("nan")
         path_bytes_per_image = Hh * Ww * (C * esz + O * 4 + esz)
         out = {
             "metric": "acquisition-scored images/sec (1024x2048, C=256, 19 cls)",
@@ -264,6 +282,11 @@ def main():
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms)},
             "path_algorithmic_GBps": round(path_bytes_per_image * value / world / 1e9, 1),
         }
+        if lowres:      # not the BASELINE unit of work: a different (smaller) input boundary, reported for DESIGN.md
+            out["config"]["workload"] = "RegionSelection boundary (N1): x4 low-res head outputs (%dx%d), upsample fused into the scorer, " \
+                                        "then the same mask + select; NOT the BASELINE unit of work" % (Hh // 4, Ww // 4)
+            out["roofline"] = None
+            out["path_algorithmic_GBps"] = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc):
             try:

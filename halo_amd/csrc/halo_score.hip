@@ -556,6 +556,7 @@ __device__ __forceinline__ T lerp4(T v00, T v01, T v10, T v11, T w00, T w01, T w
     return fma_t(v11, w11, a);
 }
 
+constexpr int LR_STAGE_IT = 2, LR_STAGE_G = 4;      // window elements per lane with precomputed offsets (<= 128 taps), channels per group
 constexpr int LR_TW = 64, LR_TH = 16, LR_PPT = 4;   // 64 x 16 output pixels per 256-thread block, 4 rows per thread
 
 // Features: per output pixel  sum_c (interp_c)^2  with the low-res taps of a channel chunk staged in LDS.
@@ -594,12 +595,46 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
     const int dx1 = tx.i1 - tx.i0;
     const T *fb = feat + (size_t)b * bstride;
     const int plane = max_rows * max_cols;
+    // staging offsets of this lane inside one channel plane of the window
+    int st_src[LR_STAGE_IT], st_dst[LR_STAGE_IT];
+    bool st_ok[LR_STAGE_IT];
+#pragma unroll
+    for (int it = 0; it < LR_STAGE_IT; ++it) {
+        const int e = (threadIdx.x & 63) + 64 * it;
+        const int r = e / cols, q = e % cols;
+        st_ok[it] = e < rows * cols;
+        st_src[it] = (ty_lo + r) * w + (tx_lo + q);
+        st_dst[it] = r * max_cols + q;
+    }
     for (int c0 = 0; c0 < C; c0 += CC) {
         const int cc = C - c0 < CC ? C - c0 : CC;
         __syncthreads();                                          // previous chunk fully consumed
-        for (int e = threadIdx.x; e < cc * rows * cols; e += TPB) {
-            const int ch = e / (rows * cols), r = (e / cols) % rows, q = e % cols;
-            tile[ch * plane + r * max_cols + q] = fb[((size_t)(c0 + ch) * h + (ty_lo + r)) * w + (tx_lo + q)];
+        // stage the chunk: a wave walks the channels (LR_STAGE_G at a time), its lanes walk the window with
+        // precomputed offsets; all loads of a group are issued before the first LDS write so that the
+        // group costs one memory round trip, not one per load
+        for (int ch0 = threadIdx.x >> 6; ch0 < cc; ch0 += (TPB / 64) * LR_STAGE_G) {
+            T v[LR_STAGE_G][LR_STAGE_IT];
+#pragma unroll
+            for (int gI = 0; gI < LR_STAGE_G; ++gI) {
+                const int ch = ch0 + gI * (TPB / 64);
+                const T *src = fb + (size_t)(c0 + (ch < cc ? ch : 0)) * h * w;
+#pragma unroll
+                for (int it = 0; it < LR_STAGE_IT; ++it) v[gI][it] = (st_ok[it] && ch < cc) ? src[st_src[it]] : (T)0;
+            }
+#pragma unroll
+            for (int gI = 0; gI < LR_STAGE_G; ++gI) {
+                const int ch = ch0 + gI * (TPB / 64);
+                if (ch < cc) {
+                    T *dst = tile + ch * plane;
+#pragma unroll
+                    for (int it = 0; it < LR_STAGE_IT; ++it)
+                        if (st_ok[it]) dst[st_dst[it]] = v[gI][it];
+                    for (int e = (threadIdx.x & 63) + 64 * LR_STAGE_IT; e < rows * cols; e += 64) {   // very large windows
+                        const int r = e / cols, q = e % cols;
+                        dst[r * max_cols + q] = fb[(size_t)(c0 + ch) * h * w + (size_t)(ty_lo + r) * w + (tx_lo + q)];
+                    }
+                }
+            }
         }
         __syncthreads();
         for (int ch = 0; ch < cc; ++ch) {
@@ -767,7 +802,13 @@ static int launch_feat_lr(const T *feat, long long bstride, int C, const LrDims 
     lr_window<T>(W, lr.wf, LR_TW, max_cols);
     const size_t plane_bytes = (size_t)max_rows * max_cols * sizeof(T);
     if (plane_bytes > 48 * 1024) return fail(HALO_E_UNSUPPORTED, "halo_score_maps_lr: source window too large for LDS (downsampling?)");
-    int CC = (int)((48 * 1024) / plane_bytes);
+    // a small chunk (<= 16 KiB of LDS per block) keeps 8 blocks resident per CU, so one block's staging
+    // loads overlap the others' interpolation (there is no intra-block double buffering)
+    size_t budget = 16 * 1024;
+    if (const char *e = getenv("HALO_LR_LDS_KB")) budget = (size_t)atoi(e) * 1024;
+    if (budget < plane_bytes) budget = plane_bytes;
+    if (budget > 48 * 1024) budget = 48 * 1024;
+    int CC = (int)(budget / plane_bytes);
     CC = CC > C ? C : CC;
     const T sh = H > 1 ? (T)(lr.hf - 1) / (T)(H - 1) : (T)0, sw = W > 1 ? (T)(lr.wf - 1) / (T)(W - 1) : (T)0;
     dim3 grid((unsigned)cdiv(W, LR_TW), (unsigned)cdiv(H, LR_TH), (unsigned)B), block(TPB);
