@@ -140,7 +140,7 @@ class Pipeline:
             lo = 0
         fb, lb, gb = self.feat[lo:lo + B], self.logit[lo:lo + B], self.gt[lo:lo + B]
         evs = None
-        if timed:
+        if timed and not self.lowres:
             evs = (self.lib.halo_event_create(), self.lib.halo_event_create())
             self.ev.append(evs)
         with torch.cuda.stream(self.s_score):
