@@ -113,67 +113,67 @@ def needs_decoder_out(cfg_, uncertainty_type, purity_type):
             or (uncertainty_type == "none" and cfg_.MODEL.HYPER))
 
 
+class AcquisitionParams:
+    """What RegionSelection reads from cfg (build.py:75-88), resolved once."""
+
+    def __init__(self, cfg_):
+        act = cfg_.ACTIVE
+        self.radius = act.RADIUS_K
+        self.mask_radius = act.MASK_RADIUS_K
+        self.window = 2 * self.radius + 1
+        self.round_budget = act.BUDGET / len(act.SELECT_ITER)          # per image, per round
+        self.unc, self.pur, self.K = act.UNCERTAINTY, act.PURITY, act.K
+        self.normalize = act.NORMALIZE
+        self.scorer = FloatingRegionScore(in_channels=cfg_.MODEL.NUM_CLASSES, size=self.window,
+                                          purity_type=self.pur, K=self.K)
+        if self.pur not in _lib.PUR:
+            raise NotImplementedError("Error: purity type '{}' not implemented".format(self.pur))
+        self.scorer._check_purity_channels(self.pur)
+
+    def regions(self, n_pixels):
+        """build.py:148-150"""
+        return math.ceil(n_pixels * self.round_budget / self.window ** 2)
+
+
+def _acquire_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev):
+    """One image of the pool (build.py:113-160) on the device; returns (mask uint8 ndarray, active, selected)
+    as host objects ready to persist."""
+    amask = origin_mask.to(dev, non_blocking=True).long().contiguous()
+    gt = origin_label.to(dev, non_blocking=True).long().contiguous()
+    active = active_cpu.to(dev).bool().contiguous()
+    selected = selected_cpu.to(dev).bool().contiguous()
+    # the two F.interpolate(align_corners=True) calls of build.py:122-135 are fused into the scorer: the
+    # C x H x W float64 embedding (4.3 GB at C=256) is never written or read
+    acquire_batch_lowres(logit_lr, embed_lr, size, gt[None], active[None], selected[None], amask[None],
+                         unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
+                         n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
+                         mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
+                         K=prm.K, c=prm.scorer.mapper.c)
+    return to_np_array(amask), active.cpu(), selected.cpu()
+
+
 def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number):
+    """Drop-in for build.py:71-186: same arguments, same files written (uint8 mode-L PNG mask at
+    path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode."""
+    prm = AcquisitionParams(cfg)
+    dev = torch.device("cuda", torch.cuda.current_device())
     feature_extractor.eval()
     classifier.eval()
-
-    per_region_pixels = (2 * cfg.ACTIVE.RADIUS_K + 1) ** 2
-    active_radius = cfg.ACTIVE.RADIUS_K
-    mask_radius = cfg.ACTIVE.MASK_RADIUS_K
-    active_budget = cfg.ACTIVE.BUDGET / len(cfg.ACTIVE.SELECT_ITER)
-    uncertainty_type = cfg.ACTIVE.UNCERTAINTY
-    purity_type = cfg.ACTIVE.PURITY
-    K = cfg.ACTIVE.K
-
-    floating_region_score = FloatingRegionScore(
-        in_channels=cfg.MODEL.NUM_CLASSES, size=2 * active_radius + 1, purity_type=purity_type, K=K)
-    if purity_type not in _lib.PUR:
-        raise NotImplementedError("Error: purity type '{}' not implemented".format(purity_type))
-    floating_region_score._check_purity_channels(purity_type)
-    dev = torch.device("cuda", torch.cuda.current_device())
-
+    moved = False
     with torch.no_grad():
-        idx = 0
-        for tgt_data in tgt_epoch_loader:
-            tgt_input, path2mask = tgt_data["img"], tgt_data["path_to_mask"]
-            origin_mask, origin_label = tgt_data["origin_mask"], tgt_data["origin_label"]
-            origin_size = tgt_data["size"]
-            active_indicator = tgt_data["active"]
-            selected_indicator = tgt_data["selected"]
-            path2indicator = tgt_data["path_to_indicator"]
-
-            tgt_input = tgt_input.to(dev, non_blocking=True)
-            if idx == 0:
-                feature_extractor.to(tgt_input.device)
-                classifier.to(tgt_input.device)
-
-            tgt_size = tgt_input.shape[-2:]
-            tgt_feat = feature_extractor(tgt_input)
-            tgt_out, decoder_out = classifier(tgt_feat, size=tgt_size)
-
-            for i in range(len(origin_mask)):
-                active_mask = origin_mask[i].to(dev, non_blocking=True).long().contiguous()
-                ground_truth = origin_label[i].to(dev, non_blocking=True).long().contiguous()
-                size = (int(origin_size[i][0]), int(origin_size[i][1]))
-                num_pixel_cur = size[0] * size[1]
-                active = active_indicator[i].to(dev).bool().contiguous()
-                selected = selected_indicator[i].to(dev).bool().contiguous()
-
-                active_regions = math.ceil(num_pixel_cur * active_budget / per_region_pixels)  # build.py:148-150
-                # build.py:122-144: the two F.interpolate(align_corners=True) calls are fused into the
-                # scorer, so the C x H x W float64 embedding (4.3 GB at C=256) is never written or read
-                acquire_batch_lowres(tgt_out[i:i + 1], decoder_out[i:i + 1], size, ground_truth[None], active[None],
-                                     selected[None], active_mask[None], unc_type=uncertainty_type,
-                                     pur_type=purity_type, normalize=cfg.ACTIVE.NORMALIZE, n_regions=active_regions,
-                                     active_radius=active_radius, mask_radius=mask_radius,
-                                     ksize=floating_region_score.size, purity_size=floating_region_score.purity_size,
-                                     K=K, c=floating_region_score.mapper.c)
-
-                active_mask_np = to_np_array(active_mask)                                  # build.py:162-166
-                Image.fromarray(active_mask_np).save(path2mask[i])
-                indicator = {"active": active.cpu(), "selected": selected.cpu()}
-                torch.save(indicator, path2indicator[i])
-            idx += 1
-
+        for batch in tgt_epoch_loader:
+            images = batch["img"].to(dev, non_blocking=True)
+            if not moved:
+                feature_extractor.to(dev)
+                classifier.to(dev)
+                moved = True
+            logits_lr, embed_lr = classifier(feature_extractor(images), size=images.shape[-2:])
+            for i in range(len(batch["origin_mask"])):          # loader batch size is 1 in the reference
+                size = (int(batch["size"][i][0]), int(batch["size"][i][1]))
+                mask_np, active, selected = _acquire_one(
+                    prm, logits_lr[i:i + 1], embed_lr[i:i + 1], size, batch["origin_mask"][i], batch["origin_label"][i],
+                    batch["active"][i], batch["selected"][i], dev)
+                Image.fromarray(mask_np).save(batch["path_to_mask"][i])                     # build.py:162-164
+                torch.save({"active": active, "selected": selected}, batch["path_to_indicator"][i])   # :165-166
     feature_extractor.train()
     classifier.train()
