@@ -187,104 +187,134 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr(const double *__restrict__ x,
 
 
 // ---------------------------------------------------------------- HyperMLR on the f64 matrix cores
-// The two feature x prototype contractions  px = <x,-P>  and  xa = <x,A^>  ([Npix x C] . [C x 2O]) and
-// the squared norm <x,x> run on v_mfma_f64_16x16x4_f64:
+// The two feature x prototype contractions  px = <x,-P>  and  xa = <x,A^>  ([Npix x C] . [C x 2O]) run on
+// v_mfma_f64_16x16x4_f64:
 //   A operand (16 pixels x 4 channels): lane l holds x[channel 4s + (l>>4)][pixel (l&15)]
 //   B operand (4 channels x 16 columns): lane l holds Wt[channel 4s + (l>>4)][column (l&15)]
 //   D (16 x 16): lane l holds column (l&15), rows (l>>4) + 4r, r = 0..3
-// Columns are laid out in four 16-wide tiles  [-P 0..15 | -P 16..31 | A^ 0..15 | A^ 16..31]  so that the
-// P and A columns of one class sit in the same lane; a fifth MFMA per step with B := A yields the
-// Gram matrix whose diagonal is ||x||^2.  Weight chunks (MLR_KC channels) are staged in LDS; x is
-// read once, straight from its NCHW planes (16 consecutive pixels = one 128-byte line per 16 lanes).
+// Column tiles (NT of them, 16 columns each) keep the -P and A^ column of a class in ONE lane:
+//   NT = 2 (O <= 16): [-P 0..15 | A^ 0..15]
+//   NT = 3 (O <= 24): [-P 0..15 | A^ 0..15 | -P 16..23, A^ 16..23]   (the last tile pairs lane j with lane j+8)
+//   NT = 4 (O <= 32): [-P 0..15 | A^ 0..15 | -P 16..31 | A^ 16..31]
+// so 19 classes cost 3 MFMAs per 16 pixels x 4 channels (38 of 48 columns useful).  ||x||^2 is accumulated
+// on the VALU beside the matrix pipe (lane (l&15, l>>4) sums channels = l>>4 mod 4, combined at the end).
+// Weight chunks (MLR_KC channels) are staged in LDS; x is read once, straight from its NCHW planes
+// (16 consecutive pixels = one 128-byte line per 16 lanes); results leave through an LDS transpose as
+// contiguous class rows.
 typedef double v4d_t __attribute__((ext_vector_type(4)));
-constexpr int MLR_KC = 32, MLR_MT = 2, MLR_NT = 4, MLR_WPAD = 1;
+constexpr int MLR_KC = 32, MLR_MT = 2, MLR_WPAD = 1;
 
-template <typename TOUT>
+template <typename TOUT, int NT>
 __global__ void __launch_bounds__(HTPB) k_hypermlr_mfma(const double *__restrict__ x, const double *__restrict__ consts, int O,
                                                         int C, long long hw, double K, TOUT *__restrict__ out)
 {
-    __shared__ double wts[MLR_NT * 16][MLR_KC + MLR_WPAD];
+    __shared__ double wts[NT * 16][MLR_KC + MLR_WPAD];
     __shared__ double xx_s[HTPB / 64][MLR_MT][16];
-    __shared__ TOUT out_s[HTPB / 64][32][MLR_MT * 16 + 1];
+    __shared__ TOUT out_s[HTPB / 64][NT == 2 ? 16 : (NT == 3 ? 24 : 32)][MLR_MT * 16 + 1];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
     const long long p_base = ((long long)blockIdx.x * (HTPB / 64) + wave) * (MLR_MT * 16);
     const double *xb = x + (size_t)b * C * hw;
     const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
-    v4d_t acc[MLR_MT][MLR_NT], gram[MLR_MT];
+    v4d_t acc[MLR_MT][NT];
+    double ss[MLR_MT];
 #pragma unroll
     for (int m = 0; m < MLR_MT; ++m) {
-        gram[m] = (v4d_t){0, 0, 0, 0};
+        ss[m] = 0.0;
 #pragma unroll
-        for (int n = 0; n < MLR_NT; ++n) acc[m][n] = (v4d_t){0, 0, 0, 0};
+        for (int n = 0; n < NT; ++n) acc[m][n] = (v4d_t){0, 0, 0, 0};
     }
     long long pix[MLR_MT];
 #pragma unroll
     for (int m = 0; m < MLR_MT; ++m) pix[m] = p_base + m * 16 + lc;
+    // x operands of a whole chunk (MLR_KC/4 k-steps x MLR_MT tiles) are requested up front and one chunk
+    // ahead, so their HBM latency hides behind the previous chunk's MFMAs and the weight staging
+    auto load_chunk = [&](int c0, double (&dst)[MLR_KC / 4][MLR_MT]) {
+#pragma unroll
+        for (int kk = 0; kk < MLR_KC / 4; ++kk) {
+            const int c = c0 + kk * 4 + lk;
+#pragma unroll
+            for (int m = 0; m < MLR_MT; ++m) dst[kk][m] = (c < C && pix[m] < hw) ? xb[(size_t)c * hw + pix[m]] : 0.0;
+        }
+    };
+    double a_cur[MLR_KC / 4][MLR_MT], a_nxt[MLR_KC / 4][MLR_MT];
+    load_chunk(0, a_cur);
     for (int c0 = 0; c0 < C; c0 += MLR_KC) {
+        if (c0 + MLR_KC < C) load_chunk(c0 + MLR_KC, a_nxt);
         __syncthreads();
-        for (int e = tid; e < MLR_NT * 16 * MLR_KC; e += HTPB) {
+        for (int e = tid; e < NT * 16 * MLR_KC; e += HTPB) {
             const int j = e / MLR_KC, k = e % MLR_KC, c = c0 + k;
-            const int cls = (j & 31);                             // class of this column (both halves: 0..31)
+            const int tile = j >> 4, col = j & 15;
+            int cls;
+            bool isA;
+            if (tile == 0) { cls = col; isA = false; }
+            else if (tile == 1) { cls = col; isA = true; }
+            else if (NT == 3) { cls = 16 + (col & 7); isA = col >= 8; }
+            else { cls = 16 + col; isA = tile == 3; }
             double v = 0.0;
-            if (cls < O && c < C) v = j < 32 ? nP[(size_t)cls * C + c] : An[(size_t)cls * C + c];
+            if (cls < O && c < C) v = isA ? An[(size_t)cls * C + c] : nP[(size_t)cls * C + c];
             wts[j][k] = v;
         }
         __syncthreads();
-#pragma unroll 2
+#pragma unroll
         for (int kk = 0; kk < MLR_KC / 4; ++kk) {
-            const int c = c0 + kk * 4 + lk;
-            double a[MLR_MT];
 #pragma unroll
-            for (int m = 0; m < MLR_MT; ++m) a[m] = (c < C && pix[m] < hw) ? xb[(size_t)c * hw + pix[m]] : 0.0;
-#pragma unroll
-            for (int n = 0; n < MLR_NT; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 const double bf = wts[n * 16 + lc][kk * 4 + lk];
 #pragma unroll
-                for (int m = 0; m < MLR_MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bf, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MLR_MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[kk][m], bf, acc[m][n], 0, 0, 0);
             }
 #pragma unroll
-            for (int m = 0; m < MLR_MT; ++m) gram[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], a[m], gram[m], 0, 0, 0);
+            for (int m = 0; m < MLR_MT; ++m) ss[m] = __builtin_fma(a_cur[kk][m], a_cur[kk][m], ss[m]);
         }
+#pragma unroll
+        for (int kk = 0; kk < MLR_KC / 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < MLR_MT; ++m) a_cur[kk][m] = a_nxt[kk][m];
     }
-    // ||x||^2 of pixel i = Gram diagonal: lane i + 16*(i & 3), register i >> 2
+    // ||x||^2 of pixel lc: the four channel-residue partial sums live in lanes lc, lc+16, lc+32, lc+48
+#pragma unroll
+    for (int m = 0; m < MLR_MT; ++m) {
+        double t = ss[m] + __shfl_xor(ss[m], 16);
+        t = t + __shfl_xor(t, 32);
+        if (lk == 0) xx_s[wave][m][lc] = t;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes before its own reads
+    __builtin_amdgcn_wave_barrier();
+    const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
+    auto logit_of = [&](double px, double xa, double ssq, int o) -> double {
+        const double ppo = pp[o], ano = anorm[o], pao = pa[o];
+        const double nx = __builtin_sqrt(ssq), xx = nx * nx;          // torch.norm(x)**2, hyperbolic.py:136
+        const double sqsq = ((K * xx) * K) * ppo;
+        const double Aa = (1.0 + (2.0 * K) * px) + K * xx;
+        const double Bb = 1.0 - K * ppo;
+        const double D = clamp_min_nanprop((1.0 + (2.0 * K) * px) + sqsq, 1e-12);
+        const double al = Aa / D, be = Bb / D;
+        const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
+        const double sq = __builtin_sqrt(mob);
+        const double pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;
+        const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
+        const double md = (be * xa + al * pao) * pn;
+        const double lamb = 2.0 / clamp_min_nanprop(1.0 - K * mp, 1e-12);
+        const double sine = (sqK * md) * lamb;
+        return ((2.0 / sqK) * ano) * asinh(sine);
+    };
 #pragma unroll
     for (int m = 0; m < MLR_MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (lk + 4 * r == lc) xx_s[wave][m][lc] = gram[m][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own-wave LDS writes visible to own-wave reads
-    __builtin_amdgcn_wave_barrier();
-    const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int o = half * 16 + lc;                             // class handled by this lane in tiles half / half+2
-        if (o < O) {
-            const double ppo = pp[o], ano = anorm[o], pao = pa[o];
-#pragma unroll
-            for (int m = 0; m < MLR_MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = lk + 4 * r;
-                    const double ssq = xx_s[wave][m][row];
-                    const double nx = __builtin_sqrt(ssq), xx = nx * nx;          // torch.norm(x)**2, hyperbolic.py:136
-                    const double px = acc[m][half][r], xa = acc[m][half + 2][r];
-                    const double sqsq = ((K * xx) * K) * ppo;
-                    const double Aa = (1.0 + (2.0 * K) * px) + K * xx;
-                    const double Bb = 1.0 - K * ppo;
-                    const double D = clamp_min_nanprop((1.0 + (2.0 * K) * px) + sqsq, 1e-12);
-                    const double al = Aa / D, be = Bb / D;
-                    const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
-                    const double sq = __builtin_sqrt(mob);
-                    const double pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;
-                    const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
-                    const double md = (be * xa + al * pao) * pn;
-                    const double lamb = 2.0 / clamp_min_nanprop(1.0 - K * mp, 1e-12);
-                    const double sine = (sqK * md) * lamb;
-                    out_s[wave][o][m * 16 + row] = (TOUT)(((2.0 / sqK) * ano) * asinh(sine));
-                }
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            const double ssq = xx_s[wave][m][row];
+            if (lc < O) out_s[wave][lc][m * 16 + row] = (TOUT)logit_of(acc[m][0][r], acc[m][1][r], ssq, lc);
+            if constexpr (NT == 3) {
+                const double xa_hi = __shfl(acc[m][2][r], (lane + 8) & 63);      // A^ column of class 16 + lc sits 8 lanes up
+                const int o = 16 + lc;
+                if (lc < 8 && o < O) out_s[wave][o][m * 16 + row] = (TOUT)logit_of(acc[m][2][r], xa_hi, ssq, o);
+            } else if constexpr (NT == 4) {
+                const int o = 16 + lc;
+                if (o < O) out_s[wave][o][m * 16 + row] = (TOUT)logit_of(acc[m][2][r], acc[m][3][r], ssq, o);
+            }
         }
-    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     // coalesced store: each class row of this wave's 32 pixels is contiguous in the (B,O,hw) output
@@ -398,11 +428,11 @@ extern "C" int halo_hypermlr_logits(const double *x, const double *P, const doub
     // matrix-core path: up to 32 classes (two 16-column tiles per operand); anything else takes the VALU kernel
     if (O <= 32 && getenv("HALO_MLR_VALU") == nullptr) {
         dim3 gridm((unsigned)cdiv(hw, (HTPB / 64) * MLR_MT * 16), (unsigned)B);
-        if (out_dtype == HALO_F32)
-            hipLaunchKernelGGL((k_hypermlr_mfma<float>), gridm, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (float *)out);
-        else if (out_dtype == HALO_F64)
-            hipLaunchKernelGGL((k_hypermlr_mfma<double>), gridm, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (double *)out);
-        else return fail(HALO_E_ARG, "halo_hypermlr_logits: bad out dtype");
+        if (out_dtype != HALO_F32 && out_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_hypermlr_logits: bad out dtype");
+#define HALO_MLR(T, NT_) hipLaunchKernelGGL((k_hypermlr_mfma<T, NT_>), gridm, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (T *)out)
+        if (out_dtype == HALO_F32) { if (O <= 16) HALO_MLR(float, 2); else if (O <= 24) HALO_MLR(float, 3); else HALO_MLR(float, 4); }
+        else { if (O <= 16) HALO_MLR(double, 2); else if (O <= 24) HALO_MLR(double, 3); else HALO_MLR(double, 4); }
+#undef HALO_MLR
         return check_launch("halo_hypermlr_logits");
     }
     dim3 grid(nblocks(hw), (unsigned)B);
