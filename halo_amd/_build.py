@@ -37,9 +37,25 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every .hip translation unit for gfx950 and link libhalo_hip.so."""
+    """Compile every .hip translation unit for gfx950 and link libhalo_hip.so.
+
+    Safe under concurrent callers (one process per GPU under torch.distributed.run all import the
+    package at once): the build runs under an exclusive file lock and re-checks staleness inside it."""
     if not force and not is_stale():
         return SO
+    import fcntl
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    with open(os.path.join(CSRC, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return SO
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -56,7 +72,7 @@ def build(force=False, verbose=False):
         if verbose and out.strip():
             print(out)
         objs.append(obj)
-    tmp = SO + ".tmp"
+    tmp = SO + ".tmp.%d" % os.getpid()
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

@@ -32,7 +32,14 @@ def build(force=False):
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
-        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+        import fcntl
+        os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+        with open(os.path.join(_HERE, "_build", ".lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _SO
 
 
