@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--source", choices=["fullres", "lowres"], default="fullres",
                     help="fullres = SURVEY 8(d) unit of work (default, the BASELINE metric); lowres = the "
                          "RegionSelection boundary: x4 low-res head outputs, upsampling fused into the scorer (N1)")
-    ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=4, help="images in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
