@@ -135,32 +135,66 @@ class AcquisitionParams:
         return math.ceil(n_pixels * self.round_budget / self.window ** 2)
 
 
-def _acquire_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev):
-    """One image of the pool (build.py:113-160) on the device; returns (mask uint8 ndarray, active, selected)
-    as host objects ready to persist."""
-    amask = origin_mask.to(dev, non_blocking=True).long().contiguous()
-    gt = origin_label.to(dev, non_blocking=True).long().contiguous()
-    active = active_cpu.to(dev).bool().contiguous()
-    selected = selected_cpu.to(dev).bool().contiguous()
-    # the two F.interpolate(align_corners=True) calls of build.py:122-135 are fused into the scorer: the
-    # C x H x W float64 embedding (4.3 GB at C=256) is never written or read
-    acquire_batch_lowres(logit_lr, embed_lr, size, gt[None], active[None], selected[None], amask[None],
-                         unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
-                         n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
-                         mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
-                         K=prm.K, c=prm.scorer.mapper.c)
-    return to_np_array(amask), active.cpu(), selected.cpu()
+class _InFlight:
+    """One image whose scoring + selection has been enqueued on the acquisition stream."""
+    __slots__ = ("amask", "active", "selected", "done", "path_mask", "path_indicator", "keep")
 
 
-def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number):
-    """Drop-in for build.py:71-186: same arguments, same files written (uint8 mode-L PNG mask at
-    path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode."""
+def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, stream):
+    """Enqueue one image of the pool (build.py:113-160) on `stream`: stage its masks, then
+    score -> mask -> select.  Asynchronous; the caller retires it with _retire()."""
+    rec = _InFlight()
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))             # the head outputs are complete from here on
+    with torch.cuda.stream(stream):
+        stream.wait_event(ready)
+        rec.amask = origin_mask.to(dev, non_blocking=True).long().contiguous()
+        gt = origin_label.to(dev, non_blocking=True).long().contiguous()
+        rec.active = active_cpu.to(dev, non_blocking=True).bool().contiguous()
+        rec.selected = selected_cpu.to(dev, non_blocking=True).bool().contiguous()
+        # the two F.interpolate(align_corners=True) calls of build.py:122-135 are fused into the scorer:
+        # the C x H x W float64 embedding (4.3 GB at C=256) is never written or read
+        acquire_batch_lowres(logit_lr, embed_lr, size, gt[None], rec.active[None], rec.selected[None], rec.amask[None],
+                             unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
+                             n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
+                             mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
+                             K=prm.K, c=prm.scorer.mapper.c)
+        rec.done = torch.cuda.Event()
+        rec.done.record(stream)
+    rec.keep = (logit_lr, embed_lr, gt)                      # alive until the side stream is done with them
+    return rec
+
+
+def _persist(mask_np, active, selected, path_mask, path_indicator):
+    """build.py:162-166: uint8 mode-L PNG + torch.save'd indicator dict (what cityscapes.py:234-251 reads back)."""
+    Image.fromarray(mask_np).save(path_mask)
+    torch.save({"active": active, "selected": selected}, path_indicator)
+
+
+def _retire(rec, writers, pending):
+    rec.done.synchronize()
+    job = (to_np_array(rec.amask), rec.active.cpu(), rec.selected.cpu(), rec.path_mask, rec.path_indicator)
+    rec.keep = None
+    pending.append(writers.submit(_persist, *job))
+
+
+def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=3, writer_threads=4):
+    """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
+    at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
+    every file on disk when the call returns.
+
+    Inside, image i's score + greedy selection runs on a side stream while the backbone processes
+    image i+1, and PNG encoding / torch.save run on a small thread pool: in the reference
+    both serialise with the 2331-step selection loop of every image."""
+    from concurrent.futures import ThreadPoolExecutor
     prm = AcquisitionParams(cfg)
     dev = torch.device("cuda", torch.cuda.current_device())
+    side = torch.cuda.Stream(dev, priority=-1)
     feature_extractor.eval()
     classifier.eval()
     moved = False
-    with torch.no_grad():
+    queue, pending = [], []
+    with ThreadPoolExecutor(max_workers=max(1, writer_threads)) as writers, torch.no_grad():
         for batch in tgt_epoch_loader:
             images = batch["img"].to(dev, non_blocking=True)
             if not moved:
@@ -170,10 +204,15 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
             logits_lr, embed_lr = classifier(feature_extractor(images), size=images.shape[-2:])
             for i in range(len(batch["origin_mask"])):          # loader batch size is 1 in the reference
                 size = (int(batch["size"][i][0]), int(batch["size"][i][1]))
-                mask_np, active, selected = _acquire_one(
-                    prm, logits_lr[i:i + 1], embed_lr[i:i + 1], size, batch["origin_mask"][i], batch["origin_label"][i],
-                    batch["active"][i], batch["selected"][i], dev)
-                Image.fromarray(mask_np).save(batch["path_to_mask"][i])                     # build.py:162-164
-                torch.save({"active": active, "selected": selected}, batch["path_to_indicator"][i])   # :165-166
+                rec = _launch_one(prm, logits_lr[i:i + 1], embed_lr[i:i + 1], size, batch["origin_mask"][i],
+                                  batch["origin_label"][i], batch["active"][i], batch["selected"][i], dev, side)
+                rec.path_mask, rec.path_indicator = batch["path_to_mask"][i], batch["path_to_indicator"][i]
+                queue.append(rec)
+                while len(queue) > max(1, in_flight):
+                    _retire(queue.pop(0), writers, pending)
+        while queue:
+            _retire(queue.pop(0), writers, pending)
+        for f in pending:
+            f.result()                                           # surface I/O errors; all files are on disk
     feature_extractor.train()
     classifier.train()

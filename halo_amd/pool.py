@@ -106,7 +106,7 @@ def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_load
     kw = dict(batch_size=1, shuffle=False, num_workers=0, pin_memory=True, drop_last=False)
     kw.update(loader_kwargs or {})
     loader = DataLoader(Subset(dataset, range(lo, hi)), **kw)
-    RegionSelection(cfg, feature_extractor, classifier, loader, round_number)
+    RegionSelection(cfg, feature_extractor, classifier, loader, round_number)      # pipelined, async writers
     if world > 1:
         dist.barrier(group=group)
     return lo, hi

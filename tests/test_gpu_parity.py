@@ -671,3 +671,39 @@ def test_selection_is_stable_beside_streaming_kernels(dev):
             assert k == len(want[b][0]), (rep, b)
             assert bits_equal(picks[b, :k].cpu().numpy(), want[b][0]), (rep, b)
             assert np.array_equal(act[b].cpu().numpy(), want[b][1]) and np.array_equal(am[b].cpu().numpy(), want[b][2]), (rep, b)
+
+
+def test_region_selection_pipelined_pool_vs_oracle(dev):
+    """More images than the in-flight depth, mixed label sizes, non-x4 resize ratios: every mask /
+    indicator file equals the oracle driver's result, and all files exist when the call returns."""
+    from PIL import Image
+    from halo_amd.core.active.build import RegionSelection
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(31)
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+    tmp = tempfile.mkdtemp(prefix="halo_rs2_")
+    sizes = [(48, 96), (64, 80), (48, 96), (40, 120), (64, 80), (48, 96), (56, 72)]
+    items, outs, oracle_in = [], [], []
+    for i, (H, W) in enumerate(sizes):
+        emb_lr = ho.expmap((rng.standard_normal((1, 8, 10, 20)) * 0.2).astype(np.float32), 1.0, dim=1)
+        logit_lr = rng.standard_normal((1, 19, 30, 50)).astype(np.float32)
+        gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+        act = rng.random((H, W)) < 0.02
+        items.append({"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [os.path.join(tmp, f"m{i}.png")],
+                      "origin_mask": torch.full((1, H, W), 255, dtype=torch.int64), "origin_label": torch.from_numpy(gt)[None],
+                      "size": torch.tensor([[H, W]]), "active": torch.from_numpy(act)[None],
+                      "selected": torch.zeros(1, H, W, dtype=torch.bool),
+                      "path_to_indicator": [os.path.join(tmp, f"i{i}.pth")], "name": [f"img{i}"]})
+        outs.append((t(logit_lr, dev), t(emb_lr, dev)))
+        oracle_in.append(dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act,
+                              selected=np.zeros((H, W), bool), origin_mask=np.full((H, W), 255, np.int64)))
+    RegionSelection(cfg, _Fake(), _Fake(outs), items, 1, in_flight=2, writer_threads=3)
+    want = ho.region_selection(cfg, oracle_in)
+    for i, (mask, act, sel, _) in enumerate(want):
+        png = np.array(Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8)
+        ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+        assert np.array_equal(png, mask), i
+        assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
