@@ -293,7 +293,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("dtype") == a.feat_dtype:
+                if rec.get("batch") == B and rec.get("dtype") == a.feat_dtype and rec.get("shape_HWCO") == [Hh, Ww, C, O]:
                     out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json"
             except Exception:
