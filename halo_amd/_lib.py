@@ -27,6 +27,9 @@ SIGNATURES = {
     "halo_pdist": (_int, [_vp, _vp, _vp, _i64, _i64, _dbl, _vp]),
     "halo_hypermlr_workspace_bytes": (_sz, [_i64, _i64]),
     "halo_hypermlr_logits": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _vp, _sz, _vp]),
+    "halo_expmap0_project_bwd": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _dbl, _vp]),
+    "halo_hypermlr_bwd_terms": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _sz, _vp]),
     "halo_bilinear_upsample": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp]),
     "halo_score_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "halo_score_maps": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,

@@ -21,6 +21,17 @@ def hyper_head_tail(feat, mapper: HyperMapper, conv_seg: HyperMLR, size=None, re
 
     resize_embed=False: DeepLab-v3+ tail (classifier.py:552-558); True: DeepLab-v2 tail, which also
     resizes the embedding (classifier.py:375-377)."""
+    training = torch.is_grad_enabled() and (feat.requires_grad or conv_seg.P_MLR.requires_grad)
+    if training:
+        # expmap and HyperMLR carry HIP backward kernels; the resize stays on F.interpolate, which autograd
+        # already differentiates (it is outside the kernels' scope under training)
+        embed = mapper.expmap(feat, dim=1)
+        out = conv_seg(embed).float()
+        if size is not None:
+            out = torch.nn.functional.interpolate(out, size=size, mode="bilinear", align_corners=True)
+            if resize_embed:
+                embed = torch.nn.functional.interpolate(embed, size=size, mode="bilinear", align_corners=True)
+        return out, embed
     with torch.no_grad():
         embed = mapper.expmap(feat, dim=1)
         out = conv_seg._hyper_logits(embed, out_dtype=torch.float32)

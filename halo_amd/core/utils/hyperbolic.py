@@ -3,8 +3,12 @@
 Same class names, method names, argument meaning, parameter names (`P_MLR`, `A_MLR`, float64,
 kaiming-uniform(a=sqrt(5)) -- checkpoint keys `classifier.conv_seg.P_MLR/A_MLR` load unchanged)
 and dtypes as the reference.  The arithmetic (geoopt's stereographic math in the reference,
-hyperbolic.py:8) runs in halo_amd/csrc/halo_hyperbolic.hip.  Inference only: the kernels have
-no autograd; a call that needs gradients raises instead of silently detaching.
+hyperbolic.py:8) runs in halo_amd/csrc/halo_hyperbolic.hip.
+
+Autograd: `HyperMapper.expmap` and `HyperMLR.forward` -- the two ops of the head
+tail the training step differentiates (core/models/classifier.py:553-554) -- are
+torch.autograd.Functions with HIP backward kernels; the other methods (logmap, distances) are
+inference-only and raise if a gradient is requested instead of silently detaching.
 """
 import math
 
@@ -36,6 +40,108 @@ def _split(shape, dim):
     return dim, outer, shape[dim], inner
 
 
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _expmap_forward(x, c, dim):
+    dev = _lib.require_device(x)
+    x = x.contiguous()
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.double()
+    y = torch.empty(x.shape, dtype=torch.float64, device=dev)
+    if x.numel():
+        _, outer, C, inner = _split(x.shape, dim)
+        _lib.check(_lib.lib().halo_expmap0_project(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(y), outer, C, inner,
+                                                   float(c), _lib.stream_ptr(dev)), "halo_expmap0_project")
+    return x, y
+
+
+class _ExpmapFn(torch.autograd.Function):
+    """y = project(expmap0(x.double()))  (hyperbolic.py:37-38) with the HIP Jacobian-transpose product."""
+
+    @staticmethod
+    def forward(ctx, x, c, dim):
+        xc, y = _expmap_forward(x.detach(), c, dim)
+        ctx.save_for_backward(xc)
+        ctx.c, ctx.dim, ctx.in_dtype = c, dim, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xc,) = ctx.saved_tensors
+        dev = xc.device
+        gy = gy.double().contiguous()
+        gx = torch.empty_like(xc)
+        if xc.numel():
+            _, outer, C, inner = _split(xc.shape, ctx.dim)
+            _lib.check(_lib.lib().halo_expmap0_project_bwd(_lib.ptr(xc), _lib.dtype_code(xc), _lib.ptr(gy), _lib.ptr(gx),
+                                                           outer, C, inner, float(ctx.c), _lib.stream_ptr(dev)),
+                       "halo_expmap0_project_bwd")
+        return gx.to(ctx.in_dtype), None, None
+
+
+def _mlr_forward(x, P, A, c, out_dtype):
+    dev = _lib.require_device(x, P, A)
+    B, Cc, H, W = x.shape
+    O = P.shape[0]
+    out = torch.empty((B, O, H, W), dtype=out_dtype, device=dev)
+    if out.numel():
+        L = _lib.lib()
+        nws = L.halo_hypermlr_workspace_bytes(O, Cc)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        _lib.check(L.halo_hypermlr_logits(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(out), _lib.dtype_code(out),
+                                          B, Cc, O, H * W, float(c), _lib.ptr(ws), nws, _lib.stream_ptr(dev)),
+                   "halo_hypermlr_logits")
+    return out
+
+
+class _HyperMLRFn(torch.autograd.Function):
+    """HyperMLR._hyper_logits (hyperbolic.py:120-184), float64, with gradients for x, P_MLR and A_MLR.
+
+    backward = one HIP kernel for everything that is not a GEMM (the reverse sweep through the Moebius /
+    projection / asinh algebra per pixel and class) + the two dense contractions
+        d x = W^T D + 2 x dxx      and      d W = D x^T        (W = [-P ; A/||A||],  D = [dpx ; dxa])
+    which are plain library GEMMs (torch.einsum -> rocBLAS)."""
+
+    @staticmethod
+    def forward(ctx, x, P, A, c):
+        xd = x.detach().double().contiguous()
+        Pd, Ad = P.detach().contiguous(), A.detach().contiguous()
+        ctx.save_for_backward(xd, Pd, Ad)
+        ctx.c = c
+        return _mlr_forward(xd, Pd, Ad, c, torch.float64)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, P, A = ctx.saved_tensors
+        dev = x.device
+        B, Cc, H, W = x.shape
+        O, hw = P.shape[0], H * W
+        gout = gout.double().contiguous()
+        terms = torch.empty((5, B, O, hw), dtype=torch.float64, device=dev)       # dpx, dxa, dpp, dpa, dan
+        dxx = torch.empty((B, hw), dtype=torch.float64, device=dev)
+        L = _lib.lib()
+        nws = L.halo_hypermlr_workspace_bytes(O, Cc)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        _lib.check(L.halo_hypermlr_bwd_terms(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(gout), B, Cc, O, hw,
+                                             float(ctx.c), _lib.ptr(terms[0]), _lib.ptr(terms[1]), _lib.ptr(dxx),
+                                             _lib.ptr(terms[2]), _lib.ptr(terms[3]), _lib.ptr(terms[4]), _lib.ptr(ws), nws,
+                                             _lib.stream_ptr(dev)), "halo_hypermlr_bwd_terms")
+        dpx, dxa = terms[0], terms[1]
+        dpp, dpa, dan = (terms[k].sum(dim=(0, 2)) for k in (2, 3, 4))            # (O,)
+        a_norm = A.norm(dim=1)                                                    # hyperbolic.py:172
+        dn = a_norm.clamp_min(1e-12)                                              # F.normalize eps, :173
+        An = A / dn[:, None]
+        xf = x.reshape(B, Cc, hw)
+        gx = torch.einsum("oc,bon->bcn", -P, dpx) + torch.einsum("oc,bon->bcn", An, dxa) + 2.0 * xf * dxx[:, None, :]
+        g_negP = torch.einsum("bon,bcn->oc", dpx, xf)                             # d L / d (-P) through px
+        g_An = torch.einsum("bon,bcn->oc", dxa, xf) + dpa[:, None] * (-P)         # through xa and pa = <-P, An>
+        gP = -g_negP + dpp[:, None] * (2.0 * P) - dpa[:, None] * An               # pp = ||P||^2
+        gA = (g_An - (g_An * An).sum(dim=1, keepdim=True) * An) / dn[:, None] + dan[:, None] * A / a_norm[:, None]
+        return gx.reshape(B, Cc, H, W), gP, gA, None
+
+
 class HyperMapper(object):
     """Maps between Euclidean and hyperbolic space and computes distances (hyperbolic.py:16-97)."""
 
@@ -44,19 +150,11 @@ class HyperMapper(object):
         self.K = torch.tensor(-self.c, dtype=float)
 
     def expmap(self, x, dim=-1):
-        """project(expmap0(x.double())) -> float64 (hyperbolic.py:28-39)."""
-        _no_grad_only(x)
-        dev = _lib.require_device(x)
-        x = x.contiguous()
-        if x.dtype not in (torch.float32, torch.float64):
-            x = x.double()
-        y = torch.empty(x.shape, dtype=torch.float64, device=dev)
-        if x.numel() == 0:
-            return y
-        _, outer, C, inner = _split(x.shape, dim)
-        _lib.check(_lib.lib().halo_expmap0_project(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(y), outer, C, inner,
-                                                   float(self.c), _lib.stream_ptr(dev)), "halo_expmap0_project")
-        return y
+        """project(expmap0(x.double())) -> float64 (hyperbolic.py:28-39); differentiable."""
+        if _needs_grad(x):
+            _lib.require_device(x)
+            return _ExpmapFn.apply(x, float(self.c), dim)
+        return _expmap_forward(x, self.c, dim)[1]
 
     def expmap2(self, inputs, dim=-1):
         """Alternative expmap with +1e-15 and eps 1e-3 (hyperbolic.py:41-49; no caller in-tree).
@@ -134,23 +232,12 @@ class HyperMLR(nn.Module):
     def _hyper_logits(self, inputs, out_dtype=torch.float64):
         """inputs (B,C,H,W) float64 -> (B,O,H,W).  out_dtype=float32 fuses the head's `.float()`
         (core/models/classifier.py:373,554)."""
-        _no_grad_only(inputs, self.P_MLR, self.A_MLR)
-        dev = _lib.require_device(inputs, self.P_MLR, self.A_MLR)
-        x = inputs.double().contiguous()
-        B, Cc, H, W = x.shape
-        O = self.num_classes
-        P = self.P_MLR.detach().contiguous()
-        A = self.A_MLR.detach().contiguous()
-        out = torch.empty((B, O, H, W), dtype=out_dtype, device=dev)
-        if out.numel() == 0:
-            return out
-        L = _lib.lib()
-        nws = L.halo_hypermlr_workspace_bytes(O, Cc)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        _lib.check(L.halo_hypermlr_logits(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(out), _lib.dtype_code(out),
-                                          B, Cc, O, H * W, float(self.c), _lib.ptr(ws), nws, _lib.stream_ptr(dev)),
-                   "halo_hypermlr_logits")
-        return out
+        _lib.require_device(inputs, self.P_MLR, self.A_MLR)
+        if _needs_grad(inputs, self.P_MLR, self.A_MLR):          # training: float64 logits with a HIP backward
+            out = _HyperMLRFn.apply(inputs, self.P_MLR, self.A_MLR, float(self.c))
+            return out if out_dtype == torch.float64 else out.to(out_dtype)
+        return _mlr_forward(inputs.double().contiguous(), self.P_MLR.detach().contiguous(),
+                            self.A_MLR.detach().contiguous(), self.c, out_dtype)
 
     def forward(self, x):
         return self._hyper_logits(x)

@@ -356,6 +356,152 @@ __global__ void __launch_bounds__(HTPB) k_bilinear(const T *__restrict__ src, T 
     dst[idx] = a;
 }
 
+
+// ================================================================ backward
+// Gradients of the head tail for training (core/models/classifier.py:553-554 under autograd).  Only the
+// parts that are not plain GEMMs are kernels here: the Jacobian-transpose product of expmap0+project,
+// and the per-(pixel, class) reverse sweep through HyperMLR's scalar algebra.  The two remaining
+// contractions of the HyperMLR backward (d x = W^T D, d W = D x^T) are plain dense GEMMs and go to the
+// BLAS library through torch (halo_amd/core/utils/hyperbolic.py).
+
+// y = project(expmap0(x.double()))  ->  gx = J^T gy,  gx in x's dtype.  Per pixel: gx = alpha*gy + beta*u.
+template <typename TIN>
+__global__ void __launch_bounds__(HTPB) k_expmap0_project_bwd(const TIN *__restrict__ x, const double *__restrict__ gy,
+                                                              TIN *__restrict__ gx, long long outer, int C, long long inner,
+                                                              double ks, double rks, double maxnorm)
+{
+    const long long idx = (long long)blockIdx.x * HTPB + threadIdx.x;
+    if (idx >= outer * inner) return;
+    const long long o = idx / inner, i = idx % inner;
+    const size_t base = (size_t)o * C * inner + i;
+    double ssq = 0.0, d = 0.0;
+    for (int ch = 0; ch < C; ++ch) {
+        const double u = ld_as_f64(x + base + (size_t)ch * inner);
+        ssq = __builtin_fma(u, u, ssq);
+        d = __builtin_fma(u, gy[base + (size_t)ch * inner], d);
+    }
+    const double n_raw = __builtin_sqrt(ssq);
+    const bool clamped = n_raw < 1e-15;                       // norm.clamp_min(1e-15): no gradient through the norm
+    const double n = clamped ? 1e-15 : n_raw;
+    const double a_raw = n * ks;
+    const double th = tanh(a_raw > 15.0 ? 15.0 : a_raw);
+    const double g = rks * th, phi = g / n;
+    const double gprime = a_raw < 15.0 ? (1.0 - th * th) : 0.0;   // d tan_k / d n (0 beyond the tanh clamp)
+    // forward's own projection decision: ||y0|| from the same element-wise values
+    double s2 = 0.0;
+    for (int ch = 0; ch < C; ++ch) { const double v = g * (ld_as_f64(x + base + (size_t)ch * inner) / n); s2 = __builtin_fma(v, v, s2); }
+    double ny = __builtin_sqrt(s2);
+    ny = ny < 1e-15 ? 1e-15 : ny;
+    const double radial = clamped ? 0.0 : (gprime - phi) / (n * n);
+    double alpha, beta;
+    if (ny > maxnorm) {
+        const double sc = maxnorm / ny;
+        const double k0 = sc * phi * phi * d / (ny * ny);     // gy0 = sc*gy - k0*u
+        const double d0 = sc * d - k0 * ssq;                  // u . gy0
+        alpha = phi * sc;
+        beta = -phi * k0 + radial * d0;
+    } else {
+        alpha = phi;
+        beta = radial * d;
+    }
+    for (int ch = 0; ch < C; ++ch) {
+        const size_t a = base + (size_t)ch * inner;
+        gx[a] = (TIN)(alpha * gy[a] + beta * ld_as_f64(x + a));
+    }
+}
+
+// Reverse sweep through _hyper_logits' scalar algebra (hyperbolic.py:146-183) for every (pixel, class):
+// given gout = dL/dlogit it writes dL/dpx, dL/dxa and the per-element contributions to dL/dpp, dL/dpa,
+// dL/d||A|| (B,O,hw each; the caller sums the last three over pixels) and dL/dxx summed over classes (B,hw).
+template <int OB>
+__global__ void __launch_bounds__(HTPB) k_hypermlr_bwd_terms(const double *__restrict__ x, const double *__restrict__ consts,
+                                                             const double *__restrict__ gout, int O, int C, long long hw,
+                                                             double K, double *__restrict__ dpx, double *__restrict__ dxa,
+                                                             double *__restrict__ dxx, double *__restrict__ dpp,
+                                                             double *__restrict__ dpa, double *__restrict__ dan)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * HTPB + threadIdx.x;
+    if (i >= hw) return;
+    const double *xb = x + (size_t)b * C * hw + i;
+    const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    double ssq = 0.0;
+    for (int j = 0; j < C; ++j) { const double v = xb[(size_t)j * hw]; ssq = __builtin_fma(v, v, ssq); }
+    const double nx = __builtin_sqrt(ssq), xx = nx * nx;
+    const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
+    double dxx_acc = 0.0;
+    for (int o0 = 0; o0 < O; o0 += OB) {
+        double px[OB], xa[OB];
+#pragma unroll
+        for (int q = 0; q < OB; ++q) { px[q] = 0.0; xa[q] = 0.0; }
+        for (int j = 0; j < C; ++j) {
+            const double v = xb[(size_t)j * hw];
+#pragma unroll
+            for (int q = 0; q < OB; ++q) {
+                const int o = o0 + q < O ? o0 + q : O - 1;
+                px[q] = __builtin_fma(v, nP[(size_t)o * C + j], px[q]);
+                xa[q] = __builtin_fma(v, An[(size_t)o * C + j], xa[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < OB; ++q) {
+            const int o = o0 + q;
+            if (o < O) {
+            const size_t oi = ((size_t)b * O + o) * hw + i;
+            const double gF = gout[oi];
+            const double ppo = pp[o], pao = pa[o], ano = anorm[o];
+            // ---- forward
+            const double t = 1.0 + (2.0 * K) * px[q];
+            const double Aa = t + K * xx, Bb = 1.0 - K * ppo;
+            const double D0 = t + ((K * xx) * K) * ppo;
+            const bool Dlive = D0 >= 1e-12;
+            const double D = Dlive ? D0 : 1e-12;
+            const double al = Aa / D, be = Bb / D;
+            const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px[q];
+            const double sq = __builtin_sqrt(mob);
+            const bool over = sq > maxnorm, under = sq < maxnorm;
+            const double pn = over ? maxnorm / (sq < 1e-12 ? 1e-12 : sq) : 1.0;
+            const double mp = under ? mob : maxnorm * maxnorm;
+            const double inner = be * xa[q] + al * pao;
+            const double md = inner * pn;
+            const double den = 1.0 - K * mp;
+            const bool denlive = den >= 1e-12;
+            const double denc = denlive ? den : 1e-12;
+            const double lam = 2.0 / denc;
+            const double s = (sqK * md) * lam;
+            // ---- reverse
+            const double two_sqK = 2.0 / sqK;
+            const double d_an = gF * two_sqK * asinh(s);
+            const double d_s = gF * two_sqK * ano / __builtin_sqrt(1.0 + s * s);
+            const double d_md = d_s * sqK * lam;
+            const double d_lam = d_s * sqK * md;
+            const double d_den = denlive ? -d_lam * 2.0 / (denc * denc) : 0.0;
+            double d_mob = under ? -K * d_den : 0.0;
+            const double d_inner = d_md * pn, d_pn = d_md * inner;
+            double d_be = d_inner * xa[q], d_al = d_inner * pao;
+            const double d_xa = d_inner * be, d_pa = d_inner * al;
+            const double d_sq = over ? -d_pn * maxnorm / (sq * sq) : 0.0;
+            if (sq > 0.0) d_mob += d_sq / (2.0 * sq);
+            d_al += d_mob * (2.0 * al * ppo + 2.0 * be * px[q]);
+            d_be += d_mob * (2.0 * be * xx + 2.0 * al * px[q]);
+            double d_pp = d_mob * al * al, d_xx = d_mob * be * be, d_px = d_mob * 2.0 * al * be;
+            const double d_Aa = d_al / D, d_Bb = d_be / D;
+            const double d_D0 = Dlive ? -(d_al * Aa + d_be * Bb) / (D * D) : 0.0;
+            double d_t = d_D0;
+            d_xx += d_D0 * K * K * ppo;
+            d_pp += d_D0 * K * K * xx;
+            d_pp += -K * d_Bb;
+            d_t += d_Aa;
+            d_xx += K * d_Aa;
+            d_px += 2.0 * K * d_t;
+            dpx[oi] = d_px; dxa[oi] = d_xa; dpp[oi] = d_pp; dpa[oi] = d_pa; dan[oi] = d_an;
+            dxx_acc += d_xx;
+            }
+        }
+    }
+    dxx[(size_t)b * hw + i] = dxx_acc;
+}
+
 }  // namespace halo
 
 using namespace halo;
@@ -459,4 +605,35 @@ extern "C" int halo_bilinear_upsample(const void *src, void *dst, int dtype, int
         hipLaunchKernelGGL((k_bilinear<float>), dim3(nblocks(n)), dim3(HTPB), 0, st, (const float *)src, (float *)dst, (long long)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
     } else return fail(HALO_E_ARG, "halo_bilinear_upsample: bad dtype");
     return check_launch("halo_bilinear_upsample");
+}
+
+extern "C" int halo_expmap0_project_bwd(const void *x, int x_dtype, const double *gy, void *gx, int64_t outer, int64_t C,
+                                        int64_t inner, double c, void *stream)
+{
+    if (!x || !gy || !gx || outer <= 0 || C <= 0 || inner <= 0) return fail(HALO_E_ARG, "halo_expmap0_project_bwd: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_expmap0_project_bwd: curvature must be > 0");
+    const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks, maxnorm = (1.0 - 1e-5) / sqrt(fabs(-c) + 1e-15);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == HALO_F32)
+        hipLaunchKernelGGL((k_expmap0_project_bwd<float>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const float *)x, gy, (float *)gx, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
+    else if (x_dtype == HALO_F64)
+        hipLaunchKernelGGL((k_expmap0_project_bwd<double>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const double *)x, gy, (double *)gx, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
+    else return fail(HALO_E_ARG, "halo_expmap0_project_bwd: bad dtype");
+    return check_launch("halo_expmap0_project_bwd");
+}
+
+extern "C" int halo_hypermlr_bwd_terms(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
+                                       int64_t O, int64_t hw, double c, double *dpx, double *dxa, double *dxx, double *dpp,
+                                       double *dpa, double *dan, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !P || !A || !gout || !dpx || !dxa || !dxx || !dpp || !dpa || !dan || B <= 0 || C <= 0 || O <= 0 || hw <= 0)
+        return fail(HALO_E_ARG, "halo_hypermlr_bwd_terms: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_hypermlr_bwd_terms: curvature must be > 0");
+    if (!workspace || workspace_bytes < halo_hypermlr_workspace_bytes(O, C)) return fail(HALO_E_WORKSPACE, "halo_hypermlr_bwd_terms: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double *consts = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)cdiv(O, 64)), dim3(64), 0, st, P, A, (int)O, (int)C, consts);
+    dim3 grid(nblocks(hw), (unsigned)B);
+    hipLaunchKernelGGL((k_hypermlr_bwd_terms<10>), grid, dim3(HTPB), 0, st, x, (const double *)consts, gout, (int)O, (int)C, (long long)hw, c, dpx, dxa, dxx, dpp, dpa, dan);
+    return check_launch("halo_hypermlr_bwd_terms");
 }

@@ -73,6 +73,19 @@ int halo_hypermlr_logits(const double *x, const double *P, const double *A, void
                          int64_t B, int64_t C, int64_t O, int64_t hw, double c, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* Backward of the head tail for training (classifier.py:553-554 under autograd).
+ *  - halo_expmap0_project_bwd: gx = J^T gy for y = HyperMapper.expmap(x, dim); gy f64, gx in x's dtype.
+ *  - halo_hypermlr_bwd_terms: reverse sweep through _hyper_logits' scalar algebra (hyperbolic.py:146-183):
+ *    from gout = dL/dlogit (B,O,hw) f64 it writes dL/dpx, dL/dxa, and the per-element contributions to
+ *    dL/dpp, dL/dpa, dL/d||A|| (B,O,hw each) plus dL/dxx summed over classes (B,hw).  The two remaining
+ *    contractions (d x = W^T D + 2 x dxx, d W = D x^T) are plain GEMMs done by the caller's BLAS.
+ *    workspace: halo_hypermlr_workspace_bytes(O, C). */
+int halo_expmap0_project_bwd(const void *x, int x_dtype, const double *gy, void *gx, int64_t outer, int64_t C,
+                             int64_t inner, double c, void *stream);
+int halo_hypermlr_bwd_terms(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
+                            int64_t O, int64_t hw, double c, double *dpx, double *dxa, double *dxx, double *dpp,
+                            double *dpa, double *dan, void *workspace, size_t workspace_bytes, void *stream);
+
 /* F.interpolate(mode="bilinear", align_corners=True) (core/active/build.py:123-125,133-135;
  * classifier.py:375-377,556-557): planes x (h,w) -> planes x (H,W), dtype F32|F64. */
 int halo_bilinear_upsample(const void *src, void *dst, int dtype, int64_t planes, int64_t h, int64_t w,

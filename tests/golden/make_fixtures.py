@@ -245,6 +245,39 @@ def gen_helpers(cfg, hyp, fr):
     np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
 
 
+def gen_grads(hyp):
+    """Autograd of the reference head tail (classifier.py:553-554): d loss / d {feat, P_MLR, A_MLR} for
+    loss = <out, Wt> + <embed, Ve>, with far-out (projected / tanh-clamped) and exact-origin pixels."""
+    out = {}
+    for tag, (C, O, h, w, c) in {"c8_o19": (8, 19, 9, 13, 1.0), "c16_o16_k07": (16, 16, 6, 10, 0.7)}.items():
+        g = torch.Generator().manual_seed(5 + C)
+        z = torch.randn(2, C, h, w, generator=g, dtype=torch.float32) * 0.3
+        z[0, :, 0, 0] *= 300.0            # tanh clamp + project
+        z[1, :, 2, 3] *= 20.0             # project only
+        z[0, :, 1, 1] = 0.0               # exact origin
+        z.requires_grad_(True)
+        mapper = hyp.HyperMapper(c=c)
+        mlr = hyp.HyperMLR(C, O, c=c)
+        with torch.no_grad():
+            torch.manual_seed(3)
+            torch.nn.init.kaiming_uniform_(mlr.P_MLR, a=math.sqrt(5))
+            torch.nn.init.kaiming_uniform_(mlr.A_MLR, a=math.sqrt(5))
+        embed = mapper.expmap(z, dim=1)
+        embed.retain_grad()
+        logits = mlr(embed.double()).float()
+        Wt = torch.randn(logits.shape, generator=g, dtype=torch.float32)
+        Ve = torch.randn(embed.shape, generator=g, dtype=torch.float64) * 0.1
+        loss = (logits * Wt).sum() + (embed * Ve).sum()
+        loss.backward()
+        out.update({f"{tag}__z": z.detach().numpy(), f"{tag}__P": mlr.P_MLR.detach().numpy(), f"{tag}__A": mlr.A_MLR.detach().numpy(),
+                    f"{tag}__Wt": Wt.numpy(), f"{tag}__Ve": Ve.numpy(), f"{tag}__c": np.array([c]),
+                    f"{tag}__embed": embed.detach().numpy(), f"{tag}__logits": logits.detach().numpy(),
+                    f"{tag}__g_z": z.grad.numpy(), f"{tag}__g_embed": embed.grad.numpy(),
+                    f"{tag}__g_P": mlr.P_MLR.grad.numpy(), f"{tag}__g_A": mlr.A_MLR.grad.numpy()})
+        print(f"  grads {tag}: |g_z| max {float(z.grad.abs().max()):.3e}, nan {bool(torch.isnan(z.grad).any())}")
+    np.savez_compressed(os.path.join(HERE, "grads.npz"), **out)
+
+
 class _FakeExtractor(torch.nn.Module):
     def forward(self, x):
         return x
@@ -333,6 +366,9 @@ def main():
     if only == "helpers":            # add-on vectors without regenerating the rest
         gen_helpers(cfg, hyp, fr)
         return
+    if only == "grads":
+        gen_grads(hyp)
+        return
     print("case A 32x64 C8 O19 (selection runs to exhaustion)")
     gen_case(cfg, hyp, fr, ab, "case_a_32x64_c8_o19", 32, 64, 8, 19, 11, 200, COMBOS)
     print("case B 64x128 C16 O19")
@@ -347,6 +383,8 @@ def main():
     gen_hypermapper(hyp)
     print("helper methods")
     gen_helpers(cfg, hyp, fr)
+    print("head-tail gradients")
+    gen_grads(hyp)
     print("RegionSelection driver, 2 rounds")
     gen_region_selection(cfg, hyp, fr, ab)
 

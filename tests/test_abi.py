@@ -67,6 +67,8 @@ def test_no_cpu_fallback():
         with torch.no_grad():
             HyperMLR(4, 3)(torch.zeros(1, 4, 2, 2, dtype=torch.float64))
     with pytest.raises(HaloHipError):
+        HyperMLR(4, 3)(torch.zeros(1, 4, 2, 2, dtype=torch.float64))          # training path: no CPU either
+    with pytest.raises(HaloHipError):
         z = torch.zeros(8, 8)
         select_pixels_to_label(z, 1, 1, 5, z.bool(), z.bool(), z.long(), z.long())
 

@@ -443,16 +443,21 @@ def test_head_tails(golden, dev):
     mlr = HyperMLR(C, O, c=1.0).to(dev)
     with torch.no_grad():
         mlr.P_MLR.copy_(t(d["P_MLR"], dev)); mlr.A_MLR.copy_(t(d["A_MLR"], dev))
-    out, emb = hyper_head_tail(t(d["z"], dev), HyperMapper(1.0), mlr, size=(H, W), resize_embed=True)
+    with torch.no_grad():
+        out, emb = hyper_head_tail(t(d["z"], dev), HyperMapper(1.0), mlr, size=(H, W), resize_embed=True)
+        out3, emb3 = hyper_head_tail(t(d["z"], dev), HyperMapper(1.0), mlr, size=(H, W))
     assert out.dtype == torch.float32 and emb.dtype == torch.float64
     assert max_abs_diff(out.cpu().numpy(), d["logit"]) < 1e-5
     assert max_abs_diff(emb.cpu().numpy(), d["embed"]) < 1e-14
-    out3, emb3 = hyper_head_tail(t(d["z"], dev), HyperMapper(1.0), mlr, size=(H, W))
     assert emb3.shape[-2:] == (H // 4, W // 4) and max_abs_diff(emb3.cpu().numpy(), d["embed_lr"]) < 1e-14
     assert np.array_equal(out3.cpu().numpy(), out.cpu().numpy())
-    mlr.P_MLR.requires_grad_(True)
+    # training mode (grad enabled, parameters require grad): same values, differentiable
+    out_t, emb_t = hyper_head_tail(t(d["z"], dev), HyperMapper(1.0), mlr, size=(H, W))
+    assert out_t.requires_grad and np.abs(out_t.detach().cpu().numpy() - d["logit"]).max() < 1e-5
+    out_t.sum().backward()
+    assert mlr.P_MLR.grad is not None and torch.isfinite(mlr.P_MLR.grad).all()
     with pytest.raises(NotImplementedError):
-        mlr(t(d["embed_lr"], dev))                                   # autograd is not provided (N3)
+        HyperMapper(1.0).logmap(t(d["embed_lr"], dev).requires_grad_(True))   # inference-only op: refuses to detach silently
 
 
 def test_select_randomized_shapes_and_radii(dev):
@@ -707,3 +712,36 @@ def test_region_selection_pipelined_pool_vs_oracle(dev):
         ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
         assert np.array_equal(png, mask), i
         assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
+
+
+def test_head_tail_gradients_match_reference_autograd(golden, dev):
+    """d loss / d {feat, P_MLR, A_MLR, embed} of the head tail (classifier.py:553-554) from the HIP backward
+    kernels + library GEMMs vs the reference's own autograd (tests/golden/grads.npz), including
+    tanh-clamped / projected pixels and an exact-origin pixel."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
+    d = golden("grads")
+    for tag in ("c8_o19", "c16_o16_k07"):
+        c = float(d[tag + "__c"][0])
+        z = t(d[tag + "__z"], dev).requires_grad_(True)
+        O, C = d[tag + "__P"].shape
+        mlr = HyperMLR(C, O, c=c).to(dev)
+        with torch.no_grad():
+            mlr.P_MLR.copy_(t(d[tag + "__P"], dev)); mlr.A_MLR.copy_(t(d[tag + "__A"], dev))
+        embed = HyperMapper(c=c).expmap(z, dim=1)
+        embed.retain_grad()
+        logits = mlr(embed.double()).float()
+        assert max_abs_diff(embed.detach().cpu().numpy(), d[tag + "__embed"]) < 1e-14
+        assert np.abs(logits.detach().cpu().numpy() - d[tag + "__logits"]).max() < 1e-5
+        loss = (logits * t(d[tag + "__Wt"], dev)).sum() + (embed * t(d[tag + "__Ve"], dev)).sum()
+        loss.backward()
+
+        def rel(a, b):
+            return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+        assert z.grad.dtype == torch.float32 and mlr.P_MLR.grad.dtype == torch.float64
+        assert rel(embed.grad.cpu().numpy(), d[tag + "__g_embed"]) < 1e-10, tag
+        assert rel(mlr.P_MLR.grad.cpu().numpy(), d[tag + "__g_P"]) < 1e-10, tag
+        assert rel(mlr.A_MLR.grad.cpu().numpy(), d[tag + "__g_A"]) < 1e-10, tag
+        assert rel(z.grad.cpu().numpy(), d[tag + "__g_z"]) < 2e-6, tag                     # float32 gradient
+        # per-pixel check incl. the clamped / projected / origin pixels
+        gz, want = z.grad.cpu().numpy(), d[tag + "__g_z"]
+        assert np.abs(gz - want).max() <= 2e-6 * np.abs(want).max() + 1e-7
