@@ -25,10 +25,11 @@ constexpr unsigned long long KEY_NEG_INF = 0x000fffffffffffffull;   // ~bits(-in
 
 __device__ __forceinline__ unsigned long long order_key(double v)
 {
-    if (v != v) return KEY_NAN;
-    if (v == 0.0) v = 0.0;                                  // -0 ties with +0 in torch.max
+    const bool isnan = v != v;
+    v = v == 0.0 ? 0.0 : v;                                 // -0 ties with +0 in torch.max
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    const unsigned long long k = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    return isnan ? KEY_NAN : k;
 }
 __device__ __forceinline__ double key_value(unsigned long long k)
 {
@@ -37,7 +38,7 @@ __device__ __forceinline__ double key_value(unsigned long long k)
     return __longlong_as_double((long long)u);
 }
 
-struct Cand { unsigned long long key; unsigned pos; };     // pos = w*H + h  (smaller wins a tie)
+struct Cand { unsigned long long key; unsigned pos; };     // pos = (w << 16) | h  (smaller wins a tie: min w, then min h)
 
 __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
 {
@@ -87,22 +88,22 @@ struct SelGeom { int H, W, th_shift, tw_shift, nty, ntx, nt; };
 // The tile shape is a compile-time constant so that all of a lane's loads are issued
 // back to back (one memory round trip per tile instead of one per pixel row).
 template <typename T, int TSH, int TSW>
-__device__ __forceinline__ Cand tile_reduce(const T *__restrict__ sc, const SelGeom &g, int tile, int lane,
+__device__ __forceinline__ Cand tile_reduce(const T *__restrict__ sc, const SelGeom &g, int ty, int tx, int lane,
                                             int wy0, int wy1, int wx0, int wx1, int py0 = 1, int py1 = 0, int px0 = 1,
                                             int px1 = 0)
 {
     constexpr int TW = 1 << TSW, NPL = (1 << (TSH + TSW)) / 64;
     static_assert(NPL >= 1, "tile smaller than a wave");
-    const int ty = tile / g.ntx, tx = tile % g.ntx;
-    const int y0 = ty << TSH, x0 = tx << TSW;
+    // element e = lane + 64*i of the tile sits at (row e >> TSW, column e & (TW-1)); for TW <= 64 a lane
+    // keeps ONE column and walks rows, so the column tests are hoisted out of the loop by the compiler
+    const int x0 = tx << TSW, y0 = ty << TSH;
     double v[NPL];
-    bool inb[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int e = lane + 64 * i;
         const int y = y0 + (e >> TSW), x = x0 + (e & (TW - 1));
-        inb[i] = y < g.H && x < g.W;
-        v[i] = inb[i] ? (double)sc[(size_t)y * g.W + x] : 0.0;
+        const int yc = y < g.H ? y : g.H - 1, xc = x < g.W ? x : g.W - 1;   // clamped: the load is unconditional
+        v[i] = (double)sc[(size_t)yc * g.W + xc];                         // (no exec-mask juggling per element)
     }
     Cand best;
     best.key = 0ull;            // below every real key (real keys are >= KEY_NEG_INF > 0)
@@ -111,16 +112,19 @@ __device__ __forceinline__ Cand tile_reduce(const T *__restrict__ sc, const SelG
     for (int i = 0; i < NPL; ++i) {
         const int e = lane + 64 * i;
         const int y = y0 + (e >> TSW), x = x0 + (e & (TW - 1));
+        const bool masked = (x >= wx0 && x <= wx1 && y >= wy0 && y <= wy1) || (x >= px0 && x <= px1 && y >= py0 && y <= py1);
+        const bool inb = x < g.W && y < g.H;
         Cand c;
-        const bool masked = (y >= wy0 && y <= wy1 && x >= wx0 && x <= wx1) || (y >= py0 && y <= py1 && x >= px0 && x <= px1);
-        c.key = masked ? KEY_NEG_INF : order_key(v[i]);
-        c.pos = (unsigned)x * (unsigned)g.H + (unsigned)y;
-        if (inb[i] && better(c, best)) best = c;
+        c.key = inb ? (masked ? KEY_NEG_INF : order_key(v[i])) : 0ull;    // out-of-image: below every real key
+        c.pos = ((unsigned)x << 16) | (unsigned)y;
+        const bool take = better(c, best);
+        best.key = take ? c.key : best.key;
+        best.pos = take ? c.pos : best.pos;
     }
     return wave_best(best);
 }
 
-template <typename T, int TSH, int TSW>
+template <typename T, int TSH, int TSW, int EPT>
 __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score, SelGeom g, int n_regions, int arad,
                                                            int mrad, unsigned char *__restrict__ active,
                                                            unsigned char *__restrict__ selected,
@@ -147,22 +151,33 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
     const long long *gtb = gt + (size_t)b * hw;
 
     // ---- build the tile table
-    for (int t = wave; t < g.nt; t += SEL_WAVES) {
-        const Cand c = tile_reduce<T, TSH, TSW>(sc, g, t, lane, 1, 0, 1, 0);
-        if (lane == 0) { tkey[t] = c.key; tpos[t] = c.pos; }
-    }
+    for (int ty = 0; ty < g.nty; ++ty)
+        for (int tx = wave; tx < g.ntx; tx += SEL_WAVES) {
+            const Cand c = tile_reduce<T, TSH, TSW>(sc, g, ty, tx, lane, 1, 0, 1, 0);
+            if (lane == 0) { tkey[ty * g.ntx + tx] = c.key; tpos[ty * g.ntx + tx] = c.pos; }
+        }
     __syncthreads();
 
     // thread-local best over the tiles this thread owns (t = tid, tid+SEL_TPB, ...)
     Cand mine;
-    auto rescan = [&]() {
-        mine.key = 0ull;
-        mine.pos = 0xffffffffu;
-        for (int t = tid; t < g.nt; t += SEL_TPB) {
-            Cand c;
-            c.key = tkey[t];
-            c.pos = tpos[t];
-            if (better(c, mine)) mine = c;
+    auto rescan = [&]() {      // EPT entries per thread; clamped unconditional LDS reads issued back to back
+        Cand e[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int t = tid + j * SEL_TPB;
+            const bool ok = t < g.nt;
+            const int tc = ok ? t : g.nt - 1;
+            const unsigned long long k = tkey[tc];
+            const unsigned q = tpos[tc];
+            e[j].key = ok ? k : 0ull;
+            e[j].pos = ok ? q : 0xffffffffu;
+        }
+        mine = e[0];
+#pragma unroll
+        for (int j = 1; j < EPT; ++j) {
+            const bool take = better(e[j], mine);
+            mine.key = take ? e[j].key : mine.key;
+            mine.pos = take ? e[j].pos : mine.pos;
         }
     };
     rescan();
@@ -192,13 +207,12 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
             if (better(c, top)) top = c;
         }
         if (top.key == KEY_NEG_INF || top.key == 0ull) break;            // build.py:40-41
-        const int w = (int)(top.pos / (unsigned)g.H), h = (int)(top.pos % (unsigned)g.H);
+        const int w = (int)(top.pos >> 16), h = (int)(top.pos & 0xffffu);
 
         // windows (build.py:45-53): low side clipped at 0, high side by the slice
         const int my0 = h - mrad < 0 ? 0 : h - mrad, my1 = h + mrad >= g.H ? g.H - 1 : h + mrad;
         const int mx0 = w - mrad < 0 ? 0 : w - mrad, mx1 = w + mrad >= g.W ? g.W - 1 : w + mrad;
         const int ty0 = my0 >> TSH, ty1 = my1 >> TSH, tx0 = mx0 >> TSW, tx1 = mx1 >> TSW;
-        const int ntx_w = tx1 - tx0 + 1, ntouch = ntx_w * (ty1 - ty0 + 1);
 
         // ---- [B]
         if (wave == SEL_WAVES - 1) {
@@ -230,20 +244,20 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
                 pk[2] = key_value(top.key);
             }
         } else {
-            for (int q = wave; q < ntouch; q += SEL_WAVES - 1) {
-                const int t = (ty0 + q / ntx_w) * g.ntx + (tx0 + q % ntx_w);
-                const Cand c = tile_reduce<T, TSH, TSW>(sc, g, t, lane, my0, my1, mx0, mx1, py0, py1, px0, px1);
-                if (lane == 0) { tkey[t] = c.key; tpos[t] = c.pos; }
-            }
+            int q = 0;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx, ++q) {
+                    if (q % (SEL_WAVES - 1) != wave) continue;
+                    const Cand c = tile_reduce<T, TSH, TSW>(sc, g, ty, tx, lane, my0, my1, mx0, mx1, py0, py1, px0, px1);
+                    if (lane == 0) { tkey[ty * g.ntx + tx] = c.key; tpos[ty * g.ntx + tx] = c.pos; }
+                }
         }
         ++np;
         lds_barrier();
         // ---- [C] owners of touched tiles refresh their cached best
         bool own = false;
-        for (int q = 0; q < ntouch; ++q) {
-            const int t = (ty0 + q / ntx_w) * g.ntx + (tx0 + q % ntx_w);
-            own |= (t % SEL_TPB) == tid;
-        }
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) own |= ((ty * g.ntx + tx) & (SEL_TPB - 1)) == tid;
         if (own) rescan();
         py0 = my0; py1 = my1; px0 = mx0; px1 = mx1;
     }
@@ -289,23 +303,31 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
         return fail(HALO_E_ARG, "halo_greedy_select: null/empty argument");
     if (dtype != HALO_F32 && dtype != HALO_F64) return fail(HALO_E_ARG, "halo_greedy_select: bad dtype");
     if (n_regions < 0 || active_radius < 0 || mask_radius < 0) return fail(HALO_E_ARG, "halo_greedy_select: negative parameter");
-    if ((uint64_t)H * (uint64_t)W >= 0xffffffffull) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image too large");
+    if (H > 65535 || W > 65535) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image side above 65535");
     if (n_regions > 0x7fffffff) n_regions = 0x7fffffff;
     const SelGeom g = make_geom(H, W);
     if ((size_t)g.nt * 12 > 96 * 1024) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image too large for the tile table");
     const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * SEL_WAVES * 12 + 64;
     dim3 grid((unsigned)B), block(SEL_TPB);
-#define HALO_SEL_LAUNCH(T, A, B_)                                                                                          \
-    hipLaunchKernelGGL((k_greedy_select<T, A, B_>), grid, block, lds, st, (T *)score, g, (int)n_regions, (int)active_radius, \
-                       (int)mask_radius, active, selected, (long long *)active_mask, (const long long *)gt, picks, n_picked)
+#define HALO_SEL_LAUNCH(T, A, B_)                                                                                               \
+    {                                                                                                                           \
+        if (g.nt <= 8 * SEL_TPB)                                                                                                \
+            hipLaunchKernelGGL((k_greedy_select<T, A, B_, 8>), grid, block, lds, st, (T *)score, g, (int)n_regions,             \
+                               (int)active_radius, (int)mask_radius, active, selected, (long long *)active_mask,               \
+                               (const long long *)gt, picks, n_picked);                                                        \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_greedy_select<T, A, B_, 16>), grid, block, lds, st, (T *)score, g, (int)n_regions,            \
+                               (int)active_radius, (int)mask_radius, active, selected, (long long *)active_mask,               \
+                               (const long long *)gt, picks, n_picked);                                                        \
+    }
     if (dtype == HALO_F64) {
-        if (g.th_shift == 4) HALO_SEL_LAUNCH(double, 4, 5);
-        else if (g.th_shift == 5) HALO_SEL_LAUNCH(double, 5, 6);
-        else HALO_SEL_LAUNCH(double, 6, 7);
+        if (g.th_shift == 4) HALO_SEL_LAUNCH(double, 4, 5)
+        else if (g.th_shift == 5) HALO_SEL_LAUNCH(double, 5, 6)
+        else HALO_SEL_LAUNCH(double, 6, 7)
     } else {
-        if (g.th_shift == 4) HALO_SEL_LAUNCH(float, 4, 5);
-        else if (g.th_shift == 5) HALO_SEL_LAUNCH(float, 5, 6);
-        else HALO_SEL_LAUNCH(float, 6, 7);
+        if (g.th_shift == 4) HALO_SEL_LAUNCH(float, 4, 5)
+        else if (g.th_shift == 5) HALO_SEL_LAUNCH(float, 5, 6)
+        else HALO_SEL_LAUNCH(float, 6, 7)
     }
 #undef HALO_SEL_LAUNCH
     return check_launch("halo_greedy_select");
