@@ -34,7 +34,7 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     if return_picks:
         picks = torch.zeros((B, max(n, 1), 3), dtype=torch.float64, device=dev)
         n_picked = torch.zeros((B,), dtype=torch.int32, device=dev)
-    if n == 0:
+    if n == 0 or B == 0:
         return (picks[:, :0], n_picked) if return_picks else None
     L = _lib.lib()
     nws = L.halo_select_workspace_bytes(B, H, W)

@@ -80,6 +80,9 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
         act = active.reshape(B, H, W).contiguous()
         act = act.view(torch.uint8) if act.dtype == torch.bool else act.to(torch.uint8)
     odt = score_dtype(pur_type, feat)
+    if B == 0 or H == 0 or W == 0:                      # empty batch / empty image: nothing to launch
+        e = torch.empty((B, H, W), dtype=odt, device=dev)
+        return (e, e.clone(), torch.empty((B, H, W), dtype=torch.float32, device=dev)) if want_maps else (e, None, None)
     if out is not None:
         assert out.shape == (B, H, W) and out.dtype == odt and out.is_contiguous() and out.device == dev
         score = out

@@ -745,3 +745,49 @@ def test_head_tail_gradients_match_reference_autograd(golden, dev):
         # per-pixel check incl. the clamped / projected / origin pixels
         gz, want = z.grad.cpu().numpy(), d[tag + "__g_z"]
         assert np.abs(gz - want).max() <= 2e-6 * np.abs(want).max() + 1e-7
+
+
+def test_empty_and_degenerate_inputs(dev):
+    """Empty batch, zero regions, 1x1 / 1xN / Nx1 images."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    s, i, u = score_maps(torch.zeros((0, 19, 8, 8), device=dev), torch.zeros((0, 4, 8, 8), dtype=torch.float64, device=dev),
+                         "entropy", "radius", True, None)
+    assert s.shape == (0, 8, 8) and s.dtype == torch.float64 and u.shape == (0, 8, 8)
+    z = torch.zeros((1, 8, 8), device=dev)
+    picks, npk = greedy_select(z.double(), 0, 1, 5, z.bool(), z.bool(), z.long(), z.long())
+    assert picks.shape[1] == 0 and int(npk[0]) == 0
+    rng = np.random.default_rng(12)
+    for (H, W) in ((1, 1), (1, 9), (7, 1), (2, 3)):
+        logit = rng.standard_normal((1, 19, H, W)).astype(np.float32)
+        emb = rng.standard_normal((1, 5, H, W)) * 0.2
+        gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+        for unc, pur in (("entropy", "radius"), ("entropy", "ripu"), ("oracle_acc", "hyper")):
+            so, io, uo = ho.floating_region_score(logit, emb, unc, pur, True, gt, size=3, purity_type=pur, K=7)
+            s, i, u = score_maps(t(logit, dev), t(emb, dev), unc, pur, True, t(gt, dev)[None], size=3, K=7)
+            assert bits_equal(s[0].cpu().numpy(), so) and bits_equal(i[0].cpu().numpy(), io) and bits_equal(u[0].cpu().numpy(), uo), (H, W, unc, pur)
+
+
+def test_bench_contract_on_a_small_shape(dev):
+    """bench.py prints ONE JSON line carrying the contract's keys (run on a tiny shape so it takes seconds)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--height", "64", "--width", "128", "--channels", "16",
+                        "--steps", "3", "--warmup", "1", "--batch", "4", "--ring", "4", "--cpu-images", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "images/s" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "images/s" and d["parity_vs_cpu"] is True
