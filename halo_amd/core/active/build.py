@@ -106,13 +106,6 @@ def acquire_batch_lowres(logit_lr, decoder_lr, size, ground_truth, active, selec
     return greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth)
 
 
-def needs_decoder_out(cfg_, uncertainty_type, purity_type):
-    """build.py:127-131."""
-    return (uncertainty_type in ["certainty", "hyperbolic"]
-            or (purity_type in ["hyper", "radius", "euc_norm"])
-            or (uncertainty_type == "none" and cfg_.MODEL.HYPER))
-
-
 class AcquisitionParams:
     """What RegionSelection reads from cfg (build.py:75-88), resolved once."""
 

@@ -178,10 +178,6 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_generic(const float *__restr
 }
 
 // ---------------------------------------------------------------- features -> radius / norm (HBM roofline)
-template <typename T> struct AccOf;
-template <> struct AccOf<double> { using type = double; };
-template <> struct AccOf<float> { using type = float; };
-
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 

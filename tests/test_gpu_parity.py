@@ -791,3 +791,20 @@ def test_bench_contract_on_a_small_shape(dev):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "images/s" and d["parity_vs_cpu"] is True
+
+
+def test_fused_and_unfused_entropy_paths_agree_bitwise(dev):
+    """k_feat_reduce with the fused per-pixel entropy vs the stand-alone k_logit_maps kernel (HALO_NO_FUSE=1)."""
+    from halo_amd.core.active.floating_region import score_maps
+    for dt in (np.float64, np.float32):
+        logit, emb, gt = _synthetic(128, 256, 24, 19, 5, dt)
+        args = (t(logit, dev), t(emb, dev), "entropy", "radius", True, None)
+        os.environ.pop("HALO_NO_FUSE", None)
+        a = score_maps(*args, size=3)
+        os.environ["HALO_NO_FUSE"] = "1"
+        try:
+            b = score_maps(*args, size=3)
+        finally:
+            os.environ.pop("HALO_NO_FUSE", None)
+        for x, y in zip(a, b):
+            assert bits_equal(x.cpu().numpy(), y.cpu().numpy())
