@@ -808,3 +808,36 @@ def test_fused_and_unfused_entropy_paths_agree_bitwise(dev):
             os.environ.pop("HALO_NO_FUSE", None)
         for x, y in zip(a, b):
             assert bits_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
+def test_region_selection_full_size_real_geometry_vs_oracle(dev):
+    """The real pipeline's geometry at full label size: logits 640x1280 and a C=64 float64 embedding at
+    160x320 resized to 1024x2048 inside the scorer (never materialised on the device), 2331 regions --
+    masks and indicators written by RegionSelection equal the oracle driver's (explicit upsample) output."""
+    from PIL import Image
+    from halo_amd.core.active.build import RegionSelection
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(2026)
+    H, W, C, O = 1024, 2048, 64, 19
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=O, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 15000, 30000, 40000, 50000], K=100, VIZ_MASK=False))
+    tmp = tempfile.mkdtemp(prefix="halo_rs3_")
+    emb_lr = ho.expmap((rng.standard_normal((1, C, 160, 320)) * 0.1).astype(np.float32), 1.0, dim=1)
+    bound = 1.0 / math.sqrt(C)
+    logit160 = ho.hypermlr(emb_lr, rng.uniform(-bound, bound, (O, C)), rng.uniform(-bound, bound, (O, C)), 1.0).astype(np.float32)
+    logit_lr = ho.bilinear(logit160, (640, 1280))                      # the v3+ head resizes logits to the input size
+    gt = rng.integers(0, O, (H, W)).astype(np.int64)
+    act = np.zeros((H, W), bool); act[100:140, 300:380] = True
+    item = {"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [os.path.join(tmp, "m.png")],
+            "origin_mask": torch.full((1, H, W), 255, dtype=torch.int64), "origin_label": torch.from_numpy(gt)[None],
+            "size": torch.tensor([[H, W]]), "active": torch.from_numpy(act)[None], "selected": torch.zeros(1, H, W, dtype=torch.bool),
+            "path_to_indicator": [os.path.join(tmp, "i.pth")], "name": ["img"]}
+    RegionSelection(cfg, _Fake(), _Fake([(t(logit_lr, dev), t(emb_lr, dev))]), [item], 1)
+    (mask, a_o, s_o, picks), = ho.region_selection(cfg, [dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act,
+                                                            selected=np.zeros((H, W), bool), origin_mask=np.full((H, W), 255, np.int64))])
+    assert len(picks) == 2331
+    ind = torch.load(os.path.join(tmp, "i.pth"))
+    assert np.array_equal(np.array(Image.open(os.path.join(tmp, "m.png")), dtype=np.uint8), mask)
+    assert np.array_equal(ind["active"].numpy(), a_o) and np.array_equal(ind["selected"].numpy(), s_o)
