@@ -841,3 +841,26 @@ def test_region_selection_full_size_real_geometry_vs_oracle(dev):
     ind = torch.load(os.path.join(tmp, "i.pth"))
     assert np.array_equal(np.array(Image.open(os.path.join(tmp, "m.png")), dtype=np.uint8), mask)
     assert np.array_equal(ind["active"].numpy(), a_o) and np.array_equal(ind["selected"].numpy(), s_o)
+
+
+def test_autograd_gradcheck_float64(dev):
+    """Finite-difference check (torch.autograd.gradcheck, float64) of the HIP backward kernels: expmap over the
+    last dim and over dim=1 (inside the ball, tanh-clamped + projected, and mixed), HyperMLR w.r.t. x, P, A."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, _HyperMLRFn
+    g = torch.Generator(device=dev).manual_seed(4)
+    m = HyperMapper(c=0.8)
+    x = (torch.randn((5, 7), generator=g, device=dev, dtype=torch.float64) * 0.4).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t_: m.expmap(t_), (x,), eps=1e-6, atol=1e-7, rtol=1e-5)
+    xb = (torch.randn((2, 6, 3, 4), generator=g, device=dev, dtype=torch.float64) * 0.3)
+    xb[0, :, 0, 0] *= 30.0                                   # projected pixel (not tanh-clamped: ||u|| sqrt(c) < 15)
+    xb.requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t_: m.expmap(t_, dim=1), (xb,), eps=1e-6, atol=1e-6, rtol=1e-4)
+    xc = (torch.randn((3, 5), generator=g, device=dev, dtype=torch.float64) * 40.0).requires_grad_(True)   # clamp + project
+    y = m.expmap(xc)
+    (gx,) = torch.autograd.grad((y * torch.randn_like(y)).sum(), xc)
+    assert torch.isfinite(gx).all() and float(gx.abs().max()) < 1e-1    # saturated: only the direction still matters
+    mlr = HyperMLR(6, 5, c=0.8).to(dev)
+    xe = m.expmap(torch.randn((2, 6, 3, 3), generator=g, device=dev) * 0.3, dim=1).detach().requires_grad_(True)
+    P = mlr.P_MLR.detach().clone().requires_grad_(True)
+    A = mlr.A_MLR.detach().clone().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, b, c_: _HyperMLRFn.apply(a, b, c_, 0.8), (xe, P, A), eps=1e-6, atol=1e-6, rtol=1e-4)
