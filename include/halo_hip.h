@@ -166,6 +166,26 @@ int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, 
                        int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- training-side window losses, float32 tensors, float64 sums on the device ----
+ *  - NegativeLearningLoss (core/loss/negative_learning_loss.py:6-16): sums = {sum -mask*log(1-p+1e-6), sum mask},
+ *    mask = p < threshold; loss = sums[0]/sums[1].  bwd: gp = gloss * mask / ((1-p+1e-6) * sums[1]).
+ *  - LocalConsistentLoss (core/loss/local_consistent_loss.py:5-17 = LocalDiscrepancy + DetectSPBoundary,
+ *    core/loss/boundary.py): x (B,O,h,w) logits, label (B,h,w) i64; writes p = softmax(x) and sums =
+ *    {sum of the per-pixel discrepancy over boundary pixels with a valid label, their count}; kl: 0 'l1', 1 'kl'.
+ *    coef_a/coef_b (B,O,h,w) receive d l/d p and d l/d mean for the backward call (NULL when no gradient is
+ *    needed).  bwd: gx = d (sums[0]/sums[1]) / d x * gloss  (zero when the selection is empty).
+ *  workspace: halo_loss_workspace_bytes(number of pixels or elements). */
+size_t halo_loss_workspace_bytes(int64_t n);
+int halo_negative_learning_fwd(const float *p, int64_t n, double threshold, double *sums, void *workspace,
+                               size_t workspace_bytes, void *stream);
+int halo_negative_learning_bwd(const float *p, int64_t n, double threshold, const double *sums, const float *gloss,
+                               float *gp, void *stream);
+int halo_local_consistent_fwd(const float *x, const int64_t *label, int64_t B, int64_t O, int64_t h, int64_t w, int kl,
+                              float *p, double *sums, float *coef_a, float *coef_b, void *workspace,
+                              size_t workspace_bytes, void *stream);
+int halo_local_consistent_bwd(const float *p, const float *coef_a, const float *coef_b, int64_t B, int64_t O, int64_t h,
+                              int64_t w, const double *sums, const float *gloss, float *gx, void *stream);
+
 /* ---- measurement helpers (HIP events in the same runtime the kernels are launched through) ---- */
 void *halo_event_create(void);
 int halo_event_record(void *event, void *stream);

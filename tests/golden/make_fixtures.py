@@ -278,6 +278,44 @@ def gen_grads(hyp):
     np.savez_compressed(os.path.join(HERE, "grads.npz"), **out)
 
 
+def gen_losses():
+    """core/loss: NegativeLearningLoss and LocalConsistentLoss (l1 and kl) forward values and gradients
+    w.r.t. their inputs, from the reference's own modules under autograd."""
+    from core.loss.local_consistent_loss import LocalConsistentLoss
+    from core.loss.negative_learning_loss import NegativeLearningLoss
+    g = torch.Generator().manual_seed(123)
+    out = {}
+    B, O, h, w = 2, 19, 24, 40
+    low = torch.randn(B, O, h // 4, w // 4, generator=g) * 2.0
+    x = F.interpolate(low, size=(h, w), mode="bilinear", align_corners=True) + 0.3 * torch.randn(B, O, h, w, generator=g)
+    x = x.clone().requires_grad_(True)
+    label = torch.randint(0, O, (B, h // 4, w // 4), generator=g)
+    label = label.repeat_interleave(4, dim=1).repeat_interleave(4, dim=2)         # blocky label map: real boundaries
+    label[torch.rand(B, h, w, generator=g) < 0.05] = 255
+    out["x"] = x.detach().numpy(); out["label"] = label.numpy()
+    for lt in ("l1", "kl"):
+        crit = LocalConsistentLoss(O, lt)
+        loss = crit(x, label)
+        (gx,) = torch.autograd.grad(loss, x)
+        out[f"lcl_{lt}__loss"] = np.array([loss.item()], dtype=np.float64)
+        out[f"lcl_{lt}__gx"] = gx.numpy()
+        print(f"  LocalConsistentLoss {lt}: loss {loss.item():.6f} |gx| max {float(gx.abs().max()):.3e}")
+    pr = torch.softmax(x.detach(), dim=1).clone().requires_grad_(True)
+    nl = NegativeLearningLoss(threshold=0.05)
+    loss = nl(pr)
+    (gp,) = torch.autograd.grad(loss, pr)
+    out["neg__p"] = pr.detach().numpy(); out["neg__loss"] = np.array([loss.item()], dtype=np.float64); out["neg__gp"] = gp.numpy()
+    print(f"  NegativeLearningLoss: loss {loss.item():.6f}")
+    # degenerate: no boundary pixel at all (constant labels) -> mean over an empty selection
+    lab0 = torch.zeros(1, 8, 8, dtype=torch.long)
+    x0 = torch.randn(1, O, 8, 8, generator=g).requires_grad_(True)
+    l0 = LocalConsistentLoss(O, "l1")(x0, lab0)
+    (g0,) = torch.autograd.grad(l0, x0, allow_unused=True)
+    out["empty__x"] = x0.detach().numpy(); out["empty__loss_isnan"] = np.array([bool(torch.isnan(l0))])
+    out["empty__gx"] = (g0 if g0 is not None else torch.zeros_like(x0)).numpy()
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+
+
 class _FakeExtractor(torch.nn.Module):
     def forward(self, x):
         return x
@@ -369,6 +407,9 @@ def main():
     if only == "grads":
         gen_grads(hyp)
         return
+    if only == "losses":
+        gen_losses()
+        return
     print("case A 32x64 C8 O19 (selection runs to exhaustion)")
     gen_case(cfg, hyp, fr, ab, "case_a_32x64_c8_o19", 32, 64, 8, 19, 11, 200, COMBOS)
     print("case B 64x128 C16 O19")
@@ -385,6 +426,8 @@ def main():
     gen_helpers(cfg, hyp, fr)
     print("head-tail gradients")
     gen_grads(hyp)
+    print("training losses")
+    gen_losses()
     print("RegionSelection driver, 2 rounds")
     gen_region_selection(cfg, hyp, fr, ab)
 

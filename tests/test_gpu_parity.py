@@ -864,3 +864,33 @@ def test_autograd_gradcheck_float64(dev):
     P = mlr.P_MLR.detach().clone().requires_grad_(True)
     A = mlr.A_MLR.detach().clone().requires_grad_(True)
     assert torch.autograd.gradcheck(lambda a, b, c_: _HyperMLRFn.apply(a, b, c_, 0.8), (xe, P, A), eps=1e-6, atol=1e-6, rtol=1e-4)
+
+
+def test_training_losses_match_reference_values_and_gradients(golden, dev):
+    """NegativeLearningLoss and LocalConsistentLoss ('l1', 'kl'): forward value and gradient w.r.t. the input
+    vs the reference's own modules under autograd (tests/golden/losses.npz), incl. the empty-selection case."""
+    from halo_amd.core.loss import LocalConsistentLoss, NegativeLearningLoss
+    d = golden("losses")
+    label = t(d["label"], dev)
+    for lt in ("l1", "kl"):
+        x = t(d["x"], dev).requires_grad_(True)
+        loss = LocalConsistentLoss(19, lt)(x, label)
+        assert loss.dtype == torch.float32
+        assert abs(loss.item() - float(d[f"lcl_{lt}__loss"][0])) < 2e-6 * max(1.0, abs(float(d[f"lcl_{lt}__loss"][0])))
+        (gx,) = torch.autograd.grad(loss, x)
+        want = d[f"lcl_{lt}__gx"]
+        assert np.abs(gx.cpu().numpy() - want).max() < 2e-5 * np.abs(want).max() + 1e-9, lt
+    with torch.no_grad():                                     # no gradient requested: no coefficient tensors
+        assert abs(float(LocalConsistentLoss(19, "l1")(t(d["x"], dev), label)) - float(d["lcl_l1__loss"][0])) < 1e-6
+    p = t(d["neg__p"], dev).requires_grad_(True)
+    loss = NegativeLearningLoss(threshold=0.05)(p)
+    assert abs(loss.item() - float(d["neg__loss"][0])) < 2e-6
+    (gp,) = torch.autograd.grad(loss, p)
+    assert np.abs(gp.cpu().numpy() - d["neg__gp"]).max() < 2e-5 * np.abs(d["neg__gp"]).max()
+    x0 = t(d["empty__x"], dev).requires_grad_(True)
+    l0 = LocalConsistentLoss(19, "l1")(x0, torch.zeros((1, 8, 8), dtype=torch.int64, device=dev))
+    assert bool(torch.isnan(l0)) == bool(d["empty__loss_isnan"][0])
+    (g0,) = torch.autograd.grad(l0, x0)
+    assert float(g0.abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        LocalConsistentLoss(19, "l2")
