@@ -203,7 +203,7 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
                                   batch["origin_label"][i], batch["active"][i], batch["selected"][i], dev, side)
                 rec.path_mask, rec.path_indicator = batch["path_to_mask"][i], batch["path_to_indicator"][i]
                 queue.append(rec)
-                while len(queue) > max(1, in_flight):
+                while len(queue) > max(0, in_flight):      # in_flight=0: fully serial, like the reference
                     _retire(queue.pop(0), writers, pending)
         while queue:
             _retire(queue.pop(0), writers, pending)

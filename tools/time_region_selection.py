@@ -1,0 +1,68 @@
+"""Timing aid: the RegionSelection driver end to end (staging, fused resize+score, greedy selection, PNG +
+indicator files) on full-size synthetic pool images, serial vs pipelined (one MI355X).  The backbone is a
+stand-in that only sleeps on the GPU for a configurable time, so the number isolates the acquisition side."""
+import os, sys, tempfile, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from halo_amd.core.active.build import RegionSelection
+from halo_amd.core.utils.hyperbolic import HyperMapper
+
+dev = torch.device("cuda:0")
+N, H, W, C, O = 24, 1024, 2048, 64, 19
+cfg = types.SimpleNamespace(
+    MODEL=types.SimpleNamespace(NUM_CLASSES=O, HYPER=True, CURVATURE=1.0),
+    ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                 BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+g = torch.Generator(device=dev).manual_seed(0)
+emb = HyperMapper(1.0).expmap(torch.randn((1, C, 160, 320), generator=g, device=dev) * 0.1, dim=1)
+logit = torch.nn.functional.interpolate(torch.randn((1, O, 160, 320), generator=g, device=dev), size=(640, 1280), mode="bilinear", align_corners=True)
+
+
+class Ident(torch.nn.Module):
+    def forward(self, x):
+        return x
+
+
+class Head(torch.nn.Module):
+    def __init__(self, busy_ms):
+        super().__init__()
+        self.busy_ms = busy_ms
+        self.a = torch.randn((4096, 4096), device=dev)
+
+    def forward(self, x, size=None):
+        if self.busy_ms > 0:                                          # stand-in for the backbone forward:
+            if MODE == "sleep":                                       #   a spin kernel on one CU (GPU mostly idle)
+                torch.cuda._sleep(int(self.busy_ms * 1e-3 * 2.1e9))
+            else:                                                     #   or back-to-back full-GPU GEMMs
+                for _ in range(int(self.busy_ms / GEMM_MS)):
+                    self.a @ self.a
+            torch.cuda.current_stream().synchronize()
+        return logit, emb
+
+
+def pool(tmp):
+    # pinned like the reference's DataLoader(pin_memory=True) batches (train_learners.py:283-289)
+    gt = torch.randint(0, O, (1, H, W)).pin_memory()
+    return [{"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [os.path.join(tmp, f"m{i}.png")],
+             "origin_mask": torch.full((1, H, W), 255, dtype=torch.int64).pin_memory(), "origin_label": gt, "size": torch.tensor([[H, W]]),
+             "active": torch.zeros(1, H, W, dtype=torch.bool).pin_memory(), "selected": torch.zeros(1, H, W, dtype=torch.bool).pin_memory(),
+             "path_to_indicator": [os.path.join(tmp, f"i{i}.pth")], "name": [f"img{i}"]} for i in range(N)]
+
+
+GEMM_MS = 1.0
+a_ = torch.randn((4096, 4096), device=dev); a_ @ a_; torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    a_ @ a_
+torch.cuda.synchronize(); GEMM_MS = (time.perf_counter() - t0) / 20 * 1e3
+print(f"4096^3 f32 GEMM: {GEMM_MS:.2f} ms")
+for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
+    for (infl, wr, tag) in ((0, 1, "serial (in_flight=0, 1 writer)"), (3, 4, "pipelined (in_flight=3, 4 writers)")):
+        tmp = tempfile.mkdtemp(prefix="halo_rs_t_")
+        items = pool(tmp)
+        RegionSelection(cfg, Ident(), Head(busy), items[:2], 1, in_flight=infl, writer_threads=wr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        RegionSelection(cfg, Ident(), Head(busy), items, 1, in_flight=infl, writer_threads=wr)
+        dt = time.perf_counter() - t0
+        print(f"backbone stand-in {MODE:5s} {busy:4.0f} ms: {tag:38s} {dt / N * 1e3:7.1f} ms/image  ({N / dt:6.1f} images/s)")
