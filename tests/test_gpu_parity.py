@@ -894,3 +894,29 @@ def test_training_losses_match_reference_values_and_gradients(golden, dev):
     assert float(g0.abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
         LocalConsistentLoss(19, "l2")
+
+
+@pytest.mark.parametrize("c", [0.5, 2.0])
+def test_score_with_other_curvatures(dev, c):
+    """cfg.MODEL.CURVATURE != 1 reaches the scorer through HyperMapper(c) (floating_region.py:68)."""
+    from halo_amd.core.active.floating_region import FloatingRegionScore, score_maps
+    from halo_amd.core.configs import cfg
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(int(c * 10))
+    H, W, C, O = 40, 64, 10, 19
+    logit = rng.standard_normal((1, O, H, W)).astype(np.float32)
+    emb = ho.expmap((rng.standard_normal((1, C, H, W)) * 0.3).astype(np.float32), c, dim=1)
+    for pur in ("radius", "hyper"):
+        so, io, uo = ho.floating_region_score(logit, emb, "entropy", pur, True, None, size=3, purity_type=pur, K=20, c=c)
+        s, i, u = score_maps(t(logit, dev), t(emb, dev), "entropy", pur, True, None, size=3, K=20, c=c)
+        assert bits_equal(s[0].cpu().numpy(), so) and bits_equal(i[0].cpu().numpy(), io)
+    old = cfg.MODEL.CURVATURE
+    try:
+        cfg.MODEL.CURVATURE = c
+        frs = FloatingRegionScore(in_channels=O, size=3, purity_type="radius")
+        assert frs.mapper.c == c
+        s2, _, _ = frs(t(logit, dev), decoder_out=t(emb, dev), unc_type="entropy", pur_type="radius", normalize=True)
+        so, _, _ = ho.floating_region_score(logit, emb, "entropy", "radius", True, None, size=3, purity_type="radius", c=c)
+        assert bits_equal(s2.cpu().numpy(), so)
+    finally:
+        cfg.MODEL.CURVATURE = old
