@@ -129,6 +129,9 @@ class Pipeline:
             if use_dist else None
         self.step_no = 0
         self.last = None
+        self.slot_lo = [None] * D          # which ring slice each slot last processed
+        self.ref_tables = {}               # ring offset -> pick table seen first (the ring repeats: tables must too)
+        self.tables_consistent = True
 
     def step(self, timed):
         from halo_amd.core.active.build import greedy_select
@@ -167,12 +170,22 @@ class Pipeline:
                 dist.all_gather_into_tensor(self.gathered[k], self.tables[k])
             self.selected_done[k].record(self.s_sel[k])
         self.last = (k, lo, npk)
+        self.slot_lo[k] = lo
         self.step_no += 1
 
     def drain(self):
         self.s_score.synchronize()
         for st in self.s_sel:
             st.synchronize()
+        # self-check under concurrency (outside the timed region): the same ring images must give the same
+        # pick tables whichever slot / step / overlap pattern processed them
+        for k, lo in enumerate(self.slot_lo):
+            if lo is None:
+                continue
+            if lo not in self.ref_tables:
+                self.ref_tables[lo] = self.tables[k].clone()
+            elif not torch.equal(self.ref_tables[lo], self.tables[k]):
+                self.tables_consistent = False
 
     def feat_kernel_ms(self):
         import ctypes
@@ -259,6 +272,7 @@ def main():
     feat_ms = pipe.feat_kernel_ms()
     k, lo, npk = pipe.last
     assert int(npk.min()) == n_regions, "selection stopped early"
+    assert pipe.tables_consistent, "pick tables of the same images differ between steps (race in the pipeline)"
 
     if rank == 0:
         esz = 8 if fdtype == torch.float64 else 4
@@ -283,6 +297,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms)},
             "path_algorithmic_GBps": round(path_bytes_per_image * value / world / 1e9, 1),
+            "pipeline_tables_consistent": bool(pipe.tables_consistent),
         }
         if lowres:      # not the BASELINE unit of work: a different (smaller) input boundary, reported for DESIGN.md
             out["config"]["workload"] = "RegionSelection boundary (N1): x4 low-res head outputs (%dx%d), upsample fused into the scorer, " \

@@ -791,6 +791,7 @@ def test_bench_contract_on_a_small_shape(dev):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "images/s" and d["parity_vs_cpu"] is True
+    assert d["pipeline_tables_consistent"] is True
 
 
 def test_fused_and_unfused_entropy_paths_agree_bitwise(dev):
