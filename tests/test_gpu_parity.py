@@ -921,3 +921,41 @@ def test_score_with_other_curvatures(dev, c):
         assert bits_equal(s2.cpu().numpy(), so)
     finally:
         cfg.MODEL.CURVATURE = old
+
+
+def test_calls_are_graph_capturable(dev):
+    """include/halo_hip.h promises asynchronous enqueue only (no allocation, no host sync inside a call):
+    capture score + select into a HIP graph through torch.cuda.CUDAGraph, replay it on new input values and
+    compare with the eager result."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps
+    B, H, W, C, O, n = 2, 64, 128, 8, 19, 12
+    d0 = [_synthetic(H, W, C, O, 700 + b) for b in range(B)]
+    d1 = [_synthetic(H, W, C, O, 800 + b) for b in range(B)]
+    logit = torch.cat([t(x[0], dev) for x in d0]); emb = torch.cat([t(x[1], dev) for x in d0])
+    gt = torch.stack([t(x[2], dev) for x in d0])
+    score = torch.empty((B, H, W), dtype=torch.float64, device=dev)
+    act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+    am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+
+    def work():
+        act.zero_(); sel.zero_(); am.fill_(255)
+        score_maps(logit, emb, "entropy", "radius", True, None, size=3, active=act, want_maps=False, out=score)
+        return greedy_select(score, n, 1, 5, act, sel, am, gt)
+
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        work()                                                   # warm-up outside capture (workspaces get cached)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        picks_g, npk_g = work()
+    logit.copy_(torch.cat([t(x[0], dev) for x in d1])); emb.copy_(torch.cat([t(x[1], dev) for x in d1]))
+    gt.copy_(torch.stack([t(x[2], dev) for x in d1]))
+    g.replay()
+    torch.cuda.synchronize()
+    got = (picks_g.clone(), npk_g.clone(), act.clone(), am.clone())
+    picks_e, npk_e = work()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], picks_e) and torch.equal(got[1], npk_e) and torch.equal(got[2], act) and torch.equal(got[3], am)
+    assert int(npk_e.min()) == n
