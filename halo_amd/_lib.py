@@ -94,7 +94,8 @@ def lib():
         if _handle is not None:
             return _handle
         try:
-            path = _build.build()
+            # HALO_LIB_PATH: load a specific build of the library (A/B timing of kernel variants)
+            path = os.environ.get("HALO_LIB_PATH") or _build.build()
         except Exception as exc:  # no hipcc and no prebuilt .so: fail loudly, never fall back
             if os.path.exists(_build.SO):
                 path = _build.SO
