@@ -30,6 +30,26 @@ __global__ void __launch_bounds__(TPB_) k_planes(const double* __restrict__ feat
     *reinterpret_cast<d2_t*>(out + (size_t)b * hw + i0) = r;
 }
 
+// explicit plane stride (in doubles)
+template <int UNROLL, int TPB_>
+__global__ void __launch_bounds__(TPB_) k_planes_s(const double* __restrict__ feat, long long bstride, int C, long long hw, long long pstride, double* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long long i0 = ((long long)blockIdx.x * TPB_ + threadIdx.x) * 2;
+    if (i0 >= hw) return;
+    const double* p = feat + (size_t)b * bstride + i0;
+    double a0 = 0, a1 = 0;
+    for (int c = 0; c + UNROLL <= C; c += UNROLL) {
+        d2_t v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(p + (size_t)(c + u) * pstride));
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { a0 = __builtin_fma(v[u].x, v[u].x, a0); a1 = __builtin_fma(v[u].y, v[u].y, a1); }
+    }
+    d2_t r; r.x = a0; r.y = a1;
+    *reinterpret_cast<d2_t*>(out + (size_t)b * hw + i0) = r;
+}
+
 // 4 doubles (32 B) per lane: a wave reads 2 KiB contiguous per plane
 template <int UNROLL, int TPB_>
 __global__ void __launch_bounds__(TPB_) k_planes4(const double* __restrict__ feat, long long bstride, int C, long long hw, double* __restrict__ out)
@@ -91,11 +111,11 @@ template <typename F> float time_ms(F f, int reps)
 int main()
 {
     const int B = 8, C = 256; const long long hw = 1024ll * 2048;
-    const size_t n = (size_t)B * C * hw;
+    const size_t n = (size_t)B * C * (hw + 70000);
     double *feat, *out;
     CK(hipMalloc(&feat, n * 8)); CK(hipMalloc(&out, (size_t)B * hw * 8));
     CK(hipMemset(feat, 0x3c, n * 8));
-    const double gb = n * 8 / 1e9;
+    const double gb = (double)B * C * hw * 8 / 1e9;
     printf("bytes per launch %.2f GB\n", gb);
 #define RUN(U, NT, T) { printf("planes unroll %2d nt %d tpb %4d:", U, NT, T); dim3 g((unsigned)((hw / 2 + T - 1) / T), B); \
     float ms = time_ms([&] { hipLaunchKernelGGL((k_planes<U, NT, T>), g, dim3(T), 0, 0, feat, (long long)C * hw, C, hw, out); }, 8); printf("  -> %.0f GB/s\n", gb / ms * 1e3); }
@@ -106,10 +126,22 @@ int main()
 #define RUN4(U, T) { printf("planes4 unroll %2d tpb %4d:", U, T); dim3 g((unsigned)((hw / 4 + T - 1) / T), B); \
     float ms = time_ms([&] { hipLaunchKernelGGL((k_planes4<U, T>), g, dim3(T), 0, 0, feat, (long long)C * hw, C, hw, out); }, 8); printf("  -> %.0f GB/s\n", gb / ms * 1e3); }
     RUN4(4, 256) RUN4(8, 256) RUN4(4, 128) RUN4(8, 128) RUN4(8, 64)
+    // plane stride: 2^24 bytes (the contiguous (C,H,W) tensor) vs padded strides -- does power-of-two aliasing matter?
+    {
+        const long long pads[] = {0, 64, 512, 4096, 65536 + 512};      // extra doubles per plane
+        for (long long pad : pads) {
+            const long long stride = hw + pad;
+            if ((size_t)B * C * stride > n) continue;
+            printf("planes unroll  8 nt 1 tpb  128 plane stride hw+%-6lld:", pad);
+            dim3 g((unsigned)((hw / 2 + 127) / 128), B);
+            float ms = time_ms([&] { hipLaunchKernelGGL((k_planes_s<8, 128>), g, dim3(128), 0, 0, feat, (long long)C * stride, C, hw, stride, out); }, 8);
+            printf("  -> %.0f GB/s\n", gb / ms * 1e3);
+        }
+    }
     for (int nt = 1; nt < 2; ++nt) for (int blocks : {2048, 4096, 8192, 16384}) {
         printf("flat nt %d blocks %5d:", nt, blocks);
-        float ms = nt ? time_ms([&] { hipLaunchKernelGGL((k_flat<1>), dim3(blocks), dim3(256), 0, 0, (const d2_t*)feat, n / 2, out); }, 8)
-                      : time_ms([&] { hipLaunchKernelGGL((k_flat<0>), dim3(blocks), dim3(256), 0, 0, (const d2_t*)feat, n / 2, out); }, 8);
+        float ms = nt ? time_ms([&] { hipLaunchKernelGGL((k_flat<1>), dim3(blocks), dim3(256), 0, 0, (const d2_t*)feat, (size_t)B * C * hw / 2, out); }, 8)
+                      : time_ms([&] { hipLaunchKernelGGL((k_flat<0>), dim3(blocks), dim3(256), 0, 0, (const d2_t*)feat, (size_t)B * C * hw / 2, out); }, 8);
         printf("  -> %.0f GB/s\n", gb / ms * 1e3);
     }
     return 0;
