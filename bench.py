@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- acquisition-scored images/s on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      # N > 1 without a launcher: starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -46,18 +46,27 @@ H, W, O = 1024, 2048, 19
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=32, help="default 32 x 16 = 512 image evaluations (configs[1]: 500)")
     ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--pool-images", type=int, default=0,
+                    help="score exactly this many image evaluations over all ranks (overrides --steps; 2975 = configs[2], "
+                         "the Cityscapes train list), the last step of a rank being a partial batch")
     ap.add_argument("--batch", type=int, default=16, help="images per step and rank")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight (selection slots); 0 = 3 for f64, 6 for f32")
-    ap.add_argument("--ring", type=int, default=16, help="distinct resident images per rank")
+    ap.add_argument("--ring", type=int, default=32, help="distinct resident images per rank (two batches: consecutive "
+                                                         "steps read different images)")
+    ap.add_argument("--branch", choices=["halo", "ripu", "hyper"], default="halo",
+                    help="halo = entropy x radius, normalised, mask radius 5 (configs/gtav/source_target.yaml, the BASELINE "
+                         "unit); ripu = entropy x ripu, not normalised, mask radius 3 (configs/gtav/ripu.yaml); hyper = "
+                         "entropy x hyper (K=100 radius bins), the defaults.py:69 purity")
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--feat-dtype", choices=["f64", "f32"], default="f64",
                     help="f64 = what the reference's hyperbolic head hands over (hyperbolic.py:37)")
     ap.add_argument("--source", choices=["fullres", "lowres"], default="fullres",
                     help="fullres = SURVEY 8(d) unit of work (default, the BASELINE metric); lowres = the "
                          "RegionSelection boundary: x4 low-res head outputs, upsampling fused into the scorer (N1)")
-    ap.add_argument("--cpu-images", type=int, default=4, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=8, help="timed images in the CPU-baseline sample, after one "
+                                                              "untimed warm-up image (0 = skip)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
@@ -97,24 +106,33 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres=False):
     return feat, logit, gt
 
 
+BRANCHES = {   # name -> (unc_type, pur_type, normalize, mask radius, K)
+    "halo": ("entropy", "radius", True, 5, 100),      # configs/gtav/source_target.yaml (HYPER head)
+    "ripu": ("entropy", "ripu", False, 3, 100),       # configs/gtav/ripu.yaml:23-27
+    "hyper": ("entropy", "hyper", True, 5, 100),      # core/configs/defaults.py:66-79
+}
+
+
 class Pipeline:
     """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
 
-    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False):
+    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False, branch="halo"):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
         self.R = feat.shape[0]
         self.lowres = lowres
+        self.unc, self.pur, self.norm, self.mrad, self.K = BRANCHES[branch]
         Hh, Ww = gt.shape[-2:]
         self.size = (Hh, Ww)
-        # The greedy selector is latency-bound (2331 dependent steps per image, one workgroup per
-        # image, ~20 ms per batch) while scoring is bandwidth-bound (~6 ms per batch): keep `depth`
-        # batches in flight, each slot selecting on its own stream, so selection hides behind scoring.
+        # Scoring is bandwidth-bound, the greedy selector is latency-bound (dependent steps, one workgroup
+        # per image): keep `depth` batches in flight, each slot selecting on its own stream, so that
+        # selection runs beside the scoring of later batches.
         D = self.D = depth
         self.s_score = torch.cuda.Stream(dev)
         self.s_sel = [torch.cuda.Stream(dev, priority=-1) for _ in range(D)]   # dispatch ahead of scoring
-        sdt = torch.float64 if feat.dtype == torch.float64 else torch.float32
+        from halo_amd.core.active.floating_region import score_dtype
+        sdt = score_dtype(self.pur, feat)
         self.score = [torch.empty((B, Hh, Ww), dtype=sdt, device=dev) for _ in range(D)]
         self.active = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
         self.selected = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
@@ -125,25 +143,30 @@ class Pipeline:
         self.world = world
         self.use_dist = use_dist
         self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]
-        self.gathered = [torch.zeros((world * B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)] \
-            if use_dist else None
+        self.counts = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(D)]
+        self.gathered = [None] * D         # (tables, counts, owner) of the whole step, every rank
         self.step_no = 0
         self.last = None
         self.slot_lo = [None] * D          # which ring slice each slot last processed
         self.ref_tables = {}               # ring offset -> pick table seen first (the ring repeats: tables must too)
         self.tables_consistent = True
+        self.min_picked = n_regions
 
-    def step(self, timed):
+    def step(self, timed, b=None):
+        """One batch of `b` (default B) images: score on s_score, then mask + select (+ the all-gather) on the slot's stream."""
         from halo_amd.core.active.build import greedy_select
         from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
+        from halo_amd.pool import gather_tables
         B, R = self.B, self.R
+        b = B if b is None else b
         k = self.step_no % self.D
         lo = (self.step_no * B) % R
         if lo + B > R:
             lo = 0
-        fb, lb, gb = self.feat[lo:lo + B], self.logit[lo:lo + B], self.gt[lo:lo + B]
+        fb, lb, gb = self.feat[lo:lo + b], self.logit[lo:lo + b], self.gt[lo:lo + b]
         evs = None
-        if timed and not self.lowres:
+        timed_kernel = timed and not self.lowres and self.pur in ("radius", "euc_norm", "hyper")
+        if timed_kernel:
             evs = (self.lib.halo_event_create(), self.lib.halo_event_create())
             self.ev.append(evs)
         with torch.cuda.stream(self.s_score):
@@ -154,23 +177,27 @@ class Pipeline:
             self.active[k].zero_()
             self.selected[k].zero_()
             self.amask[k].fill_(255)
+            # all three output maps of FloatingRegionScore.forward are written (floating_region.py:217)
             if self.lowres:
-                sc, _, _ = score_maps_lowres(lb, fb, self.size, "entropy", "radius", True, None, ksize=3, c=1.0,
-                                             active=self.active[k], want_maps=False)
-                self.score[k].copy_(sc)
+                sc, self.imp, self.unc_map = score_maps_lowres(lb, fb, self.size, self.unc, self.pur, self.norm, gb, ksize=3,
+                                                               K=self.K, c=1.0, active=self.active[k][:b], want_maps=True)
+                self.score[k][:b].copy_(sc)
             else:
-                score_maps(lb, fb, "entropy", "radius", True, None, size=3, c=1.0, active=self.active[k],
-                           want_maps=False, out=self.score[k], events=evs)
+                _, self.imp, self.unc_map = score_maps(lb, fb, self.unc, self.pur, self.norm, gb, size=3, K=self.K, c=1.0,
+                                                       active=self.active[k][:b], want_maps=True, out=self.score[k][:b],
+                                                       events=evs)
             self.scored[k].record(self.s_score)
         with torch.cuda.stream(self.s_sel[k]):
             self.s_sel[k].wait_event(self.scored[k])
-            picks, npk = greedy_select(self.score[k], self.n, 1, 5, self.active[k], self.selected[k], self.amask[k], gb)
-            self.tables[k].copy_(picks)
-            if self.use_dist:      # the path's one exchange step: per-image pick tables to every rank
-                dist.all_gather_into_tensor(self.gathered[k], self.tables[k])
+            picks, npk = greedy_select(self.score[k][:b], self.n, 1, self.mrad, self.active[k][:b], self.selected[k][:b],
+                                       self.amask[k][:b], gb)
+            self.tables[k][:b].copy_(picks)
+            self.counts[k][:b].copy_(npk)
+            if self.use_dist:      # the path's one exchange step: per-image pick tables to every rank, ONE collective
+                self.gathered[k] = gather_tables(self.tables[k][:b], self.counts[k][:b], self.world * b)
             self.selected_done[k].record(self.s_sel[k])
-        self.last = (k, lo, npk)
-        self.slot_lo[k] = lo
+        self.last = (k, lo, b)
+        self.slot_lo[k] = (lo, b)
         self.step_no += 1
 
     def drain(self):
@@ -179,12 +206,15 @@ class Pipeline:
             st.synchronize()
         # self-check under concurrency (outside the timed region): the same ring images must give the same
         # pick tables whichever slot / step / overlap pattern processed them
-        for k, lo in enumerate(self.slot_lo):
-            if lo is None:
+        for k, ent in enumerate(self.slot_lo):
+            if ent is None:
                 continue
+            lo, b = ent
+            self.min_picked = min(self.min_picked, int(self.counts[k][:b].min()))
             if lo not in self.ref_tables:
-                self.ref_tables[lo] = self.tables[k].clone()
-            elif not torch.equal(self.ref_tables[lo], self.tables[k]):
+                if b == self.B:
+                    self.ref_tables[lo] = self.tables[k].clone()
+            elif not torch.equal(self.ref_tables[lo][:b], self.tables[k][:b]):
                 self.tables_consistent = False
 
     def feat_kernel_ms(self):
@@ -200,31 +230,57 @@ class Pipeline:
         return out
 
 
-def cpu_baseline(feat, logit, gt, n_images, n_regions):
-    """The CPU oracle (kind 'port': C restatement, OpenMP over all host cores) on the first
-    `n_images` ring images: score + mask + select, s/image -> images/s.  Also returns its picks so
-    the caller can compare them with the GPU's (same inputs)."""
+def cpu_baseline(feat, logit, gt, n_images, n_regions, branch):
+    """The CPU oracle (kind 'port': C restatement, OpenMP over all host cores) on the first ring images:
+    one untimed warm-up image, then `n_images` timed ones: score + mask + select, median
+    s/image -> images/s.  Also returns image 0's picks so the caller can compare them with the GPU's."""
     from oracle import halo_oracle as ho
     ho.lib()
+    unc, pur, norm, mrad, K = BRANCHES[branch]
     cores = os.cpu_count() or 1
     times, picks = [], []
-    for i in range(n_images):
+    R = feat.shape[0]
+    for j in range(n_images + 1):
+        i = j % R
         lg = logit[i].cpu().numpy()
         ft = feat[i].cpu().numpy()
         g = gt[i].cpu().numpy()
         Hh, Ww = g.shape
         t0 = time.perf_counter()
-        s, _, _ = ho.floating_region_score(lg, ft, "entropy", "radius", True, g, size=3, purity_type="radius")
+        s, _, _ = ho.floating_region_score(lg, ft, unc, pur, norm, g, size=3, purity_type=pur, K=K)
         act = np.zeros((Hh, Ww), bool); sel = np.zeros((Hh, Ww), bool); am = np.full((Hh, Ww), 255, np.int64)
         s[act] = -np.inf
-        _, _, _, _, pk = ho.select_pixels_to_label(s, n_regions, 1, 5, act, sel, am, g, True)
-        times.append(time.perf_counter() - t0)
+        _, _, _, _, pk = ho.select_pixels_to_label(s, n_regions, 1, mrad, act, sel, am, g, True)
+        if j > 0:
+            times.append(time.perf_counter() - t0)
         picks.append(pk)
     return float(np.median(times)), cores, picks
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through
+    torch.distributed.run and relay their output.  Nothing in this process has touched the GPU yet
+    (device_count() does not initialise it), and it only waits for the children -- no exec."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit("bench.py: --gpus %d but only %d ROCm device(s) visible" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,13 +299,22 @@ def main():
     Hh, Ww, C, B = a.height, a.width, a.channels, a.batch
     R = max(B, (a.ring // B) * B)
     n_regions = math.ceil(Hh * Ww * (0.05 / 5) / 9)                    # build.py:148-150 -> 2331
+    unc, pur, norm, mrad, K = BRANCHES[a.branch]
 
     lowres = a.source == "lowres"
     if lowres:
         a.cpu_images = 0
     feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch)
 
+    # per-rank schedule: full batches, plus a partial last one when --pool-images does not divide evenly
+    if a.pool_images > 0:
+        from halo_amd.pool import shard_range
+        per_rank = shard_range(a.pool_images, 0, world)[1]            # every rank runs the largest block (weak scaling)
+        sched = [B] * (per_rank // B) + ([per_rank % B] if per_rank % B else [])
+        a.steps = len(sched)
+    else:
+        sched = [B] * a.steps
     for _ in range(a.warmup):
         pipe.step(False)
     pipe.drain()
@@ -257,8 +322,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        pipe.step(True)
+    for b in sched:
+        pipe.step(True, b)
     pipe.drain()
     torch.cuda.synchronize(dev)
     if use_dist:
@@ -270,29 +335,32 @@ def main():
         dt = float(tt.item())
 
     feat_ms = pipe.feat_kernel_ms()
-    k, lo, npk = pipe.last
-    assert int(npk.min()) == n_regions, "selection stopped early"
+    assert pipe.min_picked == n_regions, "selection stopped early"
     assert pipe.tables_consistent, "pick tables of the same images differ between steps (race in the pipeline)"
 
     if rank == 0:
         esz = 8 if fdtype == torch.float64 else 4
-        images = world * a.steps * B
+        ssz = pipe.score[0].element_size()
+        images = world * sum(sched)
         value = images / dt
         # k_feat_reduce per launch: features read + radius map written + (fused) logits read + entropy map written
         launch_bytes = B * Hh * Ww * (C * esz + esz + O * 4 + 4)
         avg_ms = float(np.mean(feat_ms)) if feat_ms else float("nan")
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9 if feat_ms else float("nan")
-        path_bytes_per_image = Hh * Ww * (C * esz + O * 4 + esz)
+        uses_feat = pur in ("radius", "euc_norm", "hyper")
+        path_bytes_per_image = Hh * Ww * ((C * esz if uses_feat else 0) + O * 4 + ssz)
         out = {
             "metric": "acquisition-scored images/sec (1024x2048, C=256, 19 cls)",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.feat_dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic pool, %dx%d, C=%d %s embedding, %d classes, HALO branch "
-                                   "(entropy x radius, normalised, 3x3), %d regions/image, radius 1, mask radius 5"
-                                   % (Hh, Ww, C, a.feat_dtype, O, n_regions),
+            "config": {"workload": "configs[%d]: synthetic pool, %dx%d, C=%d %s embedding, %d classes, %s branch "
+                                   "(%s x %s, %s, 3x3), %d regions/image, radius 1, mask radius %d"
+                                   % (2 if a.pool_images == 2975 else 1, Hh, Ww, C, a.feat_dtype, O, a.branch.upper(), unc, pur,
+                                      "normalised" if norm else "not normalised", n_regions, mrad),
                        "images_per_step_per_gpu": B, "batches_in_flight": a.depth, "resident_ring": R, "image_evaluations": images,
-                       "sharding": "image-wise, %d rank(s)%s" % (world, ", RCCL all-gather of pick tables per step" if use_dist else "")},
+                       "outputs_written": "score, region_impurity, prediction_uncertainty (+ masks, pick tables)",
+                       "sharding": "image-wise, %d rank(s)%s" % (world, ", one RCCL all-gather of pick tables per step" if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms)},
@@ -302,36 +370,43 @@ def main():
         if lowres:      # not the BASELINE unit of work: a different (smaller) input boundary, reported for DESIGN.md
             out["config"]["workload"] = "RegionSelection boundary (N1): x4 low-res head outputs (%dx%d), upsample fused into the scorer, " \
                                         "then the same mask + select; NOT the BASELINE unit of work" % (Hh // 4, Ww // 4)
+        if lowres or not feat_ms:
             out["roofline"] = None
-            out["path_algorithmic_GBps"] = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc):
+            if lowres:
+                out["path_algorithmic_GBps"] = None
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if out["roofline"] is None or not os.path.exists(pmc):
+                continue
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("dtype") == a.feat_dtype and rec.get("shape_HWCO") == [Hh, Ww, C, O]:
                     out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json"
+                    out["roofline"]["traffic_source"] = "profiles/" + name
+                    break
             except Exception:
                 pass
         if a.cpu_images > 0 and world == 1:
-            s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, min(a.cpu_images, R), n_regions)
+            s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, a.cpu_images, n_regions, a.branch)
             out["cpu_baseline"] = {"value": round(1.0 / s_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                                   "sample": "%d of the same ring images, oracle/halo_oracle.c (OpenMP), median s/image = %.2f"
-                                             % (min(a.cpu_images, R), s_img)}
-            # same inputs -> the GPU picks of the last step's images can be checked when they overlap
+                                   "sample": "1 warm-up + %d timed ring images, oracle/halo_oracle.c (OpenMP), median s/image = %.2f"
+                                             % (a.cpu_images, s_img)}
+            # same inputs -> the GPU picks of image 0 must equal the oracle's
             from halo_amd.core.active.build import acquire_batch
             act = torch.zeros((1, Hh, Ww), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
             am = torch.full((1, Hh, Ww), 255, dtype=torch.int64, device=dev)
             with torch.no_grad():
-                pk, nk = acquire_batch(logit[0:1], feat[0:1], gt[0:1], act, sel, am, unc_type="entropy",
-                                       pur_type="radius", normalize=True, n_regions=n_regions, active_radius=1, mask_radius=5)
+                pk, nk = acquire_batch(logit[0:1], feat[0:1], gt[0:1], act, sel, am, unc_type=unc, pur_type=pur, normalize=norm,
+                                       n_regions=n_regions, active_radius=1, mask_radius=mrad, K=K)
             out["parity_vs_cpu"] = bool(np.array_equal(pk[0, :int(nk[0])].cpu().numpy(), picks_cpu[0]))
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if use_dist:
-        if rank == 0 and pipe.gathered is not None:
-            k = pipe.last[0]
-            assert torch.equal(pipe.gathered[k][:B], pipe.tables[k]), "all-gathered table differs from the local one"
+        k, lo, b = pipe.last
+        g = pipe.gathered[k]
+        if g is not None:      # every rank holds the whole step's tables; its own block must be its local result
+            assert torch.equal(g[0][rank * b:(rank + 1) * b], pipe.tables[k][:b]), "all-gathered table differs from the local one"
+            assert torch.equal(g[1][rank * b:(rank + 1) * b], pipe.counts[k][:b])
         dist.destroy_process_group()
 
 

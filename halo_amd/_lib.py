@@ -56,6 +56,10 @@ SIGNATURES = {
                                   _vp, _sz, _vp]),
 }
 
+# must equal HALO_ABI_VERSION of include/halo_hip.h; bumped whenever an exported signature changes, so a stale
+# library with the same symbol names but older argument lists is refused instead of being called with shifted arguments
+ABI_VERSION = 2
+
 _lock = threading.Lock()
 _handle = None
 
@@ -96,21 +100,56 @@ def lib():
         try:
             # HALO_LIB_PATH: load a specific build of the library (A/B timing of kernel variants)
             path = os.environ.get("HALO_LIB_PATH") or _build.build()
-        except Exception as exc:  # no hipcc and no prebuilt .so: fail loudly, never fall back
-            if os.path.exists(_build.SO):
-                path = _build.SO
-            else:
+        except Exception as exc:  # no hipcc: a prebuilt in-tree .so is fine if it is current, never a stale one
+            if not os.path.exists(_build.SO):
                 raise HaloHipError("libhalo_hip.so is missing and could not be built: %s" % exc) from exc
+            if _build.is_stale() and not os.environ.get("HALO_ALLOW_STALE_LIB"):
+                raise HaloHipError("libhalo_hip.so is older than its sources and could not be rebuilt (%s); "
+                                   "set HALO_ALLOW_STALE_LIB=1 to load it anyway" % exc) from exc
+            path = _build.SO
         _preload_torch_hip_runtime()
         h = C.CDLL(path)
+        ns = _Library()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name, None)
             if fn is None:
-                raise HaloHipError("libhalo_hip.so does not export %s" % name)
+                raise HaloHipError("%s does not export %s" % (path, name))
             fn.restype = res
             fn.argtypes = args
-        _handle = h
+            setattr(ns, name, _on_stream_device(fn) if res is _int and args and args[-1] is _vp else fn)
+        got = h.halo_version()
+        if got != ABI_VERSION:
+            raise HaloHipError("%s has ABI version %d, this package binds version %d: rebuild it "
+                               "(python -m halo_amd._build --force)" % (path, got, ABI_VERSION))
+        ns._cdll = h
+        _handle = ns
     return _handle
+
+
+class _Library(object):
+    """Typed entry points of libhalo_hip.so (attributes named like the C functions)."""
+
+
+class StreamPtr(C.c_void_p):
+    """hipStream_t as void* that remembers which device it belongs to."""
+    device_index = None
+
+
+def _on_stream_device(fn):
+    """Launch on the device that owns the stream: kernels go to the CURRENT HIP device, so tensors on
+    cuda:N with cuda:M current would otherwise be launched on M's null stream against N's pointers."""
+    def call(*args):
+        import torch
+        for a in reversed(args):
+            if isinstance(a, StreamPtr):
+                idx = a.device_index
+                if idx is not None and idx != torch.cuda.current_device():
+                    with torch.cuda.device(idx):
+                        return fn(*args)
+                break
+        return fn(*args)
+    call.__name__ = getattr(fn, "__name__", "halo_call")
+    return call
 
 
 def check(rc, what=""):
@@ -151,7 +190,10 @@ def require_device(*tensors):
 
 def stream_ptr(device=None):
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    st = torch.cuda.current_stream(device)
+    p = StreamPtr(st.cuda_stream)
+    p.device_index = st.device.index
+    return p
 
 
 def ptr(t):

@@ -14,7 +14,7 @@ from PIL import Image
 
 from ... import _lib
 from ..configs import cfg
-from ..utils.hyperbolic import bilinear_align_corners
+from ..utils.hyperbolic import HyperMapper, bilinear_align_corners
 from .floating_region import FloatingRegionScore, score_maps, score_maps_lowres, _workspace
 
 
@@ -119,6 +119,14 @@ class AcquisitionParams:
         self.normalize = act.NORMALIZE
         self.scorer = FloatingRegionScore(in_channels=cfg_.MODEL.NUM_CLASSES, size=self.window,
                                           purity_type=self.pur, K=self.K)
+        # the reference's scorer reads the curvature from the one global cfg (floating_region.py:68); here the
+        # cfg that was PASSED IN decides, whether or not halo_amd.core.configs.use() was called
+        self.scorer.mapper = HyperMapper(c=cfg_.MODEL.CURVATURE)
+        if getattr(act, "VIZ_MASK", False):
+            import warnings
+            warnings.warn("halo_amd RegionSelection: cfg.ACTIVE.VIZ_MASK is set, but the visualisation plots of "
+                          "core/active/build.py:168-183 are not produced (scoring and masking are fused; "
+                          "plots are out of scope)", RuntimeWarning, stacklevel=3)
         if self.pur not in _lib.PUR:
             raise NotImplementedError("Error: purity type '{}' not implemented".format(self.pur))
         self.scorer._check_purity_channels(self.pur)
@@ -130,7 +138,7 @@ class AcquisitionParams:
 
 class _InFlight:
     """One image whose scoring + selection has been enqueued on the acquisition stream."""
-    __slots__ = ("amask", "active", "selected", "done", "path_mask", "path_indicator", "keep")
+    __slots__ = ("amask", "active", "selected", "done", "path_mask", "path_indicator", "keep", "picks", "npk")
 
 
 def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, stream):
@@ -147,7 +155,8 @@ def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active
         rec.selected = selected_cpu.to(dev, non_blocking=True).bool().contiguous()
         # the two F.interpolate(align_corners=True) calls of build.py:122-135 are fused into the scorer:
         # the C x H x W float64 embedding (4.3 GB at C=256) is never written or read
-        acquire_batch_lowres(logit_lr, embed_lr, size, gt[None], rec.active[None], rec.selected[None], rec.amask[None],
+        rec.picks, rec.npk = acquire_batch_lowres(
+                             logit_lr, embed_lr, size, gt[None], rec.active[None], rec.selected[None], rec.amask[None],
                              unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
                              n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
                              mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
@@ -164,8 +173,10 @@ def _persist(mask_np, active, selected, path_mask, path_indicator):
     torch.save({"active": active, "selected": selected}, path_indicator)
 
 
-def _retire(rec, writers, pending):
+def _retire(rec, writers, pending, tables=None):
     rec.done.synchronize()
+    if tables is not None:
+        tables.append((rec.picks[0], int(rec.npk[0])))
     # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
     # reference's cast-after-copy, build.py:67-68,162)
     job = (rec.amask.to(torch.uint8).cpu().numpy(), rec.active.cpu(), rec.selected.cpu(), rec.path_mask, rec.path_indicator)
@@ -173,10 +184,13 @@ def _retire(rec, writers, pending):
     pending.append(writers.submit(_persist, *job))
 
 
-def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=3, writer_threads=4):
+def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=3, writer_threads=4,
+                    return_tables=False):
     """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
     at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
-    every file on disk when the call returns.
+    every file on disk when the call returns.  Returns None like the reference, or -- keyword-only
+    `return_tables=True`, used by halo_amd.pool.region_selection_sharded -- the per-image pick tables
+    [(picks (n,3) float64 rows (h, w, score), count)] in loader order.
 
     Inside, image i's score + greedy selection runs on a side stream while the backbone processes
     image i+1, and PNG encoding / torch.save run on a small thread pool: in the reference
@@ -189,6 +203,7 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     classifier.eval()
     moved = False
     queue, pending = [], []
+    tables = [] if return_tables else None
     with ThreadPoolExecutor(max_workers=max(1, writer_threads)) as writers, torch.no_grad():
         for batch in tgt_epoch_loader:
             images = batch["img"].to(dev, non_blocking=True)
@@ -204,10 +219,11 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
                 rec.path_mask, rec.path_indicator = batch["path_to_mask"][i], batch["path_to_indicator"][i]
                 queue.append(rec)
                 while len(queue) > max(0, in_flight):      # in_flight=0: fully serial, like the reference
-                    _retire(queue.pop(0), writers, pending)
+                    _retire(queue.pop(0), writers, pending, tables)
         while queue:
-            _retire(queue.pop(0), writers, pending)
+            _retire(queue.pop(0), writers, pending, tables)
         for f in pending:
             f.result()                                           # surface I/O errors; all files are on disk
     feature_extractor.train()
     classifier.train()
+    return tables

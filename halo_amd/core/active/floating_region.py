@@ -119,12 +119,16 @@ def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, 
     need_feat = pur_type in ("hyper", "radius", "euc_norm")
     feat, Cc, fdt, fbs, hf, wf = None, 0, _lib.F64, 0, 0, 0
     if need_feat:
+        if decoder_lr is None:
+            raise ValueError("decoder_out is required for purity type '%s'" % pur_type)
         feat = decoder_lr if decoder_lr.dtype in (torch.float32, torch.float64) else decoder_lr.float()
         feat = feat.contiguous()
         assert feat.shape[0] == B
         Cc, hf, wf = feat.shape[1:]
         fdt, fbs = _lib.dtype_code(feat), feat.stride(0)
     need_gt = unc_type == "oracle_acc" or pur_type == "oracle_ripu"
+    if need_gt and ground_truth is None:
+        raise ValueError("ground_truth is required for '%s'/'%s'" % (unc_type, pur_type))
     gt = ground_truth.reshape(B, H, W).to(torch.int64).contiguous() if need_gt else None
     act = None
     if active is not None:

@@ -40,4 +40,8 @@ def use(other):
     from ..utils import hyperbolic  # noqa: F401
     floating_region.cfg = other
     build.cfg = other
+    import sys
+    heads = sys.modules.get(__name__.rsplit(".", 1)[0] + ".models.classifier")
+    if heads is not None:
+        heads.cfg = other
     return other

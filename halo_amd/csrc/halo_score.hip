@@ -758,11 +758,19 @@ static void launch_feat(const T *feat, long long bstride, int C, long long hw, i
 
 using namespace halo;
 
+static size_t partial_slots(int64_t H, int64_t W)
+{
+    const size_t a = (size_t)cdiv(H * W, FTPB), b = (size_t)(cdiv(W, LR_TW) * cdiv(H, LR_TH));
+    return a > b ? a : b;
+}
+
 extern "C" size_t halo_score_workspace_bytes(int64_t B, int64_t H, int64_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t n = (size_t)B * H * W;
-    const size_t nblk = (size_t)cdiv(H * W, FTPB);
+    // per-block min/max slots: one per FTPB pixels, or one per 64 x 16 tile of the low-res scorer (narrow maps
+    // such as 4096 x 4 have more tiles than 128-pixel blocks)
+    const size_t nblk = partial_slots(H, W);
     size_t s = 0;
     s += align_up(n * 4, 256);                   // ent
     s += align_up(n * 4, 256);                   // unc_raw
@@ -864,7 +872,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     float *unc_raw = ar.take<float>((size_t)B * hw);
     double *imp_raw = ar.take<double>((size_t)B * hw);
     short *pred = ar.take<short>((size_t)B * hw);
-    double *part_imp = ar.take<double>((size_t)B * cdiv(hw, FTPB) * 2);
+    double *part_imp = ar.take<double>((size_t)B * partial_slots(H, W) * 2);
     double *part_unc = ar.take<double>((size_t)B * nblk1 * 2);
     double *stats = ar.take<double>((size_t)B * 4);
     float *lr_logit_full = lr_generic_O ? ar.take<float>((size_t)B * O * hw) : nullptr;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 1
+#define HALO_ABI_VERSION 2
 
 enum { HALO_F32 = 0, HALO_F64 = 1 };
 

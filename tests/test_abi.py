@@ -30,7 +30,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in _declared_symbols():
         assert hasattr(h, s), "libhalo_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == _declared_symbols(), "ctypes table out of sync with include/halo_hip.h"
-    assert _lib.lib().halo_version() == 1
+    assert _lib.lib().halo_version() == _lib.ABI_VERSION
+    text = open(os.path.join(ROOT, "include", "halo_hip.h")).read()
+    assert "#define HALO_ABI_VERSION %d" % _lib.ABI_VERSION in text
 
 
 def test_workspace_queries_are_pure_host_functions():

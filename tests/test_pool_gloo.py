@@ -102,3 +102,149 @@ def test_two_ranks_equal_one_process(tmp_path, n_images):
     assert np.array_equal(keep, r0["keep"])
     kept = ref_t.numpy()[:, :, 2][keep]
     assert kept.min() >= np.sort(ref_t.numpy()[:, :, 2].reshape(-1))[-9]
+
+
+# ------------------------------------------------------------------ wire format and the sharded driver
+def test_wire_format_round_trips_bit_exactly():
+    from halo_amd.pool import pack_tables, unpack_tables
+    rng = np.random.default_rng(3)
+    b, n = 3, 7
+    picks = torch.zeros((b, n, 3), dtype=torch.float64)
+    picks[:, :, 0] = torch.from_numpy(rng.integers(0, 65536, (b, n)).astype(np.float64))      # h up to the selector's limit
+    picks[:, :, 1] = torch.from_numpy(rng.integers(0, 65536, (b, n)).astype(np.float64))
+    picks[:, :, 2] = torch.from_numpy(rng.standard_normal((b, n)))
+    picks[0, 0, 2] = float("nan"); picks[1, 1, 2] = -0.0; picks[2, 2, 2] = float("inf")
+    picks[0, 1, :2] = 65535.0
+    npk = torch.tensor([7, 0, 3], dtype=torch.int32)
+    wire = pack_tables(picks, npk, rows=5)
+    assert wire.dtype == torch.int32 and wire.shape == (5, 3 * n + 1)                           # 12 bytes per pick
+    t, c = unpack_tables(wire, n)
+    assert np.array_equal(t[:b].numpy().view(np.int64), picks.numpy().view(np.int64))           # bit patterns incl. NaN, -0
+    assert list(c) == [7, 0, 3, 0, 0] and float(t[3:].abs().sum()) == 0.0
+
+
+class _Pool(torch.utils.data.Dataset):
+    """Loader items shaped like core/datasets/cityscapes.py:274-286 (what RegionSelection consumes)."""
+
+    def __init__(self, root, n):
+        from oracle import halo_oracle as ho
+        self.items = []
+        for i in range(n):
+            rng = np.random.default_rng(500 + i)
+            H, W = (40, 64) if i % 2 else (48, 56)
+            emb = ho.expmap((rng.standard_normal((1, 6, 10, 16)) * 0.2).astype(np.float32), 1.0, dim=1)
+            logit = rng.standard_normal((1, 19, 12, 20)).astype(np.float32)
+            self.items.append({"img": torch.zeros(3, 8, 8), "path_to_mask": os.path.join(root, f"m{i}.png"),
+                               "origin_mask": torch.full((H, W), 255, dtype=torch.int64),
+                               "origin_label": torch.from_numpy(rng.integers(0, 19, (H, W)).astype(np.int64)),
+                               "size": torch.tensor([H, W]), "active": torch.from_numpy(rng.random((H, W)) < 0.02),
+                               "selected": torch.zeros(H, W, dtype=torch.bool),
+                               "path_to_indicator": os.path.join(root, f"i{i}.pth"), "name": f"img{i}",
+                               "logit_lr": torch.from_numpy(logit[0]), "embed_lr": torch.from_numpy(emb[0])})
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _cfg():
+    import types
+    return types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+
+
+def _oracle_driver(cfg, feature_extractor, classifier, loader, round_number):
+    """Stand-in for the HIP RegionSelection with the same contract (files written through the product's own
+    _persist; per-image pick tables returned): the CPU oracle does the arithmetic."""
+    from halo_amd.core.active.build import _persist
+    from oracle import halo_oracle as ho
+    tables = []
+    for batch in loader:
+        im = dict(logit_lr=batch["logit_lr"].numpy(), embed_lr=batch["embed_lr"].numpy(),
+                  origin_label=batch["origin_label"][0].numpy(), origin_mask=batch["origin_mask"][0].numpy(),
+                  active=batch["active"][0].numpy(), selected=batch["selected"][0].numpy())
+        (mask, act, sel, picks), = ho.region_selection(cfg, [im])
+        _persist(mask, torch.from_numpy(act), torch.from_numpy(sel), batch["path_to_mask"][0], batch["path_to_indicator"][0])
+        tables.append((torch.from_numpy(np.ascontiguousarray(picks)).reshape(-1, 3), len(picks)))
+    return tables
+
+
+def _sharded_worker(rank, world, port, n_images, root, n_regions):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from halo_amd.pool import region_selection_sharded
+    res = region_selection_sharded(_cfg(), None, None, _Pool(root, n_images), 1, driver=_oracle_driver,
+                                   loader_kwargs=dict(pin_memory=False), n_regions=n_regions)
+    np.savez(os.path.join(root, f"rank{rank}.npz"), tables=res["tables"].numpy(), counts=res["counts"].numpy(),
+             owner=res["owner"].numpy(), rng=np.array(res["range"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_regions", [None, 40])
+def test_region_selection_sharded_two_ranks_write_the_single_process_files(tmp_path, n_regions):
+    """SURVEY 8f N2 / 8e: every rank drives its block of the pool and writes its own mask / indicator files;
+    the union of the files and the all-gathered pick tables equal the single-process (reference order) run."""
+    from PIL import Image
+    from halo_amd.pool import region_selection_sharded
+    n_images = 5
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    ref = region_selection_sharded(_cfg(), None, None, _Pool(str(one), n_images), 1, driver=_oracle_driver,
+                                   loader_kwargs=dict(pin_memory=False), n_regions=n_regions)
+    assert ref["range"] == (0, n_images) and ref["keep"] is None
+    mp.spawn(_sharded_worker, args=(2, _free_port(), n_images, str(two), n_regions), nprocs=2, join=True)
+    for i in range(n_images):
+        a = np.array(Image.open(one / f"m{i}.png")); b = np.array(Image.open(two / f"m{i}.png"))
+        assert Image.open(two / f"m{i}.png").mode == "L" and np.array_equal(a, b), i
+        ia, ib = torch.load(one / f"i{i}.pth"), torch.load(two / f"i{i}.pth")
+        assert torch.equal(ia["active"], ib["active"]) and torch.equal(ia["selected"], ib["selected"]), i
+        assert ib["active"].dtype == torch.bool and int(ib["selected"].sum()) > 0
+    r0, r1 = np.load(two / "rank0.npz"), np.load(two / "rank1.npz")
+    assert list(r0["rng"]) == [0, 3] and list(r1["rng"]) == [3, 5]
+    for r in (r0, r1):
+        assert np.array_equal(r["tables"].view(np.int64), ref["tables"].numpy().view(np.int64))
+        assert np.array_equal(r["counts"], ref["counts"].numpy())
+        assert list(r["owner"]) == [0, 0, 0, 1, 1]
+    assert int(ref["counts"].min()) > 0
+
+
+class _FakeLearner:
+    """The attributes SourceFreeLearner.on_train_batch_start touches (core/train_learners.py:307-326)."""
+
+    def __init__(self, root, rank, n_images):
+        import types
+        self.cfg = _cfg()
+        self.cfg.SAVE_DIR = root
+        self.local_rank, self.debug, self.active_iters, self.active_round = rank, False, [0, 7], 0
+        self.feature_extractor = self.classifier = None
+        self.active_loader = torch.utils.data.DataLoader(_Pool(root, n_images), batch_size=1)
+        self.saved, self.logged = [], []
+        self.trainer = types.SimpleNamespace(save_checkpoint=self.saved.append)
+        self.acquisition_driver = _oracle_driver
+
+    def log(self, *a, **k):
+        self.logged.append(a)
+
+
+def test_sharded_hook_replaces_the_rank0_gate(tmp_path):
+    from halo_amd.hooks import sharded_on_train_batch_start, use_sharded_rounds
+    cls = use_sharded_rounds(type("L", (_FakeLearner,), {"on_train_batch_start": lambda self, b, i: (b, i)}))
+    assert cls.on_train_batch_start is sharded_on_train_batch_start and cls._reference_on_train_batch_start is not None
+    ln = cls(str(tmp_path), 0, 3)
+    assert ln.on_train_batch_start("batch", 3) == ("batch", 3) and ln.active_round == 0 and not ln.saved     # not an active iteration
+    assert ln.on_train_batch_start("batch", 7) == ("batch", 7)
+    assert ln.active_round == 1 and ln.saved == [os.path.join(str(tmp_path), "model_before_round_0.ckpt")]
+    assert ln.logged and ln.last_round_tables["tables"].shape[0] == 3
+    assert all(os.path.exists(tmp_path / f"m{i}.png") and os.path.exists(tmp_path / f"i{i}.pth") for i in range(3))
+    ln.debug = True
+    ln.on_train_batch_start("batch", 0)
+    assert ln.active_round == 1
