@@ -14,6 +14,7 @@ UNC = {"entropy": 0, "pixel_entropy": 1, "oracle_acc": 2}          # everything 
 UNC_ZEROS = 3
 PUR = {"ripu": 0, "oracle_ripu": 1, "hyper": 2, "none": 3, "radius": 4, "euc_norm": 5}
 E_UNSUPPORTED = -2
+SELECT = {"auto": 0, "serial": 1, "binned": 2}                      # HALO_SELECT_* of include/halo_hip.h
 
 _i64, _dbl, _int, _vp, _sz = C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_size_t
 
@@ -51,9 +52,9 @@ SIGNATURES = {
     "halo_event_record": (_int, [_vp, _vp]),
     "halo_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "halo_event_destroy": (_int, [_vp]),
-    "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "halo_greedy_select": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
-                                  _vp, _sz, _vp]),
+                                  _vp, _sz, _int, _vp]),
 }
 
 # must equal HALO_ABI_VERSION of include/halo_hip.h; bumped whenever an exported signature changes, so a stale

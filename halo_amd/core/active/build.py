@@ -7,6 +7,7 @@ on-disk side effects (uint8 mode-L PNG mask + torch.save'd {'active','selected'}
 build.py:162-166) and batches images through the fused score -> mask -> select pipeline.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -19,10 +20,12 @@ from .floating_region import FloatingRegionScore, score_maps, score_maps_lowres,
 
 
 def greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth,
-                  return_picks=True):
+                  return_picks=True, method=None):
     """Batched device-side selection.  score (B,H,W) f32|f64, active/selected (B,H,W) bool,
     active_mask/ground_truth (B,H,W) int64 -- all on one ROCm device, all mutated in place.
-    Returns (picks (B,n,3) float64 rows (h, w, value), n_picked (B,) int32) or None."""
+    Returns (picks (B,n,3) float64 rows (h, w, value), n_picked (B,) int32) or None.
+    method: "auto" (default; environment HALO_SELECT overrides) = value-binned sweep with the serial kernel
+    behind it, "serial" = the tile-table kernel only, "binned" = the sweep or HaloUnsupported.  Same results."""
     dev = _lib.require_device(score, active, selected, active_mask, ground_truth)
     B, H, W = score.shape
     for t in (score, active, selected, active_mask, ground_truth):
@@ -37,12 +40,13 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     if n == 0 or B == 0:
         return (picks[:, :0], n_picked) if return_picks else None
     L = _lib.lib()
-    nws = L.halo_select_workspace_bytes(B, H, W)
+    method = _lib.SELECT[method or os.environ.get("HALO_SELECT", "auto")]
+    nws = L.halo_select_workspace_bytes(B, H, W, n, int(mask_radius)) if method != _lib.SELECT["serial"] else 256
     ws = _workspace(dev, nws, "select")
     rc = L.halo_greedy_select(_lib.ptr(score), _lib.dtype_code(score), B, H, W, n, int(active_radius),
                               int(mask_radius), _lib.ptr(active), _lib.ptr(selected), _lib.ptr(active_mask),
                               _lib.ptr(ground_truth), _lib.ptr(picks), _lib.ptr(n_picked), _lib.ptr(ws), ws.numel(),
-                              _lib.stream_ptr(dev))
+                              method, _lib.stream_ptr(dev))
     _lib.check(rc, "halo_greedy_select")
     return (picks, n_picked) if return_picks else None
 

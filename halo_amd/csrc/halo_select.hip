@@ -14,72 +14,12 @@
 // `torch.max(score, dim=0)` / `torch.max(values, dim=0)` produces (first occurrence wins).
 // Values are compared as 64-bit ordered integers, so the picks are bit-exact functions of
 // the score map for both float32 and float64 maps.
-#include "halo_common.hpp"
+#include "halo_select_common.hpp"
 
 namespace halo {
 
 constexpr int SEL_TPB = 512;
 constexpr int SEL_WAVES = SEL_TPB / 64;
-constexpr unsigned long long KEY_NAN = 0xffffffffffffffffull;
-constexpr unsigned long long KEY_NEG_INF = 0x000fffffffffffffull;   // ~bits(-inf)
-
-__device__ __forceinline__ unsigned long long order_key(double v)
-{
-    const bool isnan = v != v;
-    v = v == 0.0 ? 0.0 : v;                                 // -0 ties with +0 in torch.max
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const unsigned long long k = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-    return isnan ? KEY_NAN : k;
-}
-__device__ __forceinline__ double key_value(unsigned long long k)
-{
-    if (k == KEY_NAN) return __longlong_as_double(0x7ff8000000000000ll);
-    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)u);
-}
-
-struct Cand { unsigned long long key; unsigned pos; };     // pos = (w << 16) | h  (smaller wins a tie: min w, then min h)
-
-__device__ __forceinline__ bool better(const Cand &a, const Cand &b)
-{
-    return a.key > b.key || (a.key == b.key && a.pos < b.pos);
-}
-// Wave-wide unsigned max via DPP row shifts / row broadcasts (no LDS crossbar traffic): 6 dependent
-// VALU+DPP steps instead of 6 ds_bpermute round trips.  Result is wave-uniform (read from lane 63).
-__device__ __forceinline__ unsigned wave_umax(unsigned x)
-{
-#define HALO_DPP_MAX(ctrl, rmask)                                                                    \
-    {                                                                                                \
-        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, true); \
-        x = o > x ? o : x;                                                                           \
-    }
-    HALO_DPP_MAX(0x111, 0xf)   // row_shr:1
-    HALO_DPP_MAX(0x112, 0xf)   // row_shr:2
-    HALO_DPP_MAX(0x114, 0xf)   // row_shr:4
-    HALO_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds its row's max
-    HALO_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
-    HALO_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
-#undef HALO_DPP_MAX
-    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-}
-
-// arg-max over a wave under `better`: high word, low word, then the smallest position among ties
-__device__ __forceinline__ Cand wave_best(Cand c)
-{
-    const unsigned hi = (unsigned)(c.key >> 32), lo = (unsigned)c.key;
-    const unsigned mh = wave_umax(hi);
-    const unsigned ml = wave_umax(hi == mh ? lo : 0u);
-    const bool tie = hi == mh && lo == ml;
-    const unsigned mp = ~wave_umax(tie ? ~c.pos : 0u);
-    Cand r;
-    r.key = ((unsigned long long)mh << 32) | ml;
-    r.pos = mp;
-    return r;
-}
-
-// LDS-only barrier: orders LDS traffic between the waves of the workgroup without draining the
-// vector-memory counter (a __syncthreads() would wait for the writer wave's window stores).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct SelGeom { int H, W, th_shift, tw_shift, nty, ntx, nt; };
 
@@ -130,8 +70,15 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
                                                            unsigned char *__restrict__ selected,
                                                            long long *__restrict__ active_mask,
                                                            const long long *__restrict__ gt, double *__restrict__ picks,
-                                                           int *__restrict__ n_picked)
+                                                           int *__restrict__ n_picked, const SelHdr *__restrict__ resume)
 {
+    // Behind the binned selector (halo_select_binned.hip): images it finished are skipped, images it handed
+    // over continue from pick `np` on the map as the reference would have it after those picks.
+    int np0 = 0;
+    if (resume) {
+        if (resume[blockIdx.x].status == SEL_DONE) return;
+        np0 = resume[blockIdx.x].np;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *tkey = reinterpret_cast<unsigned long long *>(smem);
     unsigned *tpos = reinterpret_cast<unsigned *>(smem + (size_t)g.nt * 8);
@@ -187,10 +134,10 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
     // writer wave drains them at the start of the NEXT step's phase B (they had a whole step to
     // land), and tile re-reductions mask the current AND the previous window analytically, so a
     // tile load never depends on a store younger than two steps (memory-model argument in DESIGN.md).
-    int np = 0;
+    int np = np0;
     int py0 = 1, py1 = 0, px0 = 1, px1 = 0;                              // previous window (empty)
     const T neg_inf = sizeof(T) == 8 ? (T)__longlong_as_double(0xfff0000000000000ll) : (T)__uint_as_float(0xff800000u);
-    for (int it = 0; it < n_regions; ++it) {
+    for (int it = np0; it < n_regions; ++it) {
         // ---- [A] workgroup argmax
         const Cand wb = wave_best(mine);
         const int par = (it & 1) * SEL_WAVES;
@@ -286,49 +233,94 @@ static SelGeom make_geom(int64_t H, int64_t W)
     return g;
 }
 
-extern "C" size_t halo_select_workspace_bytes(int64_t B, int64_t H, int64_t W)
+#include "halo_select_plan.hpp"
+
+static bool serial_supported(int64_t H, int64_t W)
 {
-    (void)B; (void)H; (void)W;
-    return 256;   // the tile table lives in LDS; nothing is needed in HBM today
+    if (H > 65535 || W > 65535) return false;
+    const SelGeom g = make_geom(H, W);
+    return (size_t)g.nt * 12 <= 96 * 1024;
+}
+
+extern "C" size_t halo_select_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t mask_radius)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (n_regions > H * W) n_regions = H * W;
+    const BinPlan p = binned_plan(B, H, W, n_regions, 0, mask_radius);
+    return p.ok ? p.total_bytes + 256 : 256;
+}
+
+template <typename T, int A, int B_, int EPT>
+static int launch_serial(const SelGeom &g, size_t lds, dim3 grid, hipStream_t st, void *score, int n_regions, int arad, int mrad,
+                         uint8_t *active, uint8_t *selected, int64_t *active_mask, const int64_t *gt, double *picks,
+                         int32_t *n_picked, const SelHdr *resume)
+{
+    static bool attr_set = false;       // per instantiation: tile tables above 64 KiB need the dynamic-LDS limit raised
+    if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void *)k_greedy_select<T, A, B_, EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_greedy_select<T, A, B_, EPT>), grid, dim3(SEL_TPB), lds, st, (T *)score, g, n_regions, arad, mrad, active,
+                       selected, (long long *)active_mask, (const long long *)gt, picks, n_picked, resume);
+    return HALO_OK;
 }
 
 extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,
                                   int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
                                   int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
-                                  void *workspace, size_t workspace_bytes, void *stream)
+                                  void *workspace, size_t workspace_bytes, int method, void *stream)
 {
-    (void)workspace; (void)workspace_bytes;
     hipStream_t st = (hipStream_t)stream;
     if (!score || !active || !selected || !active_mask || !gt || B <= 0 || H <= 0 || W <= 0)
         return fail(HALO_E_ARG, "halo_greedy_select: null/empty argument");
     if (dtype != HALO_F32 && dtype != HALO_F64) return fail(HALO_E_ARG, "halo_greedy_select: bad dtype");
     if (n_regions < 0 || active_radius < 0 || mask_radius < 0) return fail(HALO_E_ARG, "halo_greedy_select: negative parameter");
+    if (method < HALO_SELECT_AUTO || method > HALO_SELECT_BINNED) return fail(HALO_E_ARG, "halo_greedy_select: bad method");
     if (H > 65535 || W > 65535) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image side above 65535");
-    if (n_regions > 0x7fffffff) n_regions = 0x7fffffff;
-    const SelGeom g = make_geom(H, W);
-    if ((size_t)g.nt * 12 > 96 * 1024) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image too large for the tile table");
-    const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * SEL_WAVES * 12 + 64;
-    dim3 grid((unsigned)B), block(SEL_TPB);
-#define HALO_SEL_LAUNCH(T, A, B_)                                                                                               \
-    {                                                                                                                           \
-        if (g.nt <= 8 * SEL_TPB)                                                                                                \
-            hipLaunchKernelGGL((k_greedy_select<T, A, B_, 8>), grid, block, lds, st, (T *)score, g, (int)n_regions,             \
-                               (int)active_radius, (int)mask_radius, active, selected, (long long *)active_mask,               \
-                               (const long long *)gt, picks, n_picked);                                                        \
-        else                                                                                                                    \
-            hipLaunchKernelGGL((k_greedy_select<T, A, B_, 16>), grid, block, lds, st, (T *)score, g, (int)n_regions,            \
-                               (int)active_radius, (int)mask_radius, active, selected, (long long *)active_mask,               \
-                               (const long long *)gt, picks, n_picked);                                                        \
+    if (n_regions > H * W) n_regions = H * W;            // there are no more pixels than that to pick
+    if (n_regions == 0) {
+        if (n_picked && hipMemsetAsync(n_picked, 0, (size_t)B * 4, st) != hipSuccess) return fail(HALO_E_LAUNCH, "halo_greedy_select: memset failed");
+        return HALO_OK;
     }
+    if (!serial_supported(H, W)) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image too large for the tile table");
+    const SelGeom g = make_geom(H, W);
+
+    // ---- the binned sweep first (unless the serial kernel was asked for or the pick grid does not fit LDS)
+    const SelHdr *resume = nullptr;
+    if (method != HALO_SELECT_SERIAL) {
+        const BinPlan p = binned_plan(B, H, W, n_regions, active_radius, mask_radius);
+        if (p.ok) {
+            SelHdr *hdr = nullptr;
+            const int rc = binned_select(score, dtype, B, p, active, selected, active_mask, gt, picks, n_picked, workspace,
+                                         workspace_bytes, st, &hdr);
+            if (rc != HALO_OK) return rc;
+            resume = hdr;
+        } else if (method == HALO_SELECT_BINNED)
+            return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: the binned selector does not serve this geometry "
+                                            "(mask radius above 14 or pick grid larger than LDS)");
+    }
+
+    // ---- serial tile-table kernel: the whole job, or only the images the sweep handed over
+    const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * SEL_WAVES * 12 + 64;
+    dim3 grid((unsigned)B);
+    int rc = HALO_OK;
+#define HALO_SEL_LAUNCH(T, A, B_)                                                                                                \
+    rc = g.nt <= 8 * SEL_TPB                                                                                                     \
+             ? launch_serial<T, A, B_, 8>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius, active,    \
+                                          selected, active_mask, gt, picks, n_picked, resume)                                   \
+             : launch_serial<T, A, B_, 16>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius, active,   \
+                                           selected, active_mask, gt, picks, n_picked, resume);
     if (dtype == HALO_F64) {
-        if (g.th_shift == 4) HALO_SEL_LAUNCH(double, 4, 5)
-        else if (g.th_shift == 5) HALO_SEL_LAUNCH(double, 5, 6)
-        else HALO_SEL_LAUNCH(double, 6, 7)
+        if (g.th_shift == 4) { HALO_SEL_LAUNCH(double, 4, 5) }
+        else if (g.th_shift == 5) { HALO_SEL_LAUNCH(double, 5, 6) }
+        else { HALO_SEL_LAUNCH(double, 6, 7) }
     } else {
-        if (g.th_shift == 4) HALO_SEL_LAUNCH(float, 4, 5)
-        else if (g.th_shift == 5) HALO_SEL_LAUNCH(float, 5, 6)
-        else HALO_SEL_LAUNCH(float, 6, 7)
+        if (g.th_shift == 4) { HALO_SEL_LAUNCH(float, 4, 5) }
+        else if (g.th_shift == 5) { HALO_SEL_LAUNCH(float, 5, 6) }
+        else { HALO_SEL_LAUNCH(float, 6, 7) }
     }
 #undef HALO_SEL_LAUNCH
+    if (rc != HALO_OK) return rc;
     return check_launch("halo_greedy_select");
 }

@@ -1,0 +1,617 @@
+// select_pixels_to_label (core/active/build.py:27-64) without the per-pick memory round trip:
+// the value-binned sweep.
+//
+// The reference picks, n times, the global arg-max of the score map and suppresses a
+// (2*mask_radius+1)^2 window around it.  That sequence is the prefix, in priority order, of the
+// lexicographically-first maximal independent set of the "within one window" relation: a pixel is
+// picked iff no pixel of HIGHER priority that was itself picked lies within its window.  Whether a
+// pixel is picked therefore depends only on higher-priority pixels, so the picks can be found by
+// visiting pixels in descending priority and testing each against the picks made so far -- no
+// arg-max over the map, no dependent HBM access per pick.  Two facts bound the work:
+//   * the n-th pick has at most (n-1)*(2r+1)^2 pixels above it (each one is a pick or inside the
+//     window of an earlier pick), so only the top K = n*(2r+1)^2 values are ever visited;
+//   * two picks are more than r apart (Chebyshev), so a cell of (r+1)^2 pixels holds at most one:
+//     "the picks so far" is a byte per cell in LDS and a test reads the 3 x 3 cells around a pixel.
+//
+// Pipeline (all asynchronous on one stream, no host synchronisation):
+//   k_sel_range    min / max of the finite values, count of pickable pixels
+//   k_sel_hist1    2048 equal-width coarse bins over [min, max]                      (LDS histograms)
+//   k_sel_scan1    threshold bin t1 (top-K), every coarse bin split into count/target equal sub-bins
+//   k_sel_compact  pixels >= t1 -> staging list (key, pos, fine bin) + fine-bin histogram
+//   k_sel_scan2    fine-bin offsets
+//   k_sel_scatter  staging list -> candidates grouped by fine bin, bins in descending value order
+//   k_sel_sweep    ONE workgroup per image walks the bins: filter a bin's candidates against the
+//                  pick grid (4 waves, one candidate per lane), then wave 0 takes the survivors
+//                  in exact (value, w, h) order with a register-resident arg-max loop
+//   k_sel_apply    one wave per pick writes its windows (score = -inf, active, selected, active_mask)
+// Order inside a bin never matters (the resolve step is an exact arg-max over the bin's survivors),
+// bins are monotone in the value, so the result is the reference's sequence bit for bit.
+//
+// The sweep gives up ("bail") where its assumptions do not hold -- NaN or +inf in the map, a
+// constant map, a bin with more than 256 unsuppressed candidates (plateaus of exact ties), or
+// candidates exhausted after the threshold bin had to be dropped -- and leaves the image, in the
+// exact state the reference would have after `np` picks, to the serial kernel of halo_select.hip,
+// which is enqueued behind it and returns immediately for images that are done.
+#include <stdlib.h>
+#include <string.h>
+
+#include "halo_select_plan.hpp"
+
+namespace halo {
+
+constexpr int NB1 = 2048;        // coarse bins
+constexpr int SW_TPB = 256;      // sweep workgroup: 4 waves, one per SIMD
+constexpr int SW_SURV = 256;     // survivor capacity of one bin (4 per lane of the resolving wave)
+constexpr int FWIN = 1024;       // fine-bin offsets staged in LDS at a time
+
+// per-image arrays: element [b * stride + i]
+struct BinWs {
+    SelHdr *hdr;
+    unsigned *hist1, *cbase, *cm;            // NB1 each
+    unsigned *fhist, *fcur;                  // nfmax each
+    unsigned *foff;                          // nfmax + 1
+    uint4 *tmp;                              // captot: (key lo, key hi, pos, fine bin)
+    unsigned long long *ckey;                // captot
+    unsigned *cpos;                          // captot
+    unsigned *plist;                         // n_regions: picks as (w << 16) | h
+};
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+struct ValRange { double lo, scale; bool ok; };
+
+__device__ __forceinline__ ValRange sel_range(const SelHdr &h)
+{
+    ValRange r;
+    const double lo = key_value(~h.kmin_inv), hi = key_value(h.kmax);
+    r.lo = lo;
+    r.scale = (double)NB1 / (hi - lo);
+    r.ok = !(h.flags & SEL_F_BAD) && h.nvalid > 0 && hi > lo && r.scale > 0.0 && r.scale < 1.0e300;
+    return r;
+}
+
+// coarse bin of a finite value v >= lo; t = position in bin units (monotone in v)
+__device__ __forceinline__ int coarse_bin(double v, const ValRange &r, double &t)
+{
+    t = (v - r.lo) * r.scale;
+    const int j = (int)t;
+    return j > NB1 - 1 ? NB1 - 1 : j;
+}
+
+// ------------------------------------------------------------------ value range
+template <typename T>
+__global__ void __launch_bounds__(256) k_sel_range(const T *__restrict__ score, long long hw, BinWs ws)
+{
+    const int b = blockIdx.y;
+    const T *sc = score + (size_t)b * hw;
+    unsigned long long kmin_inv = 0, kmax = 0;
+    unsigned nval = 0, bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long long)gridDim.x * 256) {
+        const unsigned long long k = order_key((double)sc[i]);
+        const bool isbad = k >= KEY_POS_INF;                         // +inf or NaN
+        const bool ok = !isbad && k != KEY_NEG_INF;
+        bad |= isbad ? 1u : 0u;
+        nval += ok ? 1u : 0u;
+        const unsigned long long ki = ok ? ~k : 0ull, kx = ok ? k : 0ull;
+        kmin_inv = ki > kmin_inv ? ki : kmin_inv;
+        kmax = kx > kmax ? kx : kmax;
+    }
+    kmin_inv = wave_max_u64(kmin_inv);
+    kmax = wave_max_u64(kmax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nval += __shfl_xor(nval, o, 64); bad |= __shfl_xor(bad, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        SelHdr *h = ws.hdr + b;
+        if (nval) {
+            atomicMax(&h->kmin_inv, kmin_inv);
+            atomicMax(&h->kmax, kmax);
+            atomicAdd(&h->nvalid, nval);
+        }
+        if (bad) atomicOr(&h->flags, (unsigned)SEL_F_BAD);
+    }
+}
+
+// ------------------------------------------------------------------ coarse histogram
+template <typename T>
+__global__ void __launch_bounds__(256) k_sel_hist1(const T *__restrict__ score, long long hw, BinWs ws)
+{
+    __shared__ unsigned h[NB1];
+    const int b = blockIdx.y;
+    const ValRange r = sel_range(ws.hdr[b]);
+    if (!r.ok) return;
+    for (int j = threadIdx.x; j < NB1; j += 256) h[j] = 0;
+    __syncthreads();
+    const T *sc = score + (size_t)b * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long long)gridDim.x * 256) {
+        const double v = (double)sc[i];
+        const unsigned long long k = order_key(v);
+        if (k < KEY_POS_INF && k != KEY_NEG_INF) {
+            double t;
+            atomicAdd(&h[coarse_bin(v, r, t)], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned *g = ws.hist1 + (size_t)b * NB1;
+    for (int j = threadIdx.x; j < NB1; j += 256)
+        if (h[j]) atomicAdd(&g[j], h[j]);
+}
+
+// ------------------------------------------------------------------ threshold + sub-bin layout
+// One workgroup per image.  S[j] = number of values in coarse bins >= j.  t1 = the highest bin with
+// S[t1] >= kneed (0 if even S[0] is smaller: every pickable pixel is a candidate).  If S[t1] exceeds
+// the staging capacity the threshold bin is dropped (t1 + 1, `truncated`).  Coarse bin j is split into
+// m[j] = ceil(count / target) equal-width sub-bins; fine bins are numbered from the TOP of the value
+// range downwards, cbase[j] = sum of m over the bins above j.
+__global__ void __launch_bounds__(256) k_sel_scan1(BinWs ws, BinGeom g)
+{
+    __shared__ unsigned sc_c[256], sc_m[256], s_t1;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    SelHdr *hdr = ws.hdr + b;
+    const ValRange r = sel_range(*hdr);
+    const unsigned *hist = ws.hist1 + (size_t)b * NB1;
+    unsigned c[8], m[8], tc = 0, tm = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c[i] = r.ok ? hist[tid * 8 + i] : 0u;
+        m[i] = (c[i] + g.target - 1) / g.target;
+        tc += c[i];
+        tm += m[i];
+    }
+    sc_c[tid] = tc;
+    sc_m[tid] = tm;
+    if (tid == 0) s_t1 = 0;
+    __syncthreads();
+    // inclusive suffix scan over the 256 per-thread totals (Hillis-Steele)
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned ac = tid + d < 256 ? sc_c[tid + d] : 0u, am = tid + d < 256 ? sc_m[tid + d] : 0u;
+        __syncthreads();
+        sc_c[tid] += ac;
+        sc_m[tid] += am;
+        __syncthreads();
+    }
+    unsigned above_c = tid + 1 < 256 ? sc_c[tid + 1] : 0u, above_m = tid + 1 < 256 ? sc_m[tid + 1] : 0u;
+    unsigned S[8], M[8];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        M[i] = above_m;                      // fine bins above coarse bin j
+        above_c += c[i];
+        above_m += m[i];
+        S[i] = above_c;                      // values in bins >= j
+    }
+    int mine = -1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (S[i] >= g.kneed) mine = tid * 8 + i;
+    if (mine > 0) atomicMax(&s_t1, (unsigned)mine);
+    unsigned *cb = ws.cbase + (size_t)b * NB1, *cmm = ws.cm + (size_t)b * NB1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { cb[tid * 8 + i] = M[i]; cmm[tid * 8 + i] = m[i]; }
+    __syncthreads();
+    unsigned t1 = s_t1;
+    // the thread owning bin t1 decides about truncation and publishes the layout
+    if ((int)(t1 >> 3) == tid) {
+        const int i = t1 & 7;
+        unsigned trunc = 0, nf;
+        unsigned s_here = 0, m_here = 0, M_here = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q == i) { s_here = S[q]; m_here = m[q]; M_here = M[q]; }
+        if (!r.ok) { t1 = NB1; trunc = 1; nf = 0; }
+        else if (s_here > g.captot) { t1 += 1; trunc = 1; nf = M_here; }
+        else nf = M_here + m_here;
+        hdr->t1 = t1;
+        hdr->truncated = trunc;
+        hdr->nf = nf;
+    }
+}
+
+// ------------------------------------------------------------------ candidates -> staging list
+template <typename T>
+__global__ void __launch_bounds__(256) k_sel_compact(const T *__restrict__ score, BinWs ws, BinGeom g)
+{
+    __shared__ unsigned s_base[NB1], s_m[NB1];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    SelHdr *hdr = ws.hdr + b;
+    const ValRange r = sel_range(*hdr);
+    const unsigned t1 = hdr->t1;
+    if (!r.ok || t1 >= NB1) return;
+    for (int j = tid; j < NB1; j += 256) { s_base[j] = ws.cbase[(size_t)b * NB1 + j]; s_m[j] = ws.cm[(size_t)b * NB1 + j]; }
+    __syncthreads();
+    const T *sc = score + (size_t)b * g.H * g.W;
+    unsigned *fhist = ws.fhist + (size_t)b * g.nfmax;
+    uint4 *tmp = ws.tmp + (size_t)b * g.captot;
+    for (int y = blockIdx.x; y < g.H; y += gridDim.x)
+        for (int x0 = 0; x0 < g.W; x0 += 256) {
+            const int x = x0 + tid;
+            const bool in = x < g.W;
+            const double v = in ? (double)sc[(size_t)y * g.W + x] : 0.0;
+            const unsigned long long k = order_key(v);
+            bool cand = in && k < KEY_POS_INF && k != KEY_NEG_INF;
+            double t = 0.0;
+            const int j = cand ? coarse_bin(v, r, t) : 0;
+            cand = cand && (unsigned)j >= t1;
+            unsigned f = 0;
+            if (cand) {
+                const unsigned mj = s_m[j];
+                unsigned s = (unsigned)((t - (double)j) * (double)mj);       // sub-bin inside the coarse bin, monotone in v
+                s = s > mj - 1 ? mj - 1 : s;
+                f = s_base[j] + (mj - 1 - s);
+                atomicAdd(&fhist[f], 1u);
+            }
+            const unsigned long long mask = __ballot(cand);
+            if (mask) {
+                unsigned base = 0;
+                if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(&hdr->ncand, (unsigned)__builtin_popcountll(mask));
+                base = __shfl(base, (int)__builtin_ctzll(mask), 64);
+                if (cand) {
+                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < g.captot) tmp[slot] = make_uint4((unsigned)k, (unsigned)(k >> 32), ((unsigned)x << 16) | (unsigned)y, f);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------ fine-bin offsets
+__global__ void __launch_bounds__(256) k_sel_scan2(BinWs ws, BinGeom g)
+{
+    __shared__ unsigned part[256], carry;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const unsigned nf = ws.hdr[b].nf;
+    const unsigned *fhist = ws.fhist + (size_t)b * g.nfmax;
+    unsigned *foff = ws.foff + (size_t)b * (g.nfmax + 1);
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < nf; base += 2048) {
+        unsigned v[8], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned idx = base + tid * 8 + i;
+            v[i] = idx < nf ? fhist[idx] : 0u;
+            tot += v[i];
+        }
+        part[tid] = tot;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {                       // inclusive prefix scan
+            const unsigned a = tid >= d ? part[tid - d] : 0u;
+            __syncthreads();
+            part[tid] += a;
+            __syncthreads();
+        }
+        unsigned run = carry + (tid ? part[tid - 1] : 0u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned idx = base + tid * 8 + i;
+            if (idx < nf) foff[idx] = run;
+            run += v[i];
+        }
+        __syncthreads();
+        if (tid == 255) carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) foff[nf] = carry;
+}
+
+// ------------------------------------------------------------------ staging list -> bins
+__global__ void __launch_bounds__(256) k_sel_scatter(BinWs ws, BinGeom g)
+{
+    const int b = blockIdx.y;
+    const unsigned n = ws.hdr[b].ncand < g.captot ? ws.hdr[b].ncand : g.captot;
+    const uint4 *tmp = ws.tmp + (size_t)b * g.captot;
+    const unsigned *foff = ws.foff + (size_t)b * (g.nfmax + 1);
+    unsigned *fcur = ws.fcur + (size_t)b * g.nfmax;
+    unsigned long long *ckey = ws.ckey + (size_t)b * g.captot;
+    unsigned *cpos = ws.cpos + (size_t)b * g.captot;
+    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const uint4 c = tmp[e];
+        const unsigned slot = foff[c.w] + atomicAdd(&fcur[c.w], 1u);
+        ckey[slot] = ((unsigned long long)c.y << 32) | c.x;
+        cpos[slot] = c.z;
+    }
+}
+
+// ------------------------------------------------------------------ the sweep
+__global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, double *__restrict__ picks, int *__restrict__ n_picked)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *grid = smem;                                               // pick grid, one byte per cell (+ border)
+    unsigned *gridw = reinterpret_cast<unsigned *>(smem);
+    unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem + g.grid_bytes);
+    unsigned *spos = reinterpret_cast<unsigned *>(skey + SW_SURV);
+    unsigned *fwin = spos + SW_SURV;                                          // FWIN + 1 offsets
+    unsigned *ctl = fwin + FWIN + 1;                                          // [0] survivors, [1] state after a resolve
+
+    __builtin_amdgcn_s_setprio(3);     // a short serial chain beside bandwidth-bound kernels: issue ahead of them
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SelHdr *hdr = ws.hdr + b;
+    const unsigned nf = hdr->nf;
+    const bool truncated = hdr->truncated != 0;
+    const unsigned *foff = ws.foff + (size_t)b * (g.nfmax + 1);
+    const unsigned long long *ckey = ws.ckey + (size_t)b * g.captot;
+    const unsigned *cpos = ws.cpos + (size_t)b * g.captot;
+    unsigned *plist = ws.plist + (size_t)b * g.n_regions;
+
+    for (unsigned i = tid * 16; i < g.grid_bytes; i += SW_TPB * 16) *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+    const unsigned ntot = nf ? foff[nf] : 0u;
+    __syncthreads();
+
+    int np = 0;                                  // maintained by wave 0
+    int fin = 0;                                 // 0 running, 1 done, 2 bail
+    unsigned fw0 = 0, fwn = 0;                   // fwin holds foff[fw0 .. fw0 + fwn]
+    // prefetched candidate of position `ppos + tid`
+    unsigned ppos = 0;
+    unsigned long long nkey = tid < ntot ? ckey[tid] : 0ull;
+    unsigned npos = tid < ntot ? cpos[tid] : 0u;
+    const int r = g.mrad, cs = g.cs;
+
+    for (unsigned f = 0; f < nf && !fin; ++f) {
+        if (f + 1 > fw0 + fwn || fwn == 0) {     // stage the next window of bin offsets
+            lds_barrier();
+            fw0 = f;
+            fwn = nf - f < (unsigned)FWIN ? nf - f : (unsigned)FWIN;
+            for (unsigned i = tid; i <= fwn; i += SW_TPB) fwin[i] = foff[fw0 + i];
+            __syncthreads();
+        }
+        const unsigned lo = fwin[f - fw0], hi = fwin[f - fw0 + 1];
+        if (hi == lo) continue;
+        // ---- filter the bin's candidates against the pick grid, survivors -> LDS list
+        for (unsigned cs0 = lo; cs0 < hi; cs0 += SW_TPB) {
+            const unsigned cnt = hi - cs0 < (unsigned)SW_TPB ? hi - cs0 : (unsigned)SW_TPB;
+            unsigned long long key;
+            unsigned pos;
+            if (ppos == cs0) { key = nkey; pos = npos; }
+            else {                                // (first chunk after a skipped prefetch position; not the steady state)
+                key = cs0 + tid < ntot ? ckey[cs0 + tid] : 0ull;
+                pos = cs0 + tid < ntot ? cpos[cs0 + tid] : 0u;
+            }
+            ppos = cs0 + cnt;                     // the next chunk starts where this one ends
+            nkey = ppos + tid < ntot ? ckey[ppos + tid] : 0ull;
+            npos = ppos + tid < ntot ? cpos[ppos + tid] : 0u;
+
+            const int x = (int)(pos >> 16), y = (int)(pos & 0xffffu);
+            const int cx = (int)__umulhi((unsigned)x, g.cmul), cy = (int)__umulhi((unsigned)y, g.cmul);
+            const int lx = x - cx * cs, ly = y - cy * cs;
+            bool alive = (unsigned)tid < cnt;
+            const int cell0 = cy * g.gstride + cx;                           // padded address of cell (cy-1, cx-1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int addr = cell0 + a * g.gstride;
+                const unsigned w0 = gridw[addr >> 2], w1 = gridw[(addr >> 2) + 1];
+                const unsigned win = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(addr & 3) * 8u);
+                const int oy = (a - 1) * cs - ly + r;                        // ddy + r = oy + dy
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const unsigned c = (win >> (8 * bb)) & 0xffu;
+                    const unsigned q = c - 1u;
+                    const int ddy = oy + (int)(q >> 4), ddx = (bb - 1) * cs - lx + r + (int)(q & 15u);
+                    const bool hit = c != 0u && (unsigned)ddy <= (unsigned)(2 * r) && (unsigned)ddx <= (unsigned)(2 * r);
+                    alive = alive && !hit;
+                }
+            }
+            const unsigned long long mask = __ballot(alive);
+            if (mask) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&ctl[0], (unsigned)__builtin_popcountll(mask));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (alive && slot < (unsigned)SW_SURV) { skey[slot] = key; spos[slot] = pos; }
+            }
+        }
+        lds_barrier();
+        // ---- resolve: wave 0 takes the survivors in exact order
+        if (wave == 0) {
+            const unsigned sc = ctl[0];
+            int state = 0;
+            if (sc > (unsigned)SW_SURV) state = 2;                           // more unsuppressed ties than fit: hand over
+            else if (sc) {
+                Cand e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned idx = lane + 64 * i;
+                    const bool ok = idx < sc;
+                    const unsigned ic = ok ? idx : 0u;
+                    const unsigned long long k = skey[ic];
+                    const unsigned p = spos[ic];
+                    e[i].key = ok ? k : 0ull;                                // 0 = dead (below every real key)
+                    e[i].pos = ok ? p : 0xffffffffu;
+                }
+                while (true) {
+                    Cand best = e[0];
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) {
+                        const bool take = better(e[i], best);
+                        best.key = take ? e[i].key : best.key;
+                        best.pos = take ? e[i].pos : best.pos;
+                    }
+                    if (__ballot(best.key != 0ull) == 0ull) break;
+                    const Cand top = wave_best(best);
+                    const int px = (int)(top.pos >> 16), py = (int)(top.pos & 0xffffu);
+                    if (lane == 0) {
+                        plist[np] = top.pos;
+                        if (picks) {
+                            double *pk = picks + ((size_t)b * g.n_regions + np) * 3;
+                            pk[0] = (double)py;
+                            pk[1] = (double)px;
+                            pk[2] = key_value(top.key);
+                        }
+                        const int pcx = (int)__umulhi((unsigned)px, g.cmul), pcy = (int)__umulhi((unsigned)py, g.cmul);
+                        grid[(pcy + 1) * g.gstride + pcx + 1] = (unsigned char)(1 + (((py - pcy * cs) << 4) | (px - pcx * cs)));
+                    }
+                    ++np;
+                    if (np >= g.n_regions) { state = 1; break; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ex = (int)(e[i].pos >> 16), ey = (int)(e[i].pos & 0xffffu);
+                        const bool hit = (unsigned)(ex - px + r) <= (unsigned)(2 * r) && (unsigned)(ey - py + r) <= (unsigned)(2 * r);
+                        e[i].key = hit ? 0ull : e[i].key;
+                    }
+                }
+            }
+            if (lane == 0) { ctl[0] = 0; ctl[1] = (unsigned)state; }
+        }
+        lds_barrier();
+        fin = (int)ctl[1];
+    }
+    if (tid == 0) {
+        if (fin == 0) fin = truncated ? 2 : 1;   // candidates exhausted: final unless the threshold bin was dropped
+        hdr->np = np;
+        hdr->status = fin == 1 ? SEL_DONE : SEL_BAIL;
+        if (fin == 1 && n_picked) n_picked[b] = np;
+    }
+}
+
+// ------------------------------------------------------------------ windows of the picks
+// build.py:45-62 for every pick at once: all four writes store constants (or ground_truth of the
+// same pixel), so the order between picks does not matter.
+template <typename T>
+__global__ void __launch_bounds__(256) k_sel_apply(T *__restrict__ score, unsigned char *__restrict__ active,
+                                                   unsigned char *__restrict__ selected, long long *__restrict__ active_mask,
+                                                   const long long *__restrict__ gt, BinWs ws, BinGeom g)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= ws.hdr[b].np) return;
+    const unsigned pos = ws.plist[(size_t)b * g.n_regions + p];
+    const int w = (int)(pos >> 16), h = (int)(pos & 0xffffu);
+    const size_t hw = (size_t)g.H * g.W;
+    T *sc = score + (size_t)b * hw;
+    unsigned char *act = active + (size_t)b * hw, *sel = selected + (size_t)b * hw;
+    long long *am = active_mask + (size_t)b * hw;
+    const long long *gtb = gt + (size_t)b * hw;
+    const T neg_inf = sizeof(T) == 8 ? (T)__longlong_as_double(0xfff0000000000000ll) : (T)__uint_as_float(0xff800000u);
+    const int my0 = h - g.mrad < 0 ? 0 : h - g.mrad, my1 = h + g.mrad >= g.H ? g.H - 1 : h + g.mrad;
+    const int mx0 = w - g.mrad < 0 ? 0 : w - g.mrad, mx1 = w + g.mrad >= g.W ? g.W - 1 : w + g.mrad;
+    const int ay0 = h - g.arad < 0 ? 0 : h - g.arad, ay1 = h + g.arad >= g.H ? g.H - 1 : h + g.arad;
+    const int ax0 = w - g.arad < 0 ? 0 : w - g.arad, ax1 = w + g.arad >= g.W ? g.W - 1 : w + g.arad;
+    const int aw = ax1 - ax0 + 1, an = aw * (ay1 - ay0 + 1);
+    const int mw = mx1 - mx0 + 1, mn = mw * (my1 - my0 + 1);
+    for (int e = lane; e < an; e += 64) {                       // selected[...] = True; active_mask[...] = ground_truth[...]
+        const size_t o = (size_t)(ay0 + e / aw) * g.W + (ax0 + e % aw);
+        sel[o] = 1;
+        am[o] = gtb[o];
+    }
+    for (int e = lane; e < mn; e += 64) {                       // score[...] = -inf; active[...] = True
+        const size_t o = (size_t)(my0 + e / mw) * g.W + (mx0 + e % mw);
+        sc[o] = neg_inf;
+        act[o] = 1;
+    }
+}
+
+}  // namespace halo
+
+using namespace halo;
+
+namespace halo {
+
+static unsigned sel_target()
+{
+    const char *e = getenv("HALO_SEL_TARGET");       // tuning aid: expected candidates per fine bin
+    const int v = e ? atoi(e) : 0;
+    return v >= 8 && v <= 256 ? (unsigned)v : 128u;
+}
+
+BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t arad, int64_t mrad)
+{
+    BinPlan p;
+    memset(&p, 0, sizeof(p));
+    if (B <= 0 || H <= 0 || W <= 0 || n_regions <= 0 || H > 65535 || W > 65535 || mrad < 0 || mrad > 14) return p;
+    BinGeom &g = p.g;
+    g.H = (int)H; g.W = (int)W; g.n_regions = (int)n_regions; g.arad = (int)arad; g.mrad = (int)mrad;
+    g.cs = (int)mrad + 1;
+    g.gcy = (int)cdiv(H, g.cs);
+    g.gcx = (int)cdiv(W, g.cs);
+    g.gstride = (int)align_up((size_t)g.gcx + 2, 4);
+    g.cmul = (unsigned)((0x100000000ull + (unsigned)g.cs - 1) / (unsigned)g.cs);
+    g.grid_bytes = (unsigned)align_up((size_t)(g.gcy + 2) * g.gstride + 8, 16);
+    p.lds_bytes = g.grid_bytes + (size_t)SW_SURV * 12 + (FWIN + 1) * 4 + 16;
+    if (p.lds_bytes > 156 * 1024) return p;                 // pick grid does not fit the CU's LDS: serial kernel
+    const unsigned long long hw = (unsigned long long)H * W, win = (unsigned long long)(2 * mrad + 1) * (2 * mrad + 1);
+    const unsigned long long kneed = win * (unsigned long long)n_regions < hw ? win * (unsigned long long)n_regions : hw;
+    unsigned long long cap = 2 * kneed < 65536 ? 65536 : 2 * kneed;
+    if (cap > hw) cap = hw;
+    g.kneed = (unsigned)kneed;
+    g.captot = (unsigned)cap;
+    g.target = sel_target();
+    g.nfmax = (unsigned)(cap / g.target + NB1 + 1);
+    size_t o = 0;
+    auto take = [&](size_t per_image) { const size_t at = o; o += align_up(per_image * (size_t)B, 256); return at; };
+    p.off_hdr = take(sizeof(SelHdr));
+    p.off_hist1 = take((size_t)NB1 * 4);
+    p.off_fhist = take((size_t)g.nfmax * 4);
+    p.off_fcur = take((size_t)g.nfmax * 4);
+    p.zero_bytes = o;                                       // everything above is cleared at the start of a call
+    p.off_cbase = take((size_t)NB1 * 4);
+    p.off_cm = take((size_t)NB1 * 4);
+    p.off_foff = take(((size_t)g.nfmax + 1) * 4);
+    p.off_tmp = take((size_t)g.captot * 16);
+    p.off_ckey = take((size_t)g.captot * 8);
+    p.off_cpos = take((size_t)g.captot * 4);
+    p.off_plist = take((size_t)g.n_regions * 4);
+    p.total_bytes = o + 256;
+    p.ok = true;
+    return p;
+}
+
+int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *active, uint8_t *selected, int64_t *active_mask,
+                  const int64_t *gt, double *picks, int32_t *n_picked, void *workspace, size_t workspace_bytes, hipStream_t st,
+                  SelHdr **hdr_out)
+{
+    if (!workspace || workspace_bytes < p.total_bytes) return fail(HALO_E_WORKSPACE, "halo_greedy_select: workspace too small");
+    char *base = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if ((size_t)(base - (char *)workspace) + p.total_bytes - 256 > workspace_bytes) return fail(HALO_E_WORKSPACE, "halo_greedy_select: workspace too small");
+    BinWs ws;
+    ws.hdr = (SelHdr *)(base + p.off_hdr);
+    ws.hist1 = (unsigned *)(base + p.off_hist1);
+    ws.fhist = (unsigned *)(base + p.off_fhist);
+    ws.fcur = (unsigned *)(base + p.off_fcur);
+    ws.cbase = (unsigned *)(base + p.off_cbase);
+    ws.cm = (unsigned *)(base + p.off_cm);
+    ws.foff = (unsigned *)(base + p.off_foff);
+    ws.tmp = (uint4 *)(base + p.off_tmp);
+    ws.ckey = (unsigned long long *)(base + p.off_ckey);
+    ws.cpos = (unsigned *)(base + p.off_cpos);
+    ws.plist = (unsigned *)(base + p.off_plist);
+    const BinGeom &g = p.g;
+    const long long hw = (long long)g.H * g.W;
+    if (hipMemsetAsync(base, 0, p.zero_bytes, st) != hipSuccess) return fail(HALO_E_LAUNCH, "halo_greedy_select: memset failed");
+    const unsigned gx = (unsigned)(cdiv(hw, 256) < 128 ? cdiv(hw, 256) : 128);
+    const unsigned gy = (unsigned)(g.H < 128 ? g.H : 128);
+    dim3 blk(256);
+    if (dtype == HALO_F64) {
+        hipLaunchKernelGGL(k_sel_range<double>, dim3(gx, (unsigned)B), blk, 0, st, (const double *)score, hw, ws);
+        hipLaunchKernelGGL(k_sel_hist1<double>, dim3(gx, (unsigned)B), blk, 0, st, (const double *)score, hw, ws);
+    } else {
+        hipLaunchKernelGGL(k_sel_range<float>, dim3(gx, (unsigned)B), blk, 0, st, (const float *)score, hw, ws);
+        hipLaunchKernelGGL(k_sel_hist1<float>, dim3(gx, (unsigned)B), blk, 0, st, (const float *)score, hw, ws);
+    }
+    hipLaunchKernelGGL(k_sel_scan1, dim3((unsigned)B), blk, 0, st, ws, g);
+    if (dtype == HALO_F64) hipLaunchKernelGGL(k_sel_compact<double>, dim3(gy, (unsigned)B), blk, 0, st, (const double *)score, ws, g);
+    else hipLaunchKernelGGL(k_sel_compact<float>, dim3(gy, (unsigned)B), blk, 0, st, (const float *)score, ws, g);
+    hipLaunchKernelGGL(k_sel_scan2, dim3((unsigned)B), blk, 0, st, ws, g);
+    const unsigned gs = (unsigned)(cdiv(g.captot, 256) < 256 ? cdiv(g.captot, 256) : 256);
+    hipLaunchKernelGGL(k_sel_scatter, dim3(gs, (unsigned)B), blk, 0, st, ws, g);
+    static bool attr_set = false;
+    if (!attr_set) {       // the pick grid may need more than the default 64 KiB of dynamic LDS
+        if (hipFuncSetAttribute((const void *)k_sel_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sel_sweep, dim3((unsigned)B), dim3(SW_TPB), p.lds_bytes, st, ws, g, picks, n_picked);
+    const dim3 ga((unsigned)cdiv(g.n_regions, 4), (unsigned)B);
+    if (dtype == HALO_F64)
+        hipLaunchKernelGGL(k_sel_apply<double>, ga, blk, 0, st, (double *)score, active, selected, (long long *)active_mask, (const long long *)gt, ws, g);
+    else
+        hipLaunchKernelGGL(k_sel_apply<float>, ga, blk, 0, st, (float *)score, active, selected, (long long *)active_mask, (const long long *)gt, ws, g);
+    *hdr_out = ws.hdr;
+    return check_launch("halo_greedy_select (binned)");
+}
+
+}  // namespace halo

@@ -1,0 +1,94 @@
+// Shared pieces of the two selector implementations (halo_select.hip: serial tile-table kernel,
+// halo_select_binned.hip: value-binned sweep): the total order on score values and the wave-level
+// arg-max under that order.
+//
+// Order (core/active/build.py:38-43, the reference's two-stage torch.max): value descending, then
+// smallest w, then smallest h; NaN above everything; -0 == +0.  Values are compared as ordered
+// 64-bit integers, so every decision is a bit-exact function of the score map for float32 and
+// float64 maps alike.
+#pragma once
+#include "halo_common.hpp"
+
+namespace halo {
+
+constexpr unsigned long long KEY_NAN = 0xffffffffffffffffull;
+constexpr unsigned long long KEY_NEG_INF = 0x000fffffffffffffull;   // ~bits(-inf)
+constexpr unsigned long long KEY_POS_INF = 0xfff0000000000000ull;   // bits(+inf) | sign
+
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    const bool isnan = v != v;
+    v = v == 0.0 ? 0.0 : v;                                 // -0 ties with +0 in torch.max
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long k = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    return isnan ? KEY_NAN : k;
+}
+__device__ __forceinline__ double key_value(unsigned long long k)
+{
+    if (k == KEY_NAN) return __longlong_as_double(0x7ff8000000000000ll);
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+struct Cand { unsigned long long key; unsigned pos; };     // pos = (w << 16) | h  (smaller wins a tie: min w, then min h)
+
+__device__ __forceinline__ bool better(const Cand &a, const Cand &b)
+{
+    return a.key > b.key || (a.key == b.key && a.pos < b.pos);
+}
+// Wave-wide unsigned max via DPP row shifts / row broadcasts (no LDS crossbar traffic): 6 dependent
+// VALU+DPP steps instead of 6 ds_bpermute round trips.  Result is wave-uniform (read from lane 63).
+__device__ __forceinline__ unsigned wave_umax(unsigned x)
+{
+#define HALO_DPP_MAX(ctrl, rmask)                                                                    \
+    {                                                                                                \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, true); \
+        x = o > x ? o : x;                                                                           \
+    }
+    HALO_DPP_MAX(0x111, 0xf)   // row_shr:1
+    HALO_DPP_MAX(0x112, 0xf)   // row_shr:2
+    HALO_DPP_MAX(0x114, 0xf)   // row_shr:4
+    HALO_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds its row's max
+    HALO_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    HALO_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
+#undef HALO_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// arg-max over a wave under `better`: high word, low word, then the smallest position among ties
+__device__ __forceinline__ Cand wave_best(Cand c)
+{
+    const unsigned hi = (unsigned)(c.key >> 32), lo = (unsigned)c.key;
+    const unsigned mh = wave_umax(hi);
+    const unsigned ml = wave_umax(hi == mh ? lo : 0u);
+    const bool tie = hi == mh && lo == ml;
+    const unsigned mp = ~wave_umax(tie ? ~c.pos : 0u);
+    Cand r;
+    r.key = ((unsigned long long)mh << 32) | ml;
+    r.pos = mp;
+    return r;
+}
+
+// LDS-only barrier: orders LDS traffic between the waves of the workgroup without draining the
+// vector-memory counter (a __syncthreads() would wait for outstanding global stores / prefetches).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Per-image control block of the binned selector (also read by the serial kernel when it resumes an image).
+struct SelHdr {
+    unsigned long long kmin_inv;   // max over finite values of ~order_key  (zero-initialised => "no value yet")
+    unsigned long long kmax;       // max over finite values of order_key
+    unsigned nvalid;               // finite values (> -inf): what can ever be picked
+    unsigned flags;                // SEL_F_*
+    unsigned ncand;                // candidates appended to the staging list
+    unsigned nf;                   // fine bins in use
+    unsigned t1;                   // first coarse bin that contributes candidates
+    unsigned truncated;            // 1: the threshold bin was dropped (staging capacity) -> exhaustion is not final
+    int status;                    // SEL_RUN / SEL_DONE / SEL_BAIL
+    int np;                        // picks made so far
+    unsigned pad[4];
+};
+static_assert(sizeof(SelHdr) == 64, "SelHdr is 64 bytes");
+enum { SEL_RUN = 0, SEL_DONE = 1, SEL_BAIL = 2 };
+enum { SEL_F_BAD = 1 };            // NaN or +inf present: the value range cannot be binned
+
+}  // namespace halo

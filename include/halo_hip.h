@@ -160,11 +160,18 @@ int halo_quantize_radius(const void *feat, int feat_dtype, int64_t feat_bstride,
  * picks (B,n_regions,3) f64 receives (h, w, value) in selection order (may be NULL);
  * n_picked (B) i32 receives the count (may be NULL).
  */
-size_t halo_select_workspace_bytes(int64_t B, int64_t H, int64_t W);
+/* method: HALO_SELECT_AUTO runs the value-binned sweep (visit pixels in descending value order, test each
+ * against the picks so far -- no per-pick pass over the map) and leaves what it cannot finish (NaN / +inf
+ * in the map, large plateaus of exact ties, pick grid larger than LDS, mask radius above 14) to the serial
+ * tile-table kernel on the same stream; HALO_SELECT_SERIAL runs only the latter; HALO_SELECT_BINNED
+ * fails with HALO_E_UNSUPPORTED where the sweep does not serve the geometry.  All three give identical results.
+ * workspace: halo_select_workspace_bytes(B, H, W, n_regions, mask_radius). */
+enum { HALO_SELECT_AUTO = 0, HALO_SELECT_SERIAL = 1, HALO_SELECT_BINNED = 2 };
+size_t halo_select_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t mask_radius);
 int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,
                        int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
                        int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
-                       void *workspace, size_t workspace_bytes, void *stream);
+                       void *workspace, size_t workspace_bytes, int method, void *stream);
 
 /* ---- training-side window losses, float32 tensors, float64 sums on the device ----
  *  - NegativeLearningLoss (core/loss/negative_learning_loss.py:6-16): sums = {sum -mask*log(1-p+1e-6), sum mask},

@@ -41,7 +41,10 @@ def test_workspace_queries_are_pure_host_functions():
     assert L.halo_score_workspace_bytes(1, 1024, 2048) >= 1024 * 2048 * 18
     assert L.halo_score_workspace_bytes(0, 4, 4) == 0
     assert L.halo_hypermlr_workspace_bytes(19, 256) >= (3 * 19 + 2 * 19 * 256) * 8
-    assert L.halo_select_workspace_bytes(4, 1024, 2048) > 0
+    # the binned selector stages up to 2 x 121 x n candidates per image (28 bytes each); the serial kernel needs none
+    assert L.halo_select_workspace_bytes(4, 1024, 2048, 2331, 5) > 4 * 2 * 121 * 2331 * 28
+    assert L.halo_select_workspace_bytes(4, 1024, 2048, 2331, 40) == 256          # mask radius above 14: serial kernel only
+    assert L.halo_select_workspace_bytes(0, 8, 8, 1, 1) == 0
 
 
 def test_argument_errors_are_reported_not_crashed():
@@ -50,7 +53,7 @@ def test_argument_errors_are_reported_not_crashed():
     rc = L.halo_score_maps(None, 0, None, 0, 0, None, None, 1, 19, 0, 8, 8, 0, 4, 0, 3, 3, 100, 1.0, None, None, None,
                            None, 0, None)
     assert rc == -1 and b"null" in L.halo_last_error()
-    rc = L.halo_greedy_select(None, 1, 1, 8, 8, 1, 1, 5, None, None, None, None, None, None, None, 0, None)
+    rc = L.halo_greedy_select(None, 1, 1, 8, 8, 1, 1, 5, None, None, None, None, None, None, None, 0, 0, None)
     assert rc == -1
 
 

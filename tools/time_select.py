@@ -1,4 +1,6 @@
-"""Timing aid: greedy selection alone vs beside the streaming feature kernel (one MI355X)."""
+"""Timing aid: greedy selection (value-binned sweep vs the serial tile-table kernel) alone and beside the
+streaming feature kernel (one MI355X).  Prints per-call wall time, per-pick time and, with --kernels,
+HIP-event times of the sweep's individual launches (they are issued back to back on one stream)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,41 +9,42 @@ from halo_amd.core.active.floating_region import score_maps
 
 dev = torch.device("cuda:0")
 H, W, n = 1024, 2048, 2331
+mrad = int(os.environ.get("MRAD", "5"))
+methods = os.environ.get("METHODS", "auto,serial").split(",")
 for B in (1, 4, 16, 32):
     g = torch.Generator(device=dev).manual_seed(3)
     base = torch.randn((B, H // 4, W // 4), generator=g, device=dev, dtype=torch.float64)
     score0 = torch.nn.functional.interpolate(base[None], size=(H, W), mode="bilinear", align_corners=True)[0].contiguous()
     gt = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
-    def run():
-        sc = score0.clone()
-        act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
-        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        greedy_select(sc, n, 1, 5, act, sel, am, gt, return_picks=False)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) * 1e3
-    run()
-    alone = min(run() for _ in range(3))
-    # beside a streaming kernel
     feat = torch.randn((4, 256, H, W), device=dev, dtype=torch.float64) * 0.01
     logit = torch.randn((4, 19, H, W), device=dev)
     s2 = torch.cuda.Stream(dev)
-    def run_loaded():
-        sc = score0.clone()
-        act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
-        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize()
-        with torch.cuda.stream(s2):
-            for _ in range(12):
-                score_maps(logit, feat, "entropy", "radius", True, None, want_maps=False)
-        t0 = time.perf_counter()
-        greedy_select(sc, n, 1, 5, act, sel, am, gt, return_picks=False)
-        torch.cuda.current_stream().synchronize()
-        dt = (time.perf_counter() - t0) * 1e3
-        torch.cuda.synchronize()
-        return dt
-    run_loaded()
-    loaded = min(run_loaded() for _ in range(3))
-    print(f"B={B:2d}: alone {alone:7.2f} ms ({alone / n * 1e3:5.2f} us/step)   beside streaming {loaded:7.2f} ms ({loaded / n * 1e3:5.2f} us/step)")
+    ref = None
+    for method in methods:
+        def run(loaded):
+            sc = score0.clone()
+            act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+            am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            if loaded:
+                with torch.cuda.stream(s2):
+                    for _ in range(12):
+                        score_maps(logit, feat, "entropy", "radius", True, None, want_maps=False)
+            t0 = time.perf_counter()
+            picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt, method=method)
+            torch.cuda.current_stream().synchronize()
+            dt = (time.perf_counter() - t0) * 1e3
+            torch.cuda.synchronize()
+            return dt, picks, npk
+        run(False)
+        alone = min(run(False)[0] for _ in range(3))
+        run(True)
+        res = [run(True) for _ in range(3)]
+        loaded = min(r[0] for r in res)
+        picks, npk = res[-1][1], res[-1][2]
+        if ref is None:
+            ref = picks
+        same = bool(torch.equal(ref, picks))
+        print(f"B={B:2d} {method:7s}: alone {alone:7.2f} ms ({alone / n * 1e3:5.2f} us/pick)   beside streaming {loaded:7.2f} ms "
+              f"({loaded / n * 1e3:5.2f} us/pick)   picks {int(npk.min())}..{int(npk.max())}  same as first method: {same}", flush=True)
     del feat, logit
