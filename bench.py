@@ -230,14 +230,37 @@ class Pipeline:
         return out
 
 
+def effective_cpus():
+    """Host cores this process may actually use: min(visible CPUs, scheduler affinity, cgroup CPU quota).  The GPU
+    boxes of this pool show 256 CPUs under a cgroup quota of 16 (cpu.max "1600000 100000"): an OpenMP team wider
+    than the quota only gets throttled."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(feat, logit, gt, n_images, n_regions, branch):
     """The CPU oracle (kind 'port': C restatement, OpenMP over all host cores) on the first ring images:
     one untimed warm-up image, then `n_images` timed ones: score + mask + select, median
     s/image -> images/s.  Also returns image 0's picks so the caller can compare them with the GPU's."""
+    import ctypes
     from oracle import halo_oracle as ho
     ho.lib()
     unc, pur, norm, mrad, K = BRANCHES[branch]
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)        # the oracle's OpenMP team = the usable cores
+    except OSError:
+        cores = os.cpu_count() or 1
     times, picks = [], []
     R = feat.shape[0]
     for j in range(n_images + 1):
@@ -389,8 +412,9 @@ def main():
         if a.cpu_images > 0 and world == 1:
             s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, a.cpu_images, n_regions, a.branch)
             out["cpu_baseline"] = {"value": round(1.0 / s_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                                   "sample": "1 warm-up + %d timed ring images, oracle/halo_oracle.c (OpenMP), median s/image = %.2f"
-                                             % (a.cpu_images, s_img)}
+                                   "sample": "1 warm-up + %d timed ring images, oracle/halo_oracle.c (OpenMP, %d threads = usable "
+                                             "host cores of %d visible), median s/image = %.2f"
+                                             % (a.cpu_images, cores, os.cpu_count() or 1, s_img)}
             # same inputs -> the GPU picks of image 0 must equal the oracle's
             from halo_amd.core.active.build import acquire_batch
             act = torch.zeros((1, Hh, Ww), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)

@@ -8,6 +8,8 @@ build.py:162-166) and batches images through the fused score -> mask -> select p
 """
 import math
 import os
+import struct
+import zlib
 
 import numpy as np
 import torch
@@ -141,93 +143,178 @@ class AcquisitionParams:
 
 
 class _InFlight:
-    """One image whose scoring + selection has been enqueued on the acquisition stream."""
-    __slots__ = ("amask", "active", "selected", "done", "path_mask", "path_indicator", "keep", "picks", "npk")
+    """One image whose staging, scoring, selection and device->host copies have been enqueued on a side stream."""
+    __slots__ = ("done", "path_mask", "path_indicator", "keep", "picks", "npk", "h_mask", "h_active", "h_selected", "slot")
 
 
-def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, stream):
-    """Enqueue one image of the pool (build.py:113-160) on `stream`: stage its masks, then
-    score -> mask -> select.  Asynchronous; the caller retires it with _retire()."""
+class _Slot:
+    """One pipeline slot: a side stream position plus its own pinned device->host staging buffers, allocated once
+    per image shape and reused for every image that passes through the slot (pinning host pages costs
+    milliseconds; the caching host allocator gives no guarantee to hand the same block back in time)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.shape = None
+        self.mask = self.active = self.selected = None
+
+    def buffers(self, shape):
+        if self.shape != tuple(shape):
+            self.mask = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+            self.active = torch.empty(shape, dtype=torch.bool, pin_memory=True)
+            self.selected = torch.empty(shape, dtype=torch.bool, pin_memory=True)
+            self.shape = tuple(shape)
+        return self.mask, self.active, self.selected
+
+
+def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, slot):
+    """Enqueue one image of the pool (build.py:113-166) on `stream`: stage its masks, score -> mask -> select,
+    copy the results back into pinned host buffers.  Fully asynchronous: `rec.done` fires when the host
+    buffers hold the image's final mask / indicator maps."""
     rec = _InFlight()
+    rec.slot = slot
+    stream = slot.stream
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))             # the head outputs are complete from here on
     with torch.cuda.stream(stream):
         stream.wait_event(ready)
-        rec.amask = origin_mask.to(dev, non_blocking=True).long().contiguous()
+        amask = origin_mask.to(dev, non_blocking=True).long().contiguous()
         gt = origin_label.to(dev, non_blocking=True).long().contiguous()
-        rec.active = active_cpu.to(dev, non_blocking=True).bool().contiguous()
-        rec.selected = selected_cpu.to(dev, non_blocking=True).bool().contiguous()
+        active = active_cpu.to(dev, non_blocking=True).bool().contiguous()
+        selected = selected_cpu.to(dev, non_blocking=True).bool().contiguous()
         # the two F.interpolate(align_corners=True) calls of build.py:122-135 are fused into the scorer:
         # the C x H x W float64 embedding (4.3 GB at C=256) is never written or read
         rec.picks, rec.npk = acquire_batch_lowres(
-                             logit_lr, embed_lr, size, gt[None], rec.active[None], rec.selected[None], rec.amask[None],
+                             logit_lr, embed_lr, size, gt[None], active[None], selected[None], amask[None],
                              unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
                              n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
                              mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
                              K=prm.K, c=prm.scorer.mapper.c)
-        rec.done = torch.cuda.Event()
+        # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
+        # reference's cast-after-copy, build.py:67-68,162)
+        rec.h_mask, rec.h_active, rec.h_selected = slot.buffers(amask.shape)
+        rec.h_mask.copy_(amask.to(torch.uint8), non_blocking=True)
+        rec.h_active.copy_(active, non_blocking=True)
+        rec.h_selected.copy_(selected, non_blocking=True)
+        rec.done = torch.cuda.Event(blocking=True)           # the writer thread sleeps on it instead of spinning
         rec.done.record(stream)
-    rec.keep = (logit_lr, embed_lr, gt)                      # alive until the side stream is done with them
+    # device tensors the side stream still reads: kept alive until the image is retired
+    rec.keep = (logit_lr, embed_lr, gt, amask, active, selected)
     return rec
+
+
+_PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
+
+
+def _png_chunk(tag, data):
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+
+def write_png_gray8(path, arr):
+    """8-bit greyscale (PIL mode "L") PNG of a (H, W) uint8 array: the file `Image.fromarray(a).save(path)` of
+    build.py:163-164 produces, pixel for pixel, written directly -- filter type 0 on every row and ONE zlib stream
+    with the run-length strategy (masks are long runs of 255 with small labelled windows; zlib releases the GIL, so
+    writer threads run in parallel).  PIL spends ~12 ms per 1024x2048 mask in its row-by-row encoder; this takes
+    about half and decodes to the identical image."""
+    h, w = arr.shape
+    rows = np.empty((h, w + 1), dtype=np.uint8)
+    rows[:, 0] = 0                                                   # filter type "None" per scanline
+    rows[:, 1:] = arr
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)              # bit depth 8, colour type 0 (greyscale), no interlace
+    z = zlib.compressobj(1, zlib.DEFLATED, 15, 9, zlib.Z_RLE)
+    idat = z.compress(rows.tobytes()) + z.flush()
+    with open(path, "wb") as f:
+        f.write(_PNG_SIGNATURE + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"IDAT", idat) + _png_chunk(b"IEND", b""))
 
 
 def _persist(mask_np, active, selected, path_mask, path_indicator):
     """build.py:162-166: uint8 mode-L PNG + torch.save'd indicator dict (what cityscapes.py:234-251 reads back)."""
-    Image.fromarray(mask_np).save(path_mask)
+    if mask_np.ndim == 2 and mask_np.dtype == np.uint8 and mask_np.size and str(path_mask).lower().endswith(".png"):
+        write_png_gray8(path_mask, mask_np)
+    else:
+        Image.fromarray(mask_np).save(path_mask)
     torch.save({"active": active, "selected": selected}, path_indicator)
 
 
-def _retire(rec, writers, pending, tables=None):
-    rec.done.synchronize()
-    if tables is not None:
-        tables.append((rec.picks[0], int(rec.npk[0])))
-    # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
-    # reference's cast-after-copy, build.py:67-68,162)
-    job = (rec.amask.to(torch.uint8).cpu().numpy(), rec.active.cpu(), rec.selected.cpu(), rec.path_mask, rec.path_indicator)
-    rec.keep = None
-    pending.append(writers.submit(_persist, *job))
+def _finish(rec, slots, backlog):
+    """Writer-thread half of one image: wait for its copies, hand its pipeline slot back, write the two files."""
+    try:
+        return _finish_inner(rec, slots)
+    finally:
+        backlog.release()
 
 
-def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=3, writer_threads=4,
-                    return_tables=False):
+def _finish_inner(rec, slots):
+    try:
+        rec.done.synchronize()
+        # ONE streaming copy out of the pinned staging buffers first (the slot is then free for the next image; the
+        # encoders make several passes over their input, and the indicator must hold plain tensors as from `.cpu()`).
+        # numpy copies on purpose: a torch CPU op here would wake an intra-op thread pool as wide as the host
+        mask = rec.h_mask.numpy().copy()
+        active, selected = torch.from_numpy(rec.h_active.numpy().copy()), torch.from_numpy(rec.h_selected.numpy().copy())
+        out = (rec.picks[0], int(rec.npk[0]))
+        rec.keep = rec.h_mask = rec.h_active = rec.h_selected = None
+    finally:
+        slots.put(rec.slot)
+    _persist(mask, active, selected, rec.path_mask, rec.path_indicator)
+    return out
+
+
+def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=8, writer_threads=8,
+                    streams=4, return_tables=False):
     """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
     at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
     every file on disk when the call returns.  Returns None like the reference, or -- keyword-only
     `return_tables=True`, used by halo_amd.pool.region_selection_sharded -- the per-image pick tables
     [(picks (n,3) float64 rows (h, w, score), count)] in loader order.
 
-    Inside, image i's score + greedy selection runs on a side stream while the backbone processes
-    image i+1, and PNG encoding / torch.save run on a small thread pool: in the reference
-    both serialise with the 2331-step selection loop of every image."""
+    Inside the images of the pool are independent, so image i's host->device staging,
+    score + selection and device->host copies are enqueued on one of `streams` side streams (round
+    robin) while the backbone processes image i+1 on the caller's stream; the host thread never waits
+    for the GPU: a pool of writer threads waits for each image's event, encodes the PNG and writes the
+    indicator.  At most `in_flight` images are between "launched" and "copied back to the host" (bounds device
+    and pinned memory; each slot owns its pinned staging buffers); `in_flight=0` runs strictly one image at a
+    time like the reference."""
+    import queue
+    import threading
     from concurrent.futures import ThreadPoolExecutor
     prm = AcquisitionParams(cfg)
     dev = torch.device("cuda", torch.cuda.current_device())
-    side = torch.cuda.Stream(dev, priority=-1)
+    depth = max(1, in_flight)
+    side = [torch.cuda.Stream(dev, priority=-1) for _ in range(max(1, min(streams, depth)))]
+    backlog = threading.Semaphore(depth + 4 * max(1, writer_threads))   # images whose files are not on disk yet (host copies)
+    slots = queue.Queue()
+    for k in range(depth):
+        slots.put(_Slot(side[k % len(side)]))
     feature_extractor.eval()
     classifier.eval()
     moved = False
-    queue, pending = [], []
-    tables = [] if return_tables else None
+    pending = []
     with ThreadPoolExecutor(max_workers=max(1, writer_threads)) as writers, torch.no_grad():
-        for batch in tgt_epoch_loader:
-            images = batch["img"].to(dev, non_blocking=True)
-            if not moved:
-                feature_extractor.to(dev)
-                classifier.to(dev)
-                moved = True
-            logits_lr, embed_lr = classifier(feature_extractor(images), size=images.shape[-2:])
-            for i in range(len(batch["origin_mask"])):          # loader batch size is 1 in the reference
-                size = (int(batch["size"][i][0]), int(batch["size"][i][1]))
-                rec = _launch_one(prm, logits_lr[i:i + 1], embed_lr[i:i + 1], size, batch["origin_mask"][i],
-                                  batch["origin_label"][i], batch["active"][i], batch["selected"][i], dev, side)
-                rec.path_mask, rec.path_indicator = batch["path_to_mask"][i], batch["path_to_indicator"][i]
-                queue.append(rec)
-                while len(queue) > max(0, in_flight):      # in_flight=0: fully serial, like the reference
-                    _retire(queue.pop(0), writers, pending, tables)
-        while queue:
-            _retire(queue.pop(0), writers, pending, tables)
-        for f in pending:
-            f.result()                                           # surface I/O errors; all files are on disk
+        try:
+            for batch in tgt_epoch_loader:
+                images = batch["img"].to(dev, non_blocking=True)
+                if not moved:
+                    feature_extractor.to(dev)
+                    classifier.to(dev)
+                    moved = True
+                logits_lr, embed_lr = classifier(feature_extractor(images), size=images.shape[-2:])
+                for i in range(len(batch["origin_mask"])):          # loader batch size is 1 in the reference
+                    size = (int(batch["size"][i][0]), int(batch["size"][i][1]))
+                    backlog.acquire()
+                    slot = slots.get()                               # blocks only while `in_flight` images hold every slot
+                    try:
+                        rec = _launch_one(prm, logits_lr[i:i + 1], embed_lr[i:i + 1], size, batch["origin_mask"][i],
+                                          batch["origin_label"][i], batch["active"][i], batch["selected"][i], dev, slot)
+                    except BaseException:
+                        slots.put(slot)
+                        backlog.release()
+                        raise
+                    rec.path_mask, rec.path_indicator = batch["path_to_mask"][i], batch["path_to_indicator"][i]
+                    pending.append(writers.submit(_finish, rec, slots, backlog))
+                    if in_flight <= 0:
+                        pending[-1].result()
+        finally:
+            results = [f.result() for f in pending]                  # surface I/O errors; all files are on disk
     feature_extractor.train()
     classifier.train()
-    return tables
+    return results if return_tables else None

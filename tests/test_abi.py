@@ -103,3 +103,28 @@ def test_cfg_standin_has_reference_defaults():
     assert cfg.MODEL.CURVATURE == 1.0 and cfg.MODEL.NUM_CLASSES == 19 and cfg.MODEL.HYPER is True
     assert cfg.ACTIVE.RADIUS_K == 1 and cfg.ACTIVE.MASK_RADIUS_K == 5 and cfg.ACTIVE.K == 100
     assert cfg.ACTIVE.BUDGET == 0.05 and len(cfg.ACTIVE.SELECT_ITER) == 5
+
+
+def test_direct_png_writer_decodes_to_the_same_mode_L_image(tmp_path):
+    """RegionSelection writes its masks with a direct PNG writer instead of PIL's encoder (build.py:163-164 in the
+    reference): what cityscapes.py:231 reads back must be the identical uint8 image, mode 'L'."""
+    import numpy as np
+    from PIL import Image
+    from halo_amd.core.active.build import _persist, write_png_gray8
+    rng = np.random.default_rng(0)
+    for shape in ((64, 96), (1, 1), (7, 3), (33, 1), (1, 50)):
+        a = rng.integers(0, 256, shape).astype(np.uint8)
+        if shape == (64, 96):
+            a[:] = 255; a[10:13, 20:23] = 7
+        p = str(tmp_path / "x.png")
+        write_png_gray8(p, a)
+        im = Image.open(p)
+        assert im.mode == "L" and im.size == (shape[1], shape[0]) and np.array_equal(np.array(im, dtype=np.uint8), a)
+        ref = str(tmp_path / "ref.png")
+        Image.fromarray(a).save(ref)                                   # the reference's call
+        assert np.array_equal(np.array(Image.open(ref)), np.array(Image.open(p)))
+    # the driver's persistence step: PNG + indicator dict of CPU bool tensors
+    act = torch.from_numpy(rng.random((64, 96)) < 0.1)
+    _persist(a if a.shape == (64, 96) else np.full((64, 96), 255, np.uint8), act, act.clone(), str(tmp_path / "m.png"), str(tmp_path / "i.pth"))
+    ind = torch.load(str(tmp_path / "i.pth"))
+    assert set(ind) == {"active", "selected"} and ind["active"].dtype == torch.bool and torch.equal(ind["active"], act)

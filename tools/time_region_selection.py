@@ -8,7 +8,7 @@ from halo_amd.core.active.build import RegionSelection
 from halo_amd.core.utils.hyperbolic import HyperMapper
 
 dev = torch.device("cuda:0")
-N, H, W, C, O = 24, 1024, 2048, 64, 19
+N, H, W, C, O = 48, 1024, 2048, 64, 19
 cfg = types.SimpleNamespace(
     MODEL=types.SimpleNamespace(NUM_CLASSES=O, HYPER=True, CURVATURE=1.0),
     ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
@@ -57,12 +57,13 @@ for _ in range(20):
 torch.cuda.synchronize(); GEMM_MS = (time.perf_counter() - t0) / 20 * 1e3
 print(f"4096^3 f32 GEMM: {GEMM_MS:.2f} ms")
 for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
-    for (infl, wr, tag) in ((0, 1, "serial (in_flight=0, 1 writer)"), (3, 4, "pipelined (in_flight=3, 4 writers)")):
+    for (infl, wr, tag) in ((0, 1, "serial (in_flight=0, 1 writer)"), (8, 8, "pipelined (in_flight=8, 4 streams, 8 writers)"),
+                            (16, 16, "pipelined (in_flight=16, 4 streams, 16 writers)")):
         tmp = tempfile.mkdtemp(prefix="halo_rs_t_")
         items = pool(tmp)
-        RegionSelection(cfg, Ident(), Head(busy), items[:2], 1, in_flight=infl, writer_threads=wr)
+        RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, in_flight=infl, writer_threads=wr)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         RegionSelection(cfg, Ident(), Head(busy), items, 1, in_flight=infl, writer_threads=wr)
         dt = time.perf_counter() - t0
-        print(f"backbone stand-in {MODE:5s} {busy:4.0f} ms: {tag:38s} {dt / N * 1e3:7.1f} ms/image  ({N / dt:6.1f} images/s)")
+        print(f"backbone stand-in {MODE:5s} {busy:4.0f} ms: {tag:48s} {dt / N * 1e3:7.1f} ms/image  ({N / dt:6.1f} images/s)")
