@@ -13,6 +13,8 @@
 namespace halo {
 
 constexpr int HTPB = 256;
+typedef double d2_h __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ double ld_as_f64(const T *p) { return (double)*p; }
 
@@ -43,6 +45,101 @@ __global__ void __launch_bounds__(HTPB) k_expmap0_project(const TIN *__restrict_
     ny = ny < 1e-15 ? 1e-15 : ny;
     if (ny > maxnorm)                                        // project: eps = 1e-5 for float64
         for (int ch = 0; ch < C; ++ch) yp[(size_t)ch * inner] = yp[(size_t)ch * inner] / ny * maxnorm;
+}
+
+// The same map through an LDS tile: a workgroup stages P consecutive pixels x all C channels (float32 input,
+// 32-64 KiB) with 16-byte non-temporal loads issued back to back -- x is read from HBM ONCE (the kernel above walks
+// the channel planes twice with a handful of loads in flight) -- then one lane per pixel runs the norm's fma chain
+// over the tile, and all lanes write y as 16-byte non-temporal stores (the output is twice the input and written
+// once).  Arithmetic and its order are exactly the kernel's above (one sequential fma chain per pixel in channel
+// order, v = g * (x / n)), so the results are bit-identical.  project() can only act when g = tanh(.)/sqrt(c) is
+// within 1e-9 of maxnorm (||y|| <= g (1 + C 2^-52)), so the second norm is computed only for such pixels.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// x / n for many x and one n: the division sequence hipcc emits for f64 is  v_div_scale (no-op for operands in the
+// normal range), r = v_rcp_f64(n) refined by two Newton steps, q = x r, rem = fma(-n, q, x), q = fma(rem, r, q)
+// (v_div_fmas without scaling), v_div_fixup (specials).  With n in [1e-15, 1e25] and |x| a float32 value the
+// quotient is in the normal range, so the sequence below returns the identical bits with r computed once per pixel.
+__device__ __forceinline__ double exact_rcp(double n)
+{
+    double r = __builtin_amdgcn_rcp(n);
+    r = __builtin_fma(__builtin_fma(-n, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-n, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double div_by(float x, double n, double r)
+{
+    const double xd = (double)x, q = xd * r;
+    return __builtin_fma(__builtin_fma(-n, q, xd), r, q);
+}
+
+constexpr int EXP_LD = 8;      // 16-byte loads in flight per lane while staging
+
+__global__ void __launch_bounds__(HTPB) k_expmap0_project_tile(const float *__restrict__ x, double *__restrict__ y, long long outer,
+                                                               int C, long long inner, int pshift, double ks, double rks,
+                                                               double maxnorm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_e[];
+    const int P = 1 << pshift, tid = threadIdx.x;
+    float *tile = reinterpret_cast<float *>(smem_e);                         // [C][P]
+    double *s_n = reinterpret_cast<double *>(smem_e + (size_t)C * P * 4);    // per pixel: n, g, projection norm (0 = none)
+    double *s_g = s_n + P, *s_pr = s_g + P;
+    const long long tiles = (inner + P - 1) >> pshift;
+    const long long o = blockIdx.x / tiles, i0 = (blockIdx.x % tiles) << pshift;
+    const int np = inner - i0 < P ? (int)(inner - i0) : P;                   // pixels of this tile (a multiple of 4)
+    const float *xp = x + (size_t)o * C * inner + i0;
+    double *yp = y + (size_t)o * C * inner + i0;
+    // ---- stage: element e = (channel e >> (pshift-2), 4-pixel group e & (P/4-1))
+    const int gsh = pshift - 2, gmask = (1 << gsh) - 1, ngroups = C << gsh;
+    for (int e0 = tid; e0 < ngroups; e0 += HTPB * EXP_LD) {
+        f4_t q[EXP_LD];
+#pragma unroll
+        for (int u = 0; u < EXP_LD; ++u) {
+            const int e = e0 + u * HTPB, c = e >> gsh, px = (e & gmask) << 2;
+            q[u] = (f4_t){0.f, 0.f, 0.f, 0.f};
+            if (e < ngroups && px < np) q[u] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(xp + (size_t)c * inner + px));
+        }
+#pragma unroll
+        for (int u = 0; u < EXP_LD; ++u) {
+            const int e = e0 + u * HTPB;
+            if (e < ngroups) *reinterpret_cast<f4_t *>(tile + ((size_t)(e >> gsh) << pshift) + ((e & gmask) << 2)) = q[u];
+        }
+    }
+    __syncthreads();
+    // ---- one lane per pixel: ||x||, the tanh gain, and (rarely) the projection norm
+    if (tid < np) {
+        double ssq = 0.0;
+        for (int c = 0; c < C; ++c) { const double v = (double)tile[((size_t)c << pshift) + tid]; ssq = __builtin_fma(v, v, ssq); }
+        double n = __builtin_sqrt(ssq);
+        n = n < 1e-15 ? 1e-15 : n;
+        double a = n * ks;
+        a = a > 15.0 ? 15.0 : (a < -15.0 ? -15.0 : a);
+        const double g = rks * tanh(a);
+        double pr = 0.0;
+        if (g >= maxnorm * (1.0 - 1e-9)) {
+            double s2 = 0.0;
+            for (int c = 0; c < C; ++c) { const double v = g * ((double)tile[((size_t)c << pshift) + tid] / n); s2 = __builtin_fma(v, v, s2); }
+            double ny = __builtin_sqrt(s2);
+            ny = ny < 1e-15 ? 1e-15 : ny;
+            pr = ny > maxnorm ? ny : 0.0;
+        }
+        s_n[tid] = n; s_g[tid] = g; s_pr[tid] = pr;
+    }
+    __syncthreads();
+    // ---- write: a thread keeps ONE pixel pair and walks the channels (pair, n, g and the reciprocal of n hoisted).
+    // x / n is formed exactly as the hardware's own division sequence forms it for operands in the normal range
+    // (v_rcp_f64, two Newton steps, q = x r, one fma correction): same bits as `x / n`, a third of the instructions.
+    const int psh = pshift - 1, px = (tid & ((1 << psh) - 1)) << 1, cstep = HTPB >> psh;
+    if (px < np) {
+        const double n0 = s_n[px], n1 = s_n[px + 1], g0 = s_g[px], g1 = s_g[px + 1], p0 = s_pr[px], p1 = s_pr[px + 1];
+        const double r0 = exact_rcp(n0), r1 = exact_rcp(n1);
+        for (int c = tid >> psh; c < C; c += cstep) {
+            const f2_t xv = *reinterpret_cast<const f2_t *>(tile + ((size_t)c << pshift) + px);
+            double v0 = g0 * div_by(xv.x, n0, r0), v1 = g1 * div_by(xv.y, n1, r1);
+            if (p0 != 0.0) v0 = v0 / p0 * maxnorm;
+            if (p1 != 0.0) v1 = v1 / p1 * maxnorm;
+            __builtin_nontemporal_store((d2_h){v0, v1}, reinterpret_cast<d2_h *>(yp + (size_t)c * inner + px));
+        }
+    }
 }
 
 // ---------------------------------------------------------------- logmap0 + project  (hyperbolic.py:60)
@@ -357,6 +454,59 @@ __global__ void __launch_bounds__(HTPB) k_bilinear(const T *__restrict__ src, T 
 }
 
 
+// The same resize with VEC consecutive outputs per lane (16-byte non-temporal stores: the output is written once
+// and is 16-40x the input), one output row per blockIdx.y, and the row / column weights computed once per thread and
+// reused over the planes it walks (no 64-bit divisions per element).  Same arithmetic, bit-identical results.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(HTPB) k_bilinear_rows(const T *__restrict__ src, T *__restrict__ dst, int planes, int h, int w,
+                                                        int H, int W, T sh, T sw)
+{
+    const int y = blockIdx.y, xb = (blockIdx.x * HTPB + threadIdx.x) * VEC;
+    if (xb >= W) return;
+    const T fy = sh * (T)y;
+    int y0 = (int)fy;
+    y0 = y0 > h - 1 ? h - 1 : y0;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const T ly1 = fy - (T)y0, ly0 = (T)1 - ly1;
+    int x0[VEC], x1[VEC];
+    T w00[VEC], w01[VEC], w10[VEC], w11[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const T fx = sw * (T)(xb + j);
+        int a = (int)fx;
+        a = a > w - 1 ? w - 1 : a;
+        x0[j] = a;
+        x1[j] = a + (a < w - 1 ? 1 : 0);
+        const T lx1 = fx - (T)a, lx0 = (T)1 - lx1;
+        w00[j] = ly0 * lx0; w01[j] = ly0 * lx1; w10[j] = ly1 * lx0; w11[j] = ly1 * lx1;
+    }
+    for (int p = blockIdx.z; p < planes; p += gridDim.z) {
+        const T *r0 = src + ((size_t)p * h + y0) * w, *r1 = src + ((size_t)p * h + y1) * w;
+        T o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            T a = r0[x1[j]] * w01[j];
+            if constexpr (sizeof(T) == 8) {
+                a = __builtin_fma(r0[x0[j]], w00[j], a);
+                a = __builtin_fma(r1[x0[j]], w10[j], a);
+                a = __builtin_fma(r1[x1[j]], w11[j], a);
+            } else {
+                a = __builtin_fmaf(r0[x0[j]], w00[j], a);
+                a = __builtin_fmaf(r1[x0[j]], w10[j], a);
+                a = __builtin_fmaf(r1[x1[j]], w11[j], a);
+            }
+            o[j] = a;
+        }
+        T *q = dst + ((size_t)p * H + y) * W + xb;
+        if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));
+        else if constexpr (sizeof(T) == 4 && VEC == 4) __builtin_nontemporal_store((f4_t){o[0], o[1], o[2], o[3]}, reinterpret_cast<f4_t *>(q));
+        else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] = o[j];
+        }
+    }
+}
+
 // ================================================================ backward
 // Gradients of the head tail for training (core/models/classifier.py:553-554 under autograd).  Only the
 // parts that are not plain GEMMs are kernels here: the Jacobian-transpose product of expmap0+project,
@@ -515,7 +665,30 @@ extern "C" int halo_expmap0_project(const void *x, int x_dtype, double *y, int64
     if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_expmap0_project: curvature must be > 0 (Poincare ball)");
     const double ks = sqrt(fabs(-c) + 1e-15), rks = 1.0 / ks, maxnorm = (1.0 - 1e-5) / sqrt(fabs(-c) + 1e-15);
     hipStream_t st = (hipStream_t)stream;
-    if (x_dtype == HALO_F32)
+    // float32 planes (the head's case): LDS-tiled single-read kernel.  P pixels x C channels per workgroup, 32 KiB where
+    // that leaves P >= 32 (a full 128-byte line per channel row), up to 96 KiB otherwise
+    int pshift = 0;
+    size_t lds = 0;
+    if (x_dtype == HALO_F32 && inner >= 4 && inner % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+        !getenv("HALO_EXPMAP_PLANES")) {                       // A/B switch: the two-pass kernel
+        pshift = 8;                                             // P = 256
+        while (pshift > 5 && ((size_t)C << pshift) * 4 > 32 * 1024) --pshift;
+        while (pshift > 2 && (1ll << (pshift - 1)) >= inner) --pshift;      // tiny planes: no wider than needed
+        lds = ((size_t)C << pshift) * 4 + 3 * ((size_t)8 << pshift);
+        if (lds > 96 * 1024) pshift = 0;
+    }
+    if (pshift) {
+        static bool attr_set = false;
+        if (lds > 64 * 1024 && !attr_set) {
+            if (hipFuncSetAttribute((const void *)k_expmap0_project_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                return fail(HALO_E_LAUNCH, "halo_expmap0_project: cannot raise the dynamic LDS limit");
+            attr_set = true;
+        }
+        const long long tiles = (inner + (1ll << pshift) - 1) >> pshift;
+        hipLaunchKernelGGL(k_expmap0_project_tile, dim3((unsigned)(outer * tiles)), dim3(HTPB), lds, st, (const float *)x, y,
+                           (long long)outer, (int)C, (long long)inner, pshift, ks, rks, maxnorm);
+    }
+    else if (x_dtype == HALO_F32)
         hipLaunchKernelGGL((k_expmap0_project<float>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const float *)x, y, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
     else if (x_dtype == HALO_F64)
         hipLaunchKernelGGL((k_expmap0_project<double>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const double *)x, y, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
@@ -591,19 +764,138 @@ extern "C" int halo_hypermlr_logits(const double *x, const double *P, const doub
     return check_launch("halo_hypermlr_logits");
 }
 
+// Upsampling (the head tails' x1.6 ... x6.4): the per-lane source taps of the kernel above are gathers (4 per output),
+// and at 16 bytes stored per lane the texture-address path, not HBM, sets its pace.  Here a block first stages the
+// two source rows of BL_PC planes, restricted to the columns its 256*VEC outputs touch, in LDS with coalesced
+// loads, and the taps become LDS reads.  Same arithmetic, bit-identical results.
+constexpr int BL_PC = 4;
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src, T *__restrict__ dst, int planes, int h, int w,
+                                                       int H, int W, T sh, T sw, int span)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    T *tile = reinterpret_cast<T *>(smem_b);                       // [BL_PC][2][span]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int y = blockIdx.y, xb0 = blockIdx.x * HTPB * VEC, xb = xb0 + tid * VEC;
+    const T fy = sh * (T)y;
+    int y0 = (int)fy;
+    y0 = y0 > h - 1 ? h - 1 : y0;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const T ly1 = fy - (T)y0, ly0 = (T)1 - ly1;
+    // source columns this block needs
+    const int xl = xb0 + HTPB * VEC - 1 < W - 1 ? xb0 + HTPB * VEC - 1 : W - 1;
+    int sx0 = (int)(sw * (T)xb0), sx1 = (int)(sw * (T)xl);
+    sx0 = sx0 > w - 1 ? w - 1 : sx0;
+    sx1 = sx1 > w - 1 ? w - 1 : sx1;
+    sx1 += sx1 < w - 1 ? 1 : 0;
+    const int ncol = sx1 - sx0 + 1;                                // <= span (host bound)
+    int x0[VEC], x1[VEC];
+    T w00[VEC], w01[VEC], w10[VEC], w11[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int x = xb + j < W ? xb + j : W - 1;
+        const T fx = sw * (T)x;
+        int a = (int)fx;
+        a = a > w - 1 ? w - 1 : a;
+        x0[j] = a - sx0;
+        x1[j] = a + (a < w - 1 ? 1 : 0) - sx0;
+        const T lx1 = fx - (T)a, lx0 = (T)1 - lx1;
+        w00[j] = ly0 * lx0; w01[j] = ly0 * lx1; w10[j] = ly1 * lx0; w11[j] = ly1 * lx1;
+    }
+    for (int p0 = blockIdx.z * BL_PC; p0 < planes; p0 += gridDim.z * BL_PC) {
+        __syncthreads();                                           // the previous chunk's taps have been read
+        // wave wv stages tile rows wv and wv + 4 (row = plane-in-chunk * 2 + {y0, y1})
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = wave + 4 * rr, pl = row >> 1;
+            if (p0 + pl < planes) {
+                const T *sp = src + ((size_t)(p0 + pl) * h + ((row & 1) ? y1 : y0)) * w + sx0;
+                for (int col = lane; col < ncol; col += 64) tile[row * span + col] = sp[col];
+            }
+        }
+        __syncthreads();
+        if (xb < W) {
+#pragma unroll
+            for (int pl = 0; pl < BL_PC; ++pl) {
+                if (p0 + pl >= planes) break;
+                const T *r0 = tile + (pl * 2) * span, *r1 = r0 + span;
+                T o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    T a = r0[x1[j]] * w01[j];
+                    if constexpr (sizeof(T) == 8) {
+                        a = __builtin_fma(r0[x0[j]], w00[j], a);
+                        a = __builtin_fma(r1[x0[j]], w10[j], a);
+                        a = __builtin_fma(r1[x1[j]], w11[j], a);
+                    } else {
+                        a = __builtin_fmaf(r0[x0[j]], w00[j], a);
+                        a = __builtin_fmaf(r1[x0[j]], w10[j], a);
+                        a = __builtin_fmaf(r1[x1[j]], w11[j], a);
+                    }
+                    o[j] = a;
+                }
+                T *q = dst + ((size_t)(p0 + pl) * H + y) * W + xb;
+                if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));
+                else if constexpr (sizeof(T) == 4 && VEC == 4) __builtin_nontemporal_store((f4_t){o[0], o[1], o[2], o[3]}, reinterpret_cast<f4_t *>(q));
+                else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) q[j] = o[j];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int VEC>
+static void launch_bilinear_rows(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int64_t H, int64_t W, hipStream_t st)
+{
+    const T sh = H > 1 ? (T)(h - 1) / (T)(H - 1) : (T)0, sw = W > 1 ? (T)(w - 1) / (T)(W - 1) : (T)0;
+    const unsigned gx = (unsigned)cdiv(W, (int64_t)HTPB * VEC);
+    // enough blocks to fill the chip, each thread re-using its weights over the planes it walks
+    int64_t gz = cdiv(8192, (int64_t)gx * H);
+    gz = gz < 1 ? 1 : (gz > planes ? planes : gz);
+    if (gz > 65535) gz = 65535;
+    // source columns one block can touch: its 256*VEC outputs span sw*(256*VEC-1) source units, plus the +1 taps
+    const int64_t span = (int64_t)((double)sw * (double)(HTPB * VEC - 1)) + 4;
+    const size_t lds = (size_t)BL_PC * 2 * span * sizeof(T);
+    if (lds <= 32 * 1024 && !getenv("HALO_BILINEAR_ROWS")) {      // A/B switch: taps gathered from global memory
+        int64_t gzl = cdiv(8192, (int64_t)gx * H);
+        const int64_t chunks = cdiv(planes, BL_PC);
+        gzl = gzl < 1 ? 1 : (gzl > chunks ? chunks : gzl);
+        if (gzl > 65535) gzl = 65535;
+        hipLaunchKernelGGL((k_bilinear_lds<T, VEC>), dim3(gx, (unsigned)H, (unsigned)gzl), dim3(HTPB), lds, st, (const T *)src, (T *)dst,
+                           (int)planes, (int)h, (int)w, (int)H, (int)W, sh, sw, (int)span);
+        return;
+    }
+    hipLaunchKernelGGL((k_bilinear_rows<T, VEC>), dim3(gx, (unsigned)H, (unsigned)gz), dim3(HTPB), 0, st, (const T *)src, (T *)dst,
+                       (int)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
+}
+
 extern "C" int halo_bilinear_upsample(const void *src, void *dst, int dtype, int64_t planes, int64_t h, int64_t w, int64_t H,
                                       int64_t W, void *stream)
 {
     if (!src || !dst || planes <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_bilinear_upsample: null/empty argument");
+    if (dtype != HALO_F64 && dtype != HALO_F32) return fail(HALO_E_ARG, "halo_bilinear_upsample: bad dtype");
     hipStream_t st = (hipStream_t)stream;
-    const long long n = (long long)planes * H * W;
-    if (dtype == HALO_F64) {
-        const double sh = H > 1 ? (double)(h - 1) / (double)(H - 1) : 0.0, sw = W > 1 ? (double)(w - 1) / (double)(W - 1) : 0.0;
-        hipLaunchKernelGGL((k_bilinear<double>), dim3(nblocks(n)), dim3(HTPB), 0, st, (const double *)src, (double *)dst, (long long)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
-    } else if (dtype == HALO_F32) {
-        const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
-        hipLaunchKernelGGL((k_bilinear<float>), dim3(nblocks(n)), dim3(HTPB), 0, st, (const float *)src, (float *)dst, (long long)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
-    } else return fail(HALO_E_ARG, "halo_bilinear_upsample: bad dtype");
+    const bool rows = H <= 65535 && planes <= 0x7fffffff && !getenv("HALO_BILINEAR_FLAT");     // A/B switch: one element per thread
+    const bool a16 = ((uintptr_t)dst % 16) == 0;
+    if (rows && dtype == HALO_F64) {
+        if (W % 2 == 0 && a16) launch_bilinear_rows<double, 2>(src, dst, planes, h, w, H, W, st);
+        else launch_bilinear_rows<double, 1>(src, dst, planes, h, w, H, W, st);
+    } else if (rows) {
+        if (W % 4 == 0 && a16) launch_bilinear_rows<float, 4>(src, dst, planes, h, w, H, W, st);
+        else launch_bilinear_rows<float, 1>(src, dst, planes, h, w, H, W, st);
+    } else {
+        const long long n = (long long)planes * H * W;
+        if (dtype == HALO_F64) {
+            const double sh = H > 1 ? (double)(h - 1) / (double)(H - 1) : 0.0, sw = W > 1 ? (double)(w - 1) / (double)(W - 1) : 0.0;
+            hipLaunchKernelGGL((k_bilinear<double>), dim3(nblocks(n)), dim3(HTPB), 0, st, (const double *)src, (double *)dst, (long long)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
+        } else {
+            const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+            hipLaunchKernelGGL((k_bilinear<float>), dim3(nblocks(n)), dim3(HTPB), 0, st, (const float *)src, (float *)dst, (long long)planes, (int)h, (int)w, (int)H, (int)W, sh, sw);
+        }
+    }
     return check_launch("halo_bilinear_upsample");
 }
 

@@ -1179,3 +1179,49 @@ def test_bench_pool_images_and_branches_on_a_small_shape(dev):
         assert d["parity_vs_cpu"] is True and d["pipeline_tables_consistent"] is True, extra
         if extra[0] == "--pool-images":
             assert d["config"]["image_evaluations"] == 22 and d["steps"] == 6
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_head_kernel_variants_agree_bitwise(dev):
+    """Round-2 kernels of the head tail against the round-1 kernels they replace (kept behind A/B switches) and the
+    oracle: expmap0+project through an LDS tile (single read, hoisted exact division) vs the two-pass plane walk;
+    bilinear with LDS-staged taps vs global gathers vs one element per thread."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper, bilinear_align_corners
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(61)
+    for c in (1.0, 0.6):
+        m = HyperMapper(c=c)
+        for (B, C, h, w) in ((1, 256, 32, 64), (2, 64, 40, 72), (1, 8, 16, 32), (1, 512, 8, 16), (1, 5, 12, 20), (3, 19, 4, 4), (1, 64, 2, 6)):
+            z = (rng.standard_normal((B, C, h, w)) * 0.1).astype(np.float32)
+            z[0, :, 0, 0] = 0.0                                      # norm clamp
+            z[0, :, 1, 1] *= 400.0                                   # tanh clamp + projection
+            z[0, :, 1, 2] *= 30.0                                    # near the ball's boundary
+            if h > 2:
+                z[-1, :, 2, 3] = 3.0e18                              # huge finite values
+            a = m.expmap(t(z, dev), dim=1).cpu().numpy()
+            b = _with_env({"HALO_EXPMAP_PLANES": "1"}, lambda: m.expmap(t(z, dev), dim=1).cpu().numpy())
+            assert bits_equal(a, b), (c, C, h, w)
+            assert max_abs_diff(a, ho.expmap(z, c, dim=1)) < 1e-14
+            n = np.sqrt((a * a).sum(axis=1))
+            assert n.max() <= (1 - 1e-5) / math.sqrt(c) * (1 + 1e-12)
+    for dt in (np.float64, np.float32):
+        for (planes, hin, hout) in ((5, (16, 32), (64, 128)), (3, (40, 80), (64, 128)), (2, (10, 20), (64, 128)), (4, (23, 37), (50, 77)),
+                                    (1, (64, 128), (64, 128)), (7, (5, 7), (96, 130)), (2, (64, 96), (16, 24)), (9, (33, 65), (129, 1030))):
+            src = rng.standard_normal((1, planes) + hin).astype(dt)
+            a = bilinear_align_corners(t(src, dev), hout).cpu().numpy()
+            b = _with_env({"HALO_BILINEAR_ROWS": "1"}, lambda: bilinear_align_corners(t(src, dev), hout).cpu().numpy())
+            c_ = _with_env({"HALO_BILINEAR_FLAT": "1"}, lambda: bilinear_align_corners(t(src, dev), hout).cpu().numpy())
+            assert bits_equal(a, b) and bits_equal(a, c_), (dt, planes, hin, hout)
+            assert bits_equal(a, ho.bilinear(src, hout)), (dt, planes, hin, hout)
