@@ -380,6 +380,78 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const TL *__restrict__ 
     if (count) count[(size_t)b * hw + i] = cnt;
 }
 
+// 3 x 3 window (the only purity window the reference's drivers use: RADIUS_K = 1, and always for 'hyper'): the
+// sliding-window class histogram on an LDS label tile.  A 256-thread block covers 64 x 16 pixels; the 66 x 18 label
+// tile (halo included, out-of-image = -1) is staged once, each lane takes the 3 x 6 labels of its 4 consecutive
+// pixels into registers and walks the distinct classes of each 3 x 3 window in ascending order -- the same sums in
+// the same order as the generic kernel above, with no global re-scan per class.
+constexpr int RI_TW = 64, RI_TH = 16;
+
+template <typename TL>
+__global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__ pred, int H, int W, float logK,
+                                                          float *__restrict__ imp, float *__restrict__ count)
+{
+    __shared__ int lab[RI_TH + 2][RI_TW + 2 + 2];                  // +2: row stride 68 words
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int X0 = blockIdx.x * RI_TW, Y0 = blockIdx.y * RI_TH;
+    const long long hw = (long long)H * W;
+    const TL *pp = pred + (size_t)b * hw;
+    for (int e = tid; e < (RI_TH + 2) * (RI_TW + 2); e += TPB) {
+        const int ty = e / (RI_TW + 2), tx = e % (RI_TW + 2);
+        const int y = Y0 + ty - 1, x = X0 + tx - 1;
+        lab[ty][tx] = (y >= 0 && y < H && x >= 0 && x < W) ? (int)pp[(size_t)y * W + x] : -1;
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = (tid & 15) * 4;                  // 16 lanes x 4 pixels per tile row
+    const int y = Y0 + ly, xb = X0 + lx;
+    if (y >= H || xb >= W) return;
+    int v[3][6];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 6; ++dx) v[dy][dx] = lab[ly + dy][lx + dx];
+    const int ny = (y > 0 ? 1 : 0) + 1 + (y < H - 1 ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = xb + j;
+        if (x >= W) break;
+        const float cnt = (float)(ny * ((x > 0 ? 1 : 0) + 1 + (x < W - 1 ? 1 : 0)));
+        float a = 0.0f;
+        int cur = -1;
+        while (true) {
+            int nxt = 0x7fffffff;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) { const int q = v[dy][j + dx]; nxt = (q > cur && q < nxt) ? q : nxt; }
+            if (nxt == 0x7fffffff) break;
+            int n = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) n += v[dy][j + dx] == nxt ? 1 : 0;
+            const float d = (float)n / cnt;
+            a = a + (-d) * det_logf(d + 1e-6f);
+            cur = nxt;
+        }
+        imp[(size_t)b * hw + (size_t)y * W + x] = a / logK;
+        if (count) count[(size_t)b * hw + (size_t)y * W + x] = cnt;
+    }
+}
+
+template <typename TL>
+static void launch_region_impurity(const TL *pred, int64_t B, int64_t H, int64_t W, int k, float logK, float *imp, float *count,
+                                   hipStream_t st)
+{
+    if (k == 3 && cdiv(H, RI_TH) <= 65535 && B <= 65535 && !getenv("HALO_IMPURITY_GENERIC")) {     // A/B switch
+        hipLaunchKernelGGL((k_region_impurity3<TL>), dim3((unsigned)cdiv(W, RI_TW), (unsigned)cdiv(H, RI_TH), (unsigned)B), dim3(TPB), 0, st,
+                           pred, (int)H, (int)W, logK, imp, count);
+    } else {
+        hipLaunchKernelGGL((k_region_impurity<TL>), dim3((unsigned)cdiv(H * W, TPB), (unsigned)B), dim3(TPB), 0, st, pred, (int)H, (int)W, k,
+                           logK, imp, count);
+    }
+}
+
 // ---------------------------------------------------------------- entropy_conv + /count (floating_region.py:42-51,90,204)
 // k x k all-ones box SUM with zero padding, taps added in row-major order starting from +0.
 // count = in-bounds size of the pk x pk purity window for ripu / oracle_ripu / hyper, else 1.
@@ -951,7 +1023,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     }
     if (hist) {
         const float logK = (float)log((double)(pur_type == HALO_PUR_HYPER ? K : O));
-        hipLaunchKernelGGL((k_region_impurity<short>), grid1, block, 0, st, (const short *)pred, (int)H, (int)W, pksize, logK, (float *)imp_raw, (float *)nullptr);
+        launch_region_impurity<short>((const short *)pred, B, H, W, pksize, logK, (float *)imp_raw, (float *)nullptr, st);
         hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
         nblk_imp = nblk1;
     } else if (pur_type == HALO_PUR_NONE) {
@@ -1011,10 +1083,7 @@ extern "C" int halo_region_impurity(const int64_t *pred, int64_t B, int64_t H, i
 {
     if (!pred || !impurity || B <= 0 || H <= 0 || W <= 0 || K < 1) return fail(HALO_E_ARG, "halo_region_impurity: null/empty argument");
     if (ksize < 1 || !(ksize & 1)) return fail(HALO_E_ARG, "halo_region_impurity: window size must be odd");
-    const long long hw = (long long)H * W;
-    dim3 block(TPB), grid1((unsigned)cdiv(hw, TPB), (unsigned)B);
-    hipLaunchKernelGGL((k_region_impurity<long long>), grid1, block, 0, (hipStream_t)stream, (const long long *)pred, (int)H, (int)W,
-                       ksize, (float)log((double)K), impurity, count);
+    launch_region_impurity<long long>((const long long *)pred, B, H, W, ksize, (float)log((double)K), impurity, count, (hipStream_t)stream);
     return check_launch("halo_region_impurity");
 }
 

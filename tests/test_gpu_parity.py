@@ -1225,3 +1225,23 @@ def test_head_kernel_variants_agree_bitwise(dev):
             c_ = _with_env({"HALO_BILINEAR_FLAT": "1"}, lambda: bilinear_align_corners(t(src, dev), hout).cpu().numpy())
             assert bits_equal(a, b) and bits_equal(a, c_), (dt, planes, hin, hout)
             assert bits_equal(a, ho.bilinear(src, hout)), (dt, planes, hin, hout)
+
+
+def test_region_impurity_lds_tile_equals_generic_kernel(dev):
+    """The 3x3 sliding-window histogram on an LDS label tile vs the generic global re-scan kernel (A/B switch) and
+    the oracle, for label maps with many / few distinct classes, odd sizes, 1-pixel-wide maps."""
+    from halo_amd.core.active.floating_region import FloatingRegionScore
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(71)
+    for (H, W, K) in ((64, 128, 19), (37, 53, 100), (1, 70, 19), (90, 1, 7), (16, 64, 2), (130, 67, 19)):
+        f = FloatingRegionScore(in_channels=K, size=3, purity_type="ripu")
+        for kind in ("noise", "blobs"):
+            lab = rng.integers(0, K, (H, W))
+            if kind == "blobs":
+                lab = (ho.bilinear(rng.standard_normal((1, max(1, H // 8) + 1, max(1, W // 8) + 1)), (H, W))[0] * 2).astype(np.int64) % K
+            lab = lab.astype(np.int64)
+            imp, cnt = f.compute_region_impurity(t(lab, dev), K)
+            imp_g, cnt_g = _with_env({"HALO_IMPURITY_GENERIC": "1"}, lambda: f.compute_region_impurity(t(lab, dev), K))
+            assert bits_equal(imp.cpu().numpy(), imp_g.cpu().numpy()) and bits_equal(cnt.cpu().numpy(), cnt_g.cpu().numpy()), (H, W, K, kind)
+            want_i, want_c = ho.region_impurity(lab, K, 3)
+            assert bits_equal(imp.cpu().numpy(), want_i) and np.array_equal(cnt.cpu().numpy(), want_c), (H, W, K, kind)
