@@ -422,6 +422,169 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr_mfma(const double *__restrict
     }
 }
 
+// ---------------------------------------------------------------- HyperMLR, weights resident in LDS
+// Same operand layout and contraction as k_hypermlr_mfma, restructured around what that kernel waits for:
+//   * ALL of [-P | A^] (NT*16 rows x C channels, 98 KiB at C = 256) is staged in LDS once per workgroup, and the
+//     workgroup's 8 waves then walk pixel tiles on their own -- no barrier and no weight traffic inside the loop
+//     (the chunked kernel re-staged 12 KiB behind two barriers for every 32 channels);
+//   * 8 waves = two per SIMD sharing that one weight image: while one wave runs its VALU epilogue the other keeps
+//     the SIMD's matrix pipe busy (the f64 epilogue costs about as many issue cycles as the contraction);
+//   * a lane's two row tiles are the EVEN and ODD pixel of a pair, so one 16-byte load feeds both MFMA operands;
+//   * the epilogue shares one reciprocal of D between alpha and beta, and evaluates the projection quotient only
+//     in waves that hold a pixel beyond maxnorm.
+// Row stride of the weight image = C + pad doubles with (C + pad) mod 32 == 2: the 16 x 4 (row, channel) operand
+// fetch of a wave is then conflict-free on the 64 LDS banks.
+constexpr int MLRP_TPB = 512, MLRP_SK = 4, MLRP_RING = 4;
+
+template <typename TOUT, int NT>
+__global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__restrict__ x, const double *__restrict__ consts,
+                                                                int O, int C, int wstride, long long hw, long long tiles_per_img,
+                                                                long long ntiles, double K, TOUT *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
+    double *wts = reinterpret_cast<double *>(smem_m);                                        // [2*O][wstride]: rows -P 0..O-1, then A^ 0..O-1
+    double *stage = wts + (size_t)2 * O * wstride;                                           // per wave: px [O][32] | xa [O][32] | ||x||^2 [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    for (int j = wave; j < 2 * O; j += MLRP_TPB / 64) {
+        const double *srow = j < O ? nP + (size_t)j * C : An + (size_t)(j - O) * C;
+        for (int k = lane; k < C; k += 64) wts[(size_t)j * wstride + k] = srow[k];
+    }
+    __syncthreads();
+    // this lane's B-operand rows: column lc of tile n is (class, -P | A^) = tile 0: (lc, P)  tile 1: (lc, A)
+    // tile 2 of NT = 3: (16 + (lc & 7), lc >= 8)   tiles 2 / 3 of NT = 4: (16 + lc, P / A); columns of classes >= O are zero
+    int wrow[NT];
+    bool wok[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int cls = lc;
+        bool isA = n == 1;
+        if (n >= 2) {
+            if (NT == 3) { cls = 16 + (lc & 7); isA = lc >= 8; }
+            else { cls = 16 + lc; isA = n == 3; }
+        }
+        wok[n] = cls < O;
+        wrow[n] = ((isA ? O : 0) + (cls < O ? cls : 0)) * wstride;
+    }
+    const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
+    double *pxs = stage + (size_t)wave * (2 * O * 32 + 32), *xas = pxs + O * 32, *xs = xas + O * 32;
+    // x operands travel through a register ring of MLRP_RING stages of MLRP_SK k-steps (16 channels) each: the loads
+    // of stage s + RING - 1 are issued before the MFMAs of stage s, and the stream of stages runs ACROSS tile
+    // boundaries (the first stages of the wave's next tile are in flight during this tile's epilogue).
+    const int nst = C / (4 * MLRP_SK);                               // stages per tile; host: C % (4*SK*RING) == 0
+    const long long tile0 = (long long)blockIdx.x * (MLRP_TPB / 64) + wave, tstride = (long long)gridDim.x * (MLRP_TPB / 64);
+    // Loads are unconditional 16-byte pairs (host: hw even): a lane whose pixel pair lies beyond the image, or a
+    // look-ahead past the wave's last tile, reads a clamped valid address instead and its results are never stored.
+    struct TileRef { const double *q; long long b, p_base; };
+    auto tile_ref = [&](long long tile) {
+        TileRef t_;
+        const long long tl = tile < ntiles ? tile : ntiles - 1;
+        t_.b = tl / tiles_per_img;
+        t_.p_base = (tl % tiles_per_img) * 32;
+        long long pix0 = t_.p_base + 2 * lc;                        // this lane's pixel pair: row lc of tile m = 0 (even) and m = 1 (odd)
+        pix0 = pix0 + 1 < hw ? pix0 : hw - 2;
+        t_.q = x + (size_t)t_.b * C * hw + pix0;
+        return t_;
+    };
+    auto issue = [&](const TileRef &t_, int st, double (&dst)[MLRP_SK][2]) {
+#pragma unroll
+        for (int kk = 0; kk < MLRP_SK; ++kk) {
+            const d2_h v = *reinterpret_cast<const d2_h *>(t_.q + (size_t)(st * (4 * MLRP_SK) + kk * 4 + lk) * hw);
+            dst[kk][0] = v.x; dst[kk][1] = v.y;
+        }
+    };
+    double ring[MLRP_RING][MLRP_SK][2];
+    TileRef cur = tile_ref(tile0);
+#pragma unroll
+    for (int u = 0; u < MLRP_RING - 1; ++u) issue(cur, u, ring[u]);
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
+        const TileRef nxt = tile_ref(tile + tstride);
+        const long long b = cur.b, p_base = cur.p_base;
+        v4d_t acc[2][NT];
+        double ss[2] = {0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = (v4d_t){0, 0, 0, 0};
+        for (int s0 = 0; s0 < nst; s0 += MLRP_RING) {
+#pragma unroll
+            for (int u = 0; u < MLRP_RING; ++u) {
+                const int st = s0 + u, ahead = st + MLRP_RING - 1;  // stage `ahead` lives in slot ahead % RING = (u + RING - 1) % RING
+                if (ahead < nst) issue(cur, ahead, ring[(u + MLRP_RING - 1) % MLRP_RING]);
+                else issue(nxt, ahead - nst, ring[(u + MLRP_RING - 1) % MLRP_RING]);
+#pragma unroll
+                for (int kk = 0; kk < MLRP_SK; ++kk) {
+                    const int k = st * (4 * MLRP_SK) + kk * 4 + lk;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const double bf = wok[n] ? wts[wrow[n] + k] : 0.0;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][kk][m], bf, acc[m][n], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) ss[m] = __builtin_fma(ring[u][kk][m], ring[u][kk][m], ss[m]);
+                }
+            }
+        }
+        // ---- hand the accumulators to a flat (class, pixel) mapping through LDS: in the MFMA layout a lane would run
+        // the f64 epilogue 16 times per tile (8 rows x 2 class slots, the second slot 3/16 useful at 19 classes); flat,
+        // 32 pixels x O classes over 64 lanes is O/2 evaluations.  Pixel q = 2 * row + m; slot of (class o, pixel q) is
+        // o*32 + ((q + o) & 31): conflict-free for the column-wise writes and the row-wise reads alike.
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            double t_ = ss[m] + __shfl_xor(ss[m], 16);               // ||x||^2 of row lc: four channel-residue partial sums
+            t_ = t_ + __shfl_xor(t_, 32);
+            if (lk == 0) xs[2 * lc + m] = t_;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 2 * (lk + 4 * r) + m;
+                if (lc < O) {
+                    pxs[lc * 32 + ((q + lc) & 31)] = acc[m][0][r];
+                    xas[lc * 32 + ((q + lc) & 31)] = acc[m][1][r];
+                }
+                if constexpr (NT == 3) {
+                    const int o = 16 + (lc & 7);
+                    if (o < O) (lc < 8 ? pxs : xas)[o * 32 + ((q + o) & 31)] = acc[m][2][r];
+                } else if constexpr (NT == 4) {
+                    const int o = 16 + lc;
+                    if (o < O) {
+                        pxs[o * 32 + ((q + o) & 31)] = acc[m][2][r];
+                        xas[o * 32 + ((q + o) & 31)] = acc[m][3][r];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes before its own reads
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int e = lane; e < O * 32; e += 64) {
+            const int o = e >> 5, q = e & 31;
+            const double px = pxs[o * 32 + ((q + o) & 31)], xa = xas[o * 32 + ((q + o) & 31)];
+            const double nx = __builtin_sqrt(xs[q]), xx = nx * nx;            // torch.norm(x)**2, hyperbolic.py:136
+            const double ppo = pp[o], ano = anorm[o], pao = pa[o];
+            const double sqsq = ((K * xx) * K) * ppo;
+            const double base = 1.0 + (2.0 * K) * px;
+            const double Aa = base + K * xx;
+            const double Bb = 1.0 - K * ppo;
+            const double rD = 1.0 / clamp_min_nanprop(base + sqsq, 1e-12);   // one reciprocal for alpha and beta
+            const double al = Aa * rD, be = Bb * rD;
+            const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
+            const double sq = __builtin_sqrt(mob);
+            double pn = 1.0;
+            if (__any(sq > maxnorm)) pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;   // rare: beyond the ball
+            const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
+            const double md = (be * xa + al * pao) * pn;
+            const double lamb = 2.0 / clamp_min_nanprop(1.0 - K * mp, 1e-12);
+            const double sine = (sqK * md) * lamb;
+            const long long p_ = p_base + q;
+            if (p_ < hw) out[((size_t)b * O + o) * hw + p_] = (TOUT)(((2.0 / sqK) * ano) * asinh_det(sine));
+        }
+        __builtin_amdgcn_wave_barrier();      // the next tile's accumulators reuse the staging rows
+        cur = nxt;
+    }
+}
+
 // ---------------------------------------------------------------- bilinear, align_corners=True
 // out = fma(v11,w11, fma(v10,w10, fma(v00,w00, v01*w01))), w_ij = ly_i*lx_j, weights in the tensor's dtype
 template <typename T>
@@ -745,9 +908,36 @@ extern "C" int halo_hypermlr_logits(const double *x, const double *P, const doub
     double *consts = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)cdiv(O, 64)), dim3(64), 0, st, P, A, (int)O, (int)C, consts);
     // matrix-core path: up to 32 classes (two 16-column tiles per operand); anything else takes the VALU kernel
+    if (out_dtype != HALO_F32 && out_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_hypermlr_logits: bad out dtype");
+    // weights-resident matrix-core kernel when the [-P | A^] image plus the per-wave staging fits LDS
+    if (O <= 32 && getenv("HALO_MLR_VALU") == nullptr && getenv("HALO_MLR_CHUNKED") == nullptr) {
+        const int NT = O <= 16 ? 2 : (O <= 24 ? 3 : 4);
+        const int wstride = (int)C + (int)(((2 - C) % 32 + 32) % 32);            // (C + pad) mod 32 == 2
+        const size_t lds = ((size_t)2 * O * wstride + (size_t)(MLRP_TPB / 64) * (2 * O * 32 + 32)) * 8;
+        if (lds <= 160 * 1024 && C % (4 * MLRP_SK * MLRP_RING) == 0 && hw % 2 == 0 && hw >= 2 &&      // the stage ring must line up across tiles
+            ((uintptr_t)x % 16) == 0) {
+            const long long tiles_per_img = cdiv(hw, 32), ntiles = tiles_per_img * B;
+            long long gx = cdiv(ntiles, MLRP_TPB / 64);
+            gx = gx > 256 ? 256 : gx;                                              // one resident workgroup per CU, persistent over tiles
+#define HALO_MLRP(T, NT_)                                                                                                          \
+    {                                                                                                                             \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) {                                                                                                          \
+            if (hipFuncSetAttribute((const void *)k_hypermlr_mfma_res<T, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+                return fail(HALO_E_LAUNCH, "halo_hypermlr_logits: cannot raise the dynamic LDS limit");                            \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_hypermlr_mfma_res<T, NT_>), dim3((unsigned)gx), dim3(MLRP_TPB), lds, st, x, (const double *)consts, (int)O, \
+                           (int)C, wstride, (long long)hw, tiles_per_img, ntiles, c, (T *)out);                                   \
+    }
+            if (out_dtype == HALO_F32) { if (NT == 2) HALO_MLRP(float, 2) else if (NT == 3) HALO_MLRP(float, 3) else HALO_MLRP(float, 4) }
+            else { if (NT == 2) HALO_MLRP(double, 2) else if (NT == 3) HALO_MLRP(double, 3) else HALO_MLRP(double, 4) }
+#undef HALO_MLRP
+            return check_launch("halo_hypermlr_logits");
+        }
+    }
     if (O <= 32 && getenv("HALO_MLR_VALU") == nullptr) {
         dim3 gridm((unsigned)cdiv(hw, (HTPB / 64) * MLR_MT * 16), (unsigned)B);
-        if (out_dtype != HALO_F32 && out_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_hypermlr_logits: bad out dtype");
 #define HALO_MLR(T, NT_) hipLaunchKernelGGL((k_hypermlr_mfma<T, NT_>), gridm, dim3(HTPB), 0, st, x, (const double *)consts, (int)O, (int)C, (long long)hw, c, (T *)out)
         if (out_dtype == HALO_F32) { if (O <= 16) HALO_MLR(float, 2); else if (O <= 24) HALO_MLR(float, 3); else HALO_MLR(float, 4); }
         else { if (O <= 16) HALO_MLR(double, 2); else if (O <= 24) HALO_MLR(double, 3); else HALO_MLR(double, 4); }

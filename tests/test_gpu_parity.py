@@ -36,6 +36,19 @@ def t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def bits_equal(a, b):
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
@@ -620,7 +633,8 @@ def test_hypermlr_matrix_core_path_matches_valu_path(golden, dev):
     from halo_amd.core.utils.hyperbolic import HyperMLR
     from oracle import halo_oracle as ho
     rng = np.random.default_rng(21)
-    for (B, C, O, h, w) in ((1, 64, 19, 20, 36), (2, 256, 19, 16, 24), (1, 10, 16, 7, 9), (1, 33, 3, 5, 5), (1, 8, 32, 4, 13)):
+    for (B, C, O, h, w) in ((1, 64, 19, 20, 36), (2, 256, 19, 16, 24), (1, 10, 16, 7, 9), (1, 33, 3, 5, 5), (1, 8, 32, 4, 13),
+                            (3, 64, 19, 9, 7), (1, 256, 19, 33, 66), (2, 20, 24, 1, 1)):
         x = ho.expmap((rng.standard_normal((B, C, h, w)) * 0.2).astype(np.float32), 1.0, dim=1)
         x[0, :, 0, 0] = 0.0
         mlr = HyperMLR(C, O, c=1.0).to(dev)
@@ -634,8 +648,9 @@ def test_hypermlr_matrix_core_path_matches_valu_path(golden, dev):
                 v = mlr(t(x, dev)).cpu().numpy()
             finally:
                 os.environ.pop("HALO_MLR_VALU", None)
-        assert max_abs_diff(a, want) < 1e-11 and max_abs_diff(v, want) < 1e-11
-        assert max_abs_diff(a, v) < 1e-12
+            ch = _with_env({"HALO_MLR_CHUNKED": "1"}, lambda: mlr(t(x, dev)).cpu().numpy())       # round-1 matrix-core kernel
+        assert max_abs_diff(a, want) < 1e-11 and max_abs_diff(v, want) < 1e-11 and max_abs_diff(ch, want) < 1e-11
+        assert max_abs_diff(a, v) < 1e-12 and max_abs_diff(a, ch) < 1e-12
         assert np.abs(a32 - want.astype(np.float32)).max() < 1e-5
     # 33 classes: more than two column tiles -> VALU kernel
     mlr = HyperMLR(8, 33, c=1.0).to(dev)
@@ -1179,19 +1194,6 @@ def test_bench_pool_images_and_branches_on_a_small_shape(dev):
         assert d["parity_vs_cpu"] is True and d["pipeline_tables_consistent"] is True, extra
         if extra[0] == "--pool-images":
             assert d["config"]["image_evaluations"] == 22 and d["steps"] == 6
-
-
-def _with_env(env, fn):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return fn()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_head_kernel_variants_agree_bitwise(dev):
