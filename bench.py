@@ -52,7 +52,7 @@ def parse():
                     help="score exactly this many image evaluations over all ranks (overrides --steps; 2975 = configs[2], "
                          "the Cityscapes train list), the last step of a rank being a partial batch")
     ap.add_argument("--batch", type=int, default=16, help="images per step and rank")
-    ap.add_argument("--depth", type=int, default=0, help="batches in flight (selection slots); 0 = 3 for f64, 6 for f32")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight (selection slots)")
     ap.add_argument("--ring", type=int, default=32, help="distinct resident images per rank (two batches: consecutive "
                                                          "steps read different images)")
     ap.add_argument("--branch", choices=["halo", "ripu", "hyper"], default="halo",
@@ -317,8 +317,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == world
     fdtype = torch.float64 if a.feat_dtype == "f64" else torch.float32
-    if a.depth <= 0:
-        a.depth = 3 if a.feat_dtype == "f64" else 6
+    a.depth = max(1, a.depth)
     Hh, Ww, C, B = a.height, a.width, a.channels, a.batch
     R = max(B, (a.ring // B) * B)
     n_regions = math.ceil(Hh * Ww * (0.05 / 5) / 9)                    # build.py:148-150 -> 2331

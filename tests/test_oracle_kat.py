@@ -145,3 +145,42 @@ def test_elementary_functions_accuracy():
         want = mp.log(mp.mpf(float(x)))
         ulp = float(np.spacing(abs(float(want)))) or 5e-324
         assert abs(mp.mpf(got) - want) <= 1.0 * ulp
+
+
+def test_float32_embedding_radius_brackets_both_artanh_conventions():
+    """VERDICT r1 (geoopt, parity unpinned): for a FLOAT32 embedding the radius map is
+    dist0 = 2/sqrt(c) * artanh(sqrt(c)*||x||) evaluated on float32 data.  The fixtures' geoopt stand-in casts the
+    artanh argument to float64 and back; current geoopt (as recalled, not reachable here) may evaluate
+    0.5*(log1p(z) - log1p(-z)) in the input dtype.  Known answers (mpmath on the SAME float32 norm) bracket the
+    question: both conventions and the oracle stay within 1.5 float32 ulp of the exact value, the oracle equals the
+    float64 convention exactly, and the two conventions differ from each other by at most 2 ulp -- three orders of
+    magnitude inside the 1e-4 score tolerance; only a pick whose runner-up is closer than that could depend on it.
+    (The float64 embedding of HYPER=True, the reference's default, is unaffected: it has one convention.)"""
+    rng = np.random.default_rng(11)
+    worst = {"oracle": 0.0, "f32": 0.0, "f64": 0.0, "between": 0.0}
+    for scale in (0.02, 0.1, 0.3, 0.6):
+        x = (rng.standard_normal((200, 16)) * scale / 4.0).astype(np.float32)
+        nrm = np.sqrt((x.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32)).astype(np.float32)
+        keep = nrm < 0.999
+        x, nrm = x[keep], nrm[keep]
+        got = ho.dist0(x, 1.0)                                           # oracle, float32 in -> float32 out
+        assert got.dtype == np.float32
+        # the oracle's own float32 norm is a sequential fma chain: recompute exactly that
+        ssq = np.zeros(len(x), np.float32)
+        for j in range(x.shape[1]):
+            ssq = (x[:, j].astype(np.float64) * x[:, j].astype(np.float64) + ssq.astype(np.float64)).astype(np.float32)
+        n32 = np.sqrt(ssq).astype(np.float32)
+        z = np.minimum(n32, np.float32(1.0 - 1e-7)).astype(np.float32)
+        conv64 = (2.0 * (0.5 * (np.log1p(z.astype(np.float64)) - np.log1p(-z.astype(np.float64)))).astype(np.float32)).astype(np.float32)
+        conv32 = (np.float32(2.0) * (np.float32(0.5) * (np.log1p(z) - np.log1p(-z)))).astype(np.float32)
+        exact = np.array([float(2 * mp.atanh(mp.mpf(float(v)))) for v in z])
+        ulp = np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
+        worst["oracle"] = max(worst["oracle"], float(np.max(np.abs(got.astype(np.float64) - exact) / ulp)))
+        worst["f64"] = max(worst["f64"], float(np.max(np.abs(conv64.astype(np.float64) - exact) / ulp)))
+        worst["f32"] = max(worst["f32"], float(np.max(np.abs(conv32.astype(np.float64) - exact) / ulp)))
+        worst["between"] = max(worst["between"], float(np.max(np.abs(conv32.astype(np.float64) - conv64.astype(np.float64)) / ulp)))
+        assert np.array_equal(got, conv64), "the oracle follows the float64-artanh convention of the fixtures' stand-in"
+    assert worst["oracle"] <= 1.5 and worst["f64"] <= 1.5 and worst["f32"] <= 2.5, worst
+    assert worst["between"] <= 3.0, worst
+    # in absolute terms: radius <= 12.3, float32 ulp there is 9.5e-7 -> the conventions agree to 3e-6 << 1e-4
+    assert worst["between"] * 9.6e-7 < 1e-4

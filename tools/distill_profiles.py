@@ -1,0 +1,125 @@
+"""Turn gpurun_out/r02/ (tools/collect_profiles.sh on an MI355X box) into the tracked summaries under profiles/."""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r02")
+DST = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern))
+    return f[0] if f else None
+
+
+def copy_json(name, dst):
+    p = os.path.join(SRC, name)
+    if not os.path.exists(p):
+        return None
+    lines = [ln for ln in open(p) if ln.startswith("{")]
+    if not lines:
+        return None
+    d = json.loads(lines[-1])
+    json.dump(d, open(os.path.join(DST, dst), "w"), indent=1)
+    return d
+
+
+def stats_csv(pattern, dst, top=40):
+    f = one(pattern)
+    if not f:
+        return
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(DST, dst), "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows[:top]:
+            w.writerow([r["Name"][:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+
+def counters(pattern):
+    f = one(pattern)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if f:
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def durations(pattern, key):
+    f = one(pattern)
+    out = []
+    if f:
+        for r in csv.DictReader(open(f)):
+            if key in r["Kernel_Name"]:
+                out.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    return out
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    d = copy_json("bench_default.json", "r02_bench_default.json")
+    copy_json("bench_under_rocprof.json", "r02_bench_under_rocprof.json")
+    for v in ("f32", "lowres", "c512", "ripu", "hyper", "pool2975"):
+        copy_json("bench_%s.json" % v, "r02_bench_%s.json" % v)
+    stats_csv("trace/*/*_kernel_stats.csv", "r02_kernel_stats.csv")
+    stats_csv("trace_ripu/*/*_kernel_stats.csv", "r02_kernel_stats_ripu.csv", 25)
+    stats_csv("trace_hyper/*/*_kernel_stats.csv", "r02_kernel_stats_hyper.csv", 25)
+    stats_csv("trace_select/*/*_kernel_stats.csv", "r02_kernel_stats_select_tool.csv", 25)
+    for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt"):
+        p = os.path.join(SRC, t)
+        if os.path.exists(p):
+            keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]
+            open(os.path.join(DST, "r02_" + t), "w").writelines(keep)
+    # ---- HBM traffic of the roofline kernel (two separate --pmc passes; gfx950: FETCH_SIZE doubled)
+    fetch, write = counters("pmc_fetch/*/*counter_collection.csv"), counters("pmc_write/*/*counter_collection.csv")
+    per = {}
+    feat = None
+    for k in fetch:
+        per[short(k)] = {"FETCH_SIZE_raw": round(sum(fetch[k]["FETCH_SIZE"]) / max(1, len(fetch[k]["FETCH_SIZE"])), 1)}
+        if "k_feat_reduce" in k:
+            feat = k
+    for k in write:
+        per.setdefault(short(k), {})["WRITE_SIZE"] = round(sum(write[k]["WRITE_SIZE"]) / max(1, len(write[k]["WRITE_SIZE"])), 1)
+    if feat:
+        f_kb = sum(fetch[feat]["FETCH_SIZE"]) / len(fetch[feat]["FETCH_SIZE"])
+        wk = [k for k in write if "k_feat_reduce" in k][0]
+        w_kb = min(write[wk]["WRITE_SIZE"])
+        B, H, W, C, O = 16, 1024, 2048, 256, 19
+        alg = B * H * W * (C * 8 + 8 + O * 4 + 4)
+        hbm = int(2 * f_kb * 1024 + w_kb * 1024)
+        json.dump({"round": 2, "kernel": short(feat), "batch": B, "dtype": "f64", "shape_HWCO": [H, W, C, O],
+                   "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
+                              "--cpu-images 0 --ring 16 (two separate passes)",
+                   "FETCH_SIZE_KB_avg_per_launch": f_kb, "WRITE_SIZE_KB_min_per_launch": w_kb,
+                   "correction": "gfx950: FETCH_SIZE reports 1/2 of a 16-B/lane coalesced streaming read (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
+                   "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
+                   "per_kernel_KB": per}, open(os.path.join(DST, "r02_pmc_summary.json"), "w"), indent=1)
+    # ---- HyperMLR on the matrix cores
+    mlr = counters("pmc_mlr/*/*counter_collection.csv")
+    clk = counters("pmc_mlr_clk/*/*counter_collection.csv")
+    for k in mlr:
+        if "hypermlr" in k:
+            c = {n: sum(v) / len(v) for n, v in mlr[k].items()}
+            dur = durations("pmc_mlr/*/*kernel_trace.csv", "hypermlr")
+            gui = [sum(v["GRBM_GUI_ACTIVE"]) / len(v["GRBM_GUI_ACTIVE"]) for kk, v in clk.items() if "hypermlr" in kk]
+            dur_clk = durations("pmc_mlr_clk/*/*kernel_trace.csv", "hypermlr")
+            cycles = gui[0] / 8 if gui else None          # summed over the 8 XCDs
+            util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cycles if cycles else None
+            json.dump({"round": 2, "kernel": short(k), "shape": "x (1,256,1024,2048) f64, 19 classes, float32 logits",
+                       "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_mlr.py ; second pass --pmc GRBM_GUI_ACTIVE",
+                       "counters_avg_per_launch": c, "duration_ms": dur, "duration_ms_clock_pass": dur_clk,
+                       "shader_cycles_per_launch": cycles, "effective_clock_GHz": (cycles / (sum(dur_clk) / len(dur_clk) * 1e-3) / 1e9) if cycles and dur_clk else None,
+                       "mfma_busy_cycles_per_SIMD": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024,
+                       "mfma_utilisation": util, "note": "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (64 per v_mfma_f64_16x16x4_f64) summed over 1024 SIMDs; "
+                                                         "f64 MFMA and f64 VALU share the FP64 units, so the epilogue's VALU time adds to, not overlaps with, the MFMA time"},
+                      open(os.path.join(DST, "r02_mfma_head.json"), "w"), indent=1)
+    print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith("r02_")))
+    if d:
+        print("default bench:", d["value"], d["unit"], "roofline", d["roofline"])
+
+
+if __name__ == "__main__":
+    main()
