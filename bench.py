@@ -67,6 +67,9 @@ def parse():
                          "RegionSelection boundary: x4 low-res head outputs, upsampling fused into the scorer (N1)")
     ap.add_argument("--cpu-images", type=int, default=8, help="timed images in the CPU-baseline sample, after one "
                                                               "untimed warm-up image (0 = skip)")
+    ap.add_argument("--resets", choices=["score", "side"], default="score",
+                    help="where the per-batch round-1 state resets run: on the scoring stream (default) or on a low-priority "
+                         "housekeeping stream right after the slot's selection (tuning aid)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
@@ -116,7 +119,8 @@ BRANCHES = {   # name -> (unc_type, pur_type, normalize, mask radius, K)
 class Pipeline:
     """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
 
-    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False, branch="halo"):
+    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False, branch="halo",
+                 resets="score"):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
@@ -137,6 +141,9 @@ class Pipeline:
         self.active = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
         self.selected = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
         self.amask = [torch.full((B, Hh, Ww), 255, dtype=torch.int64, device=dev) for _ in range(D)]
+        self.resets = resets
+        self.s_house = torch.cuda.Stream(dev)
+        self.reset_done = [torch.cuda.Event() for _ in range(D)]
         self.scored = [torch.cuda.Event() for _ in range(D)]
         self.selected_done = [torch.cuda.Event() for _ in range(D)]
         self.ev = []                       # (start, stop) HIP events around k_feat_reduce
@@ -170,13 +177,16 @@ class Pipeline:
             evs = (self.lib.halo_event_create(), self.lib.halo_event_create())
             self.ev.append(evs)
         with torch.cuda.stream(self.s_score):
-            self.s_score.wait_event(self.selected_done[k])          # buffers k free again
             # round-1 state for this batch (the loader's job in the reference, cityscapes.py:245-251).
-            # Kept on the scoring stream: moving the three fills to the slot's select stream measured
+            # Kept on the scoring stream by default: moving the three fills to the slot's select stream measured
             # 5-8 % SLOWER end to end (they then run at high priority beside the feature stream).
-            self.active[k].zero_()
-            self.selected[k].zero_()
-            self.amask[k].fill_(255)
+            if self.resets == "score" or self.step_no < self.D:
+                self.s_score.wait_event(self.selected_done[k])      # buffers k free again
+                self.active[k].zero_()
+                self.selected[k].zero_()
+                self.amask[k].fill_(255)
+            else:
+                self.s_score.wait_event(self.reset_done[k])
             # all three output maps of FloatingRegionScore.forward are written (floating_region.py:217)
             if self.lowres:
                 sc, self.imp, self.unc_map = score_maps_lowres(lb, fb, self.size, self.unc, self.pur, self.norm, gb, ksize=3,
@@ -196,6 +206,13 @@ class Pipeline:
             if self.use_dist:      # the path's one exchange step: per-image pick tables to every rank, ONE collective
                 self.gathered[k] = gather_tables(self.tables[k][:b], self.counts[k][:b], self.world * b)
             self.selected_done[k].record(self.s_sel[k])
+        if self.resets == "side":
+            with torch.cuda.stream(self.s_house):
+                self.s_house.wait_event(self.selected_done[k])
+                self.active[k].zero_()
+                self.selected[k].zero_()
+                self.amask[k].fill_(255)
+                self.reset_done[k].record(self.s_house)
         self.last = (k, lo, b)
         self.slot_lo[k] = (lo, b)
         self.step_no += 1
@@ -327,7 +344,7 @@ def main():
     if lowres:
         a.cpu_images = 0
     feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch, a.resets)
 
     # per-rank schedule: full batches, plus a partial last one when --pool-images does not divide evenly
     if a.pool_images > 0:

@@ -317,8 +317,73 @@ __global__ void __launch_bounds__(256) k_sel_scatter(BinWs ws, BinGeom g)
     }
 }
 
+// ------------------------------------------------------------------ resolve one bin (one wave)
+// The survivors of a bin -- candidates no earlier pick suppresses -- are taken in exact (value desc, w asc, h asc)
+// order: arg-max over the wave, commit (pick list, pick grid), kill the survivors inside the new window, repeat.
+// Returns 0 (bin done) or 1 (n_regions reached).  With a single survivor alive the arg-max is a lane read.
+template <int R>
+__device__ __forceinline__ int resolve_bin(const unsigned long long *skey, const unsigned *spos, unsigned sc, int lane, int r, int cs,
+                                           const BinGeom &g, unsigned char *grid, unsigned *plist, int &np)
+{
+    Cand e[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const unsigned idx = lane + 64 * i;
+        const bool ok = idx < sc;
+        const unsigned ic = ok ? idx : 0u;
+        const unsigned long long k = skey[ic];
+        const unsigned p = spos[ic];
+        e[i].key = ok ? k : 0ull;                                // 0 = dead (below every real key)
+        e[i].pos = ok ? p : 0xffffffffu;
+    }
+    while (true) {
+        Cand best = e[0];
+#pragma unroll
+        for (int i = 1; i < R; ++i) {
+            const bool take = better(e[i], best);
+            best.key = take ? e[i].key : best.key;
+            best.pos = take ? e[i].pos : best.pos;
+        }
+        const unsigned long long am = __ballot(best.key != 0ull);
+        if (am == 0ull) return 0;
+        // arg-max under (key desc, pos asc).  Survivors of one bin lie in one narrow value slice: their keys usually
+        // share the high word and are distinct, so the common case is ONE 32-bit DPP reduction (the general form is three)
+        const unsigned hi = (unsigned)(best.key >> 32), lo = (unsigned)best.key;
+        const bool alive = best.key != 0ull;
+        Cand top;
+        const int l0 = (int)__builtin_ctzll(am);
+        if ((am & (am - 1ull)) == 0ull) {                        // exactly one lane holds a live survivor
+            top.key = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, l0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, l0);
+            top.pos = (unsigned)__builtin_amdgcn_readlane((int)best.pos, l0);
+        } else {
+            unsigned mh = (unsigned)__builtin_amdgcn_readlane((int)hi, l0);
+            if (__ballot(alive && hi != mh) != 0ull) mh = wave_umax(alive ? hi : 0u);
+            const unsigned ml = wave_umax((alive && hi == mh) ? lo : 0u);
+            const bool tie = alive && hi == mh && lo == ml;
+            const unsigned long long tm = __ballot(tie);
+            top.key = ((unsigned long long)mh << 32) | ml;
+            if ((tm & (tm - 1ull)) == 0ull) top.pos = (unsigned)__builtin_amdgcn_readlane((int)best.pos, (int)__builtin_ctzll(tm));
+            else top.pos = ~wave_umax(tie ? ~best.pos : 0u);
+        }
+        const int px = (int)(top.pos >> 16), py = (int)(top.pos & 0xffffu);
+        if (lane == 0) {                                         // the pick table's (h, w, value) rows are written by k_sel_apply
+            plist[np] = top.pos;
+            const int pcx = (int)__umulhi((unsigned)px, g.cmul), pcy = (int)__umulhi((unsigned)py, g.cmul);
+            grid[(pcy + 1) * g.gstride + pcx + 1] = (unsigned char)(1 + (((py - pcy * cs) << 4) | (px - pcx * cs)));
+        }
+        ++np;
+        if (np >= g.n_regions) return 1;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ex = (int)(e[i].pos >> 16), ey = (int)(e[i].pos & 0xffffu);
+            const bool hit = (unsigned)(ex - px + r) <= (unsigned)(2 * r) && (unsigned)(ey - py + r) <= (unsigned)(2 * r);
+            e[i].key = hit ? 0ull : e[i].key;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the sweep
-__global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, double *__restrict__ picks, int *__restrict__ n_picked)
+__global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *__restrict__ n_picked)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *grid = smem;                                               // pick grid, one byte per cell (+ border)
@@ -352,6 +417,12 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, doubl
     unsigned npos = tid < ntot ? cpos[tid] : 0u;
     const int r = g.mrad, cs = g.cs;
 
+#ifdef HALO_SWEEP_STAMPS
+    unsigned long long t_f = 0, t_a = 0, t_r = 0, t_b = 0, t0 = __builtin_amdgcn_s_memtime(), nb = 0;
+#define STAMP(acc) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
+#else
+#define STAMP(acc)
+#endif
     for (unsigned f = 0; f < nf && !fin; ++f) {
         if (f + 1 > fw0 + fwn || fwn == 0) {     // stage the next window of bin offsets
             lds_barrier();
@@ -405,61 +476,35 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, doubl
                 if (alive && slot < (unsigned)SW_SURV) { skey[slot] = key; spos[slot] = pos; }
             }
         }
+        STAMP(t_f)
         lds_barrier();
+        STAMP(t_a)
         // ---- resolve: wave 0 takes the survivors in exact order
         if (wave == 0) {
             const unsigned sc = ctl[0];
             int state = 0;
             if (sc > (unsigned)SW_SURV) state = 2;                           // more unsuppressed ties than fit: hand over
             else if (sc) {
-                Cand e[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned idx = lane + 64 * i;
-                    const bool ok = idx < sc;
-                    const unsigned ic = ok ? idx : 0u;
-                    const unsigned long long k = skey[ic];
-                    const unsigned p = spos[ic];
-                    e[i].key = ok ? k : 0ull;                                // 0 = dead (below every real key)
-                    e[i].pos = ok ? p : 0xffffffffu;
-                }
-                while (true) {
-                    Cand best = e[0];
-#pragma unroll
-                    for (int i = 1; i < 4; ++i) {
-                        const bool take = better(e[i], best);
-                        best.key = take ? e[i].key : best.key;
-                        best.pos = take ? e[i].pos : best.pos;
-                    }
-                    if (__ballot(best.key != 0ull) == 0ull) break;
-                    const Cand top = wave_best(best);
-                    const int px = (int)(top.pos >> 16), py = (int)(top.pos & 0xffffu);
-                    if (lane == 0) {
-                        plist[np] = top.pos;
-                        if (picks) {
-                            double *pk = picks + ((size_t)b * g.n_regions + np) * 3;
-                            pk[0] = (double)py;
-                            pk[1] = (double)px;
-                            pk[2] = key_value(top.key);
-                        }
-                        const int pcx = (int)__umulhi((unsigned)px, g.cmul), pcy = (int)__umulhi((unsigned)py, g.cmul);
-                        grid[(pcy + 1) * g.gstride + pcx + 1] = (unsigned char)(1 + (((py - pcy * cs) << 4) | (px - pcx * cs)));
-                    }
-                    ++np;
-                    if (np >= g.n_regions) { state = 1; break; }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int ex = (int)(e[i].pos >> 16), ey = (int)(e[i].pos & 0xffffu);
-                        const bool hit = (unsigned)(ex - px + r) <= (unsigned)(2 * r) && (unsigned)(ey - py + r) <= (unsigned)(2 * r);
-                        e[i].key = hit ? 0ull : e[i].key;
-                    }
-                }
+                // R survivors per lane: one when the bin leaves at most 64 (the common case), else four
+                if (sc <= 64u) state = resolve_bin<1>(skey, spos, sc, lane, r, cs, g, grid, plist, np);
+                else state = resolve_bin<4>(skey, spos, sc, lane, r, cs, g, grid, plist, np);
             }
             if (lane == 0) { ctl[0] = 0; ctl[1] = (unsigned)state; }
         }
+        STAMP(t_r)
         lds_barrier();
         fin = (int)ctl[1];
+        STAMP(t_b)
+#ifdef HALO_SWEEP_STAMPS
+        ++nb;
+#endif
     }
+#ifdef HALO_SWEEP_STAMPS
+    if (tid == 0) {      // diagnostic build only: phase cycle sums of wave 0 into the header's padding words
+        hdr->pad[0] = (unsigned)(t_f >> 4); hdr->pad[1] = (unsigned)(t_a >> 4); hdr->pad[2] = (unsigned)(t_r >> 4); hdr->pad[3] = (unsigned)(t_b >> 4);
+        hdr->nvalid = (unsigned)nb;
+    }
+#endif
     if (tid == 0) {
         if (fin == 0) fin = truncated ? 2 : 1;   // candidates exhausted: final unless the threshold bin was dropped
         hdr->np = np;
@@ -474,7 +519,7 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, doubl
 template <typename T>
 __global__ void __launch_bounds__(256) k_sel_apply(T *__restrict__ score, unsigned char *__restrict__ active,
                                                    unsigned char *__restrict__ selected, long long *__restrict__ active_mask,
-                                                   const long long *__restrict__ gt, BinWs ws, BinGeom g)
+                                                   const long long *__restrict__ gt, double *__restrict__ picks, BinWs ws, BinGeom g)
 {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -483,6 +528,17 @@ __global__ void __launch_bounds__(256) k_sel_apply(T *__restrict__ score, unsign
     const int w = (int)(pos >> 16), h = (int)(pos & 0xffffu);
     const size_t hw = (size_t)g.H * g.W;
     T *sc = score + (size_t)b * hw;
+    // (h, w, value) row of the pick table.  The value is read BEFORE this wave writes its window: no other pick's window
+    // covers this pixel (picks are more than mask_radius apart), so it still holds the original score
+    if (picks) {
+        const double v = key_value(order_key((double)sc[(size_t)h * g.W + w]));      // -0 -> +0, as the serial kernel reports it
+        if (lane == 0) {
+            double *pk = picks + ((size_t)b * g.n_regions + p) * 3;
+            pk[0] = (double)h;
+            pk[1] = (double)w;
+            pk[2] = v;
+        }
+    }
     unsigned char *act = active + (size_t)b * hw, *sel = selected + (size_t)b * hw;
     long long *am = active_mask + (size_t)b * hw;
     const long long *gtb = gt + (size_t)b * hw;
@@ -606,12 +662,12 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
             return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_sel_sweep, dim3((unsigned)B), dim3(SW_TPB), p.lds_bytes, st, ws, g, picks, n_picked);
+    hipLaunchKernelGGL(k_sel_sweep, dim3((unsigned)B), dim3(SW_TPB), p.lds_bytes, st, ws, g, n_picked);
     const dim3 ga((unsigned)cdiv(g.n_regions, 4), (unsigned)B);
     if (dtype == HALO_F64)
-        hipLaunchKernelGGL(k_sel_apply<double>, ga, blk, 0, st, (double *)score, active, selected, (long long *)active_mask, (const long long *)gt, ws, g);
+        hipLaunchKernelGGL(k_sel_apply<double>, ga, blk, 0, st, (double *)score, active, selected, (long long *)active_mask, (const long long *)gt, picks, ws, g);
     else
-        hipLaunchKernelGGL(k_sel_apply<float>, ga, blk, 0, st, (float *)score, active, selected, (long long *)active_mask, (const long long *)gt, ws, g);
+        hipLaunchKernelGGL(k_sel_apply<float>, ga, blk, 0, st, (float *)score, active, selected, (long long *)active_mask, (const long long *)gt, picks, ws, g);
     *hdr_out = ws.hdr;
     return check_launch("halo_greedy_select (binned)");
 }
