@@ -8,17 +8,20 @@
 One *step* = one batch of B synthetic Cityscapes-shaped images (1024x2048, C=256 float64 embedding,
 19 classes) through the whole unit of work of SURVEY.md 8(d): FloatingRegionScore.forward (HALO
 branch: entropy x radius, normalised, 3x3) + `score[active] = -inf` + select_pixels_to_label
-(2331 regions, radius 1, mask radius 5), inputs resident in HBM.  Scoring of batch s+1 (HBM-bound)
-overlaps the latency-bound greedy selection of batch s on a second HIP stream.
+(2331 regions, radius 1, mask radius 5), inputs resident in HBM, all three output maps written.
+Scoring of batch s+1 (HBM-bound) overlaps the selection of batch s on the slot's own HIP stream.
 
-Workload at N=1: BASELINE.json configs[1] -- a pool of `steps*B` image evaluations drawn from a
-ring of R distinct resident images (the 500-image pool does not fit in HBM at 4.3 GB/image).
+Workload at N=1: BASELINE.json configs[1] -- a pool of `steps*B` image evaluations (default 32 x 16 =
+512) drawn from a ring of R = 32 distinct resident images, so consecutive steps read different
+images (a 500-image pool does not fit in HBM at 4.3 GB/image); `--pool-images 2975` = configs[2].
 N>1: the pool is sharded image-wise, every rank runs the same per-rank workload (weak scaling)
-and the per-image pick tables are all-gathered (RCCL) once per step.
+and the per-image pick tables are exchanged with ONE RCCL all-gather per step.
+`--branch ripu|hyper`, `--feat-dtype f32`, `--channels 512`, `--source lowres` are variants for
+DESIGN.md / profiles/, not the BASELINE unit.
 
 Prints ONE JSON line (rank 0).  roofline: the feature-reduction kernel's algorithmic bytes / its
 average duration measured live with HIP events on its own stream.  cpu_baseline: the CPU oracle
-(OpenMP, all host cores) on a bounded sample of the same images (kind "port").
+(OpenMP over the host cores this process may use) on 1 warm-up + 8 of the same images (kind "port").
 """
 import argparse
 import json
@@ -70,6 +73,7 @@ def parse():
     ap.add_argument("--resets", choices=["score", "side"], default="score",
                     help="where the per-batch round-1 state resets run: on the scoring stream (default) or on a low-priority "
                          "housekeeping stream right after the slot's selection (tuning aid)")
+    ap.add_argument("--sel-priority", type=int, default=-1, help="stream priority of the selection streams (-1 = high)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
@@ -120,7 +124,7 @@ class Pipeline:
     """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
 
     def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False, branch="halo",
-                 resets="score"):
+                 resets="score", sel_priority=-1):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
@@ -134,7 +138,7 @@ class Pipeline:
         # selection runs beside the scoring of later batches.
         D = self.D = depth
         self.s_score = torch.cuda.Stream(dev)
-        self.s_sel = [torch.cuda.Stream(dev, priority=-1) for _ in range(D)]   # dispatch ahead of scoring
+        self.s_sel = [torch.cuda.Stream(dev, priority=sel_priority) for _ in range(D)]   # -1: dispatch ahead of scoring
         from halo_amd.core.active.floating_region import score_dtype
         sdt = score_dtype(self.pur, feat)
         self.score = [torch.empty((B, Hh, Ww), dtype=sdt, device=dev) for _ in range(D)]
@@ -344,7 +348,7 @@ def main():
     if lowres:
         a.cpu_images = 0
     feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch, a.resets)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch, a.resets, a.sel_priority)
 
     # per-rank schedule: full batches, plus a partial last one when --pool-images does not divide evenly
     if a.pool_images > 0:
