@@ -166,6 +166,18 @@ class _Slot:
         return self.mask, self.active, self.selected
 
 
+_SIDE = {}
+
+
+def _side_streams(dev, n):
+    """The acquisition's side streams, created once per device and reused by every round: the scorer's and the selector's
+    scratch buffers are cached per stream (floating_region._workspace), so fresh streams per call would strand them."""
+    have = _SIDE.setdefault(dev.index, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(dev, priority=-1))
+    return have[:n]
+
+
 def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, slot):
     """Enqueue one image of the pool (build.py:113-166) on `stream`: stage its masks, score -> mask -> select,
     copy the results back into pinned host buffers.  Fully asynchronous: `rec.done` fires when the host
@@ -280,7 +292,7 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     prm = AcquisitionParams(cfg)
     dev = torch.device("cuda", torch.cuda.current_device())
     depth = max(1, in_flight)
-    side = [torch.cuda.Stream(dev, priority=-1) for _ in range(max(1, min(streams, depth)))]
+    side = _side_streams(dev, max(1, min(streams, depth)))
     backlog = threading.Semaphore(depth + 4 * max(1, writer_threads))   # images whose files are not on disk yet (host copies)
     slots = queue.Queue()
     for k in range(depth):

@@ -1247,3 +1247,53 @@ def test_region_impurity_lds_tile_equals_generic_kernel(dev):
             assert bits_equal(imp.cpu().numpy(), imp_g.cpu().numpy()) and bits_equal(cnt.cpu().numpy(), cnt_g.cpu().numpy()), (H, W, K, kind)
             want_i, want_c = ho.region_impurity(lab, K, 3)
             assert bits_equal(imp.cpu().numpy(), want_i) and np.array_equal(cnt.cpu().numpy(), want_c), (H, W, K, kind)
+
+
+def test_v2_head_class_end_to_end_against_reference_vectors(golden, dev):
+    """The drop-in head class (classifier.py:335-379 interface: dict in, (logits, embedding) out, both resized for
+    DeepLab-v2) with its dilated branches set to pass the golden latent through: outputs equal the reference's vectors.
+    Also: the patched forward on a reference-SHAPED head object (foreign mapper / conv_seg classes) shares parameters."""
+    import torch.nn as nn
+    from halo_amd.core.models.classifier import ASPP_Classifier_V2_Hyper, _tail_modules, v2_hyper_forward
+    from halo_amd.core.utils.hyperbolic import HyperMLR
+    d = golden("case_b_64x128_c16_o19")
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    head = ASPP_Classifier_V2_Hyper(C, [6, 12], [6, 12], O, C).to(dev).eval()
+    assert sorted(head.state_dict()) == ["conv2d_list.0.bias", "conv2d_list.0.weight", "conv2d_list.1.bias", "conv2d_list.1.weight",
+                                         "conv_seg.A_MLR", "conv_seg.P_MLR"]
+    with torch.no_grad():
+        for m in head.conv2d_list:
+            m.weight.zero_(); m.bias.zero_()
+        for c in range(C):
+            head.conv2d_list[0].weight[c, c, 1, 1] = 1.0          # branch 0 = identity, branch 1 = 0: embed input = x['out']
+        head.conv_seg.P_MLR.copy_(t(d["P_MLR"], dev)); head.conv_seg.A_MLR.copy_(t(d["A_MLR"], dev))
+        out, emb = head({"out": t(d["z"], dev)}, size=(H, W))
+        out_lr, emb_lr = head({"out": t(d["z"], dev)})
+    assert out.dtype == torch.float32 and emb.dtype == torch.float64 and out.shape == (1, O, H, W) and emb.shape == (1, C, H, W)
+    assert max_abs_diff(out.cpu().numpy(), d["logit"]) < 1e-5 and max_abs_diff(emb.cpu().numpy(), d["embed"]) < 1e-14
+    assert max_abs_diff(emb_lr.cpu().numpy(), d["embed_lr"]) < 1e-14 and np.abs(out_lr.cpu().numpy() - d["logit_lr"]).max() < 1e-5
+
+    class RefMapper:                                   # what a reference-built head holds when its classes were imported earlier
+        def __init__(self, c):
+            self.c = c
+
+    class RefMLR(nn.Module):
+        def __init__(self, src):
+            super().__init__()
+            self.c, self.K, self.num_classes = src.c, src.K, src.num_classes
+            self.P_MLR, self.A_MLR = src.P_MLR, src.A_MLR
+
+    foreign = nn.Module()
+    foreign.conv2d_list = head.conv2d_list
+    foreign.mapper, foreign.conv_seg = RefMapper(1.0), RefMLR(head.conv_seg)
+    with torch.no_grad():
+        out2, emb2 = v2_hyper_forward(foreign, {"out": t(d["z"], dev)}, size=(H, W))
+    assert torch.equal(out2, out) and torch.equal(emb2, emb)
+    mapper, seg = _tail_modules(foreign)
+    assert isinstance(seg, HyperMLR) and seg.P_MLR is foreign.conv_seg.P_MLR and "_halo_tail" not in dict(foreign.named_modules())
+    assert sorted(foreign.state_dict()) == sorted(head.state_dict())
+    # training mode: differentiable through the HIP backward kernels
+    head.train()
+    out_t, _ = head({"out": t(d["z"], dev).requires_grad_(True)}, size=(H, W))
+    out_t.square().mean().backward()
+    assert head.conv_seg.P_MLR.grad is not None and head.conv2d_list[0].weight.grad is not None
