@@ -42,7 +42,10 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     if n == 0 or B == 0:
         return (picks[:, :0], n_picked) if return_picks else None
     L = _lib.lib()
-    method = _lib.SELECT[method or os.environ.get("HALO_SELECT", "auto")]
+    name = method or os.environ.get("HALO_SELECT", "auto")
+    if name not in _lib.SELECT:
+        raise ValueError("greedy_select: method must be one of %s, got %r" % (sorted(_lib.SELECT), name))
+    method = _lib.SELECT[name]
     nws = L.halo_select_workspace_bytes(B, H, W, n, int(mask_radius)) if method != _lib.SELECT["serial"] else 256
     ws = _workspace(dev, nws, "select")
     rc = L.halo_greedy_select(_lib.ptr(score), _lib.dtype_code(score), B, H, W, n, int(active_radius),
