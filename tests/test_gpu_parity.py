@@ -1297,3 +1297,77 @@ def test_v2_head_class_end_to_end_against_reference_vectors(golden, dev):
     out_t, _ = head({"out": t(d["z"], dev).requires_grad_(True)}, size=(H, W))
     out_t.square().mean().backward()
     assert head.conv_seg.P_MLR.grad is not None and head.conv2d_list[0].weight.grad is not None
+
+
+SHARDED_SCRIPT = r'''
+import os, sys, types
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from PIL import Image
+torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+from halo_amd.pool import region_selection_sharded
+from oracle import halo_oracle as ho
+from test_pool_gloo import _Pool, _cfg
+root = {tmp!r}
+dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+
+
+class Head(torch.nn.Module):            # "classifier": hands back the item's precomputed low-res head outputs
+    def forward(self, x, size=None):
+        return self.cur["logit_lr"][None].to(dev), self.cur["embed_lr"][None].to(dev)
+
+
+class Loader:                            # a DataLoader-like object over the pool that tells the head which item is current
+    def __init__(self, ds, head):
+        self.dataset, self.head = ds, head
+
+
+pool = _Pool(root, 5)
+head = Head()
+
+
+class Tap(torch.nn.Module):              # "feature extractor": records the batch so Head can return that image's outputs
+    def forward(self, x):
+        return x
+
+
+# the driver iterates a DataLoader built by region_selection_sharded over the dataset; route the per-item head outputs
+class DS(torch.utils.data.Dataset):
+    def __len__(self):
+        return len(pool)
+
+    def __getitem__(self, i):
+        it = dict(pool[i])
+        head.cur = it
+        return {{k: v for k, v in it.items() if k not in ("logit_lr", "embed_lr")}}
+
+
+res = region_selection_sharded(_cfg(), Tap(), head, DS(), 1, loader_kwargs=dict(pin_memory=False))
+cfg = _cfg()
+want = ho.region_selection(cfg, [dict(logit_lr=it["logit_lr"][None].numpy(), embed_lr=it["embed_lr"][None].numpy(),
+                                      origin_label=it["origin_label"].numpy(), origin_mask=it["origin_mask"].numpy(),
+                                      active=it["active"].numpy(), selected=it["selected"].numpy()) for it in pool.items])
+assert res["range"] == (0, 5) and res["tables"].is_cuda and res["tables"].shape[0] == 5
+for i, (mask, act, sel, picks) in enumerate(want):
+    assert np.array_equal(np.array(Image.open(os.path.join(root, "m%d.png" % i))), mask), i
+    ind = torch.load(os.path.join(root, "i%d.pth" % i))
+    assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
+    k = int(res["counts"][i])
+    assert k == len(picks) and np.array_equal(res["tables"][i, :k].cpu().numpy().view(np.int64), np.ascontiguousarray(picks).view(np.int64)), i
+dist.destroy_process_group()
+print("sharded ok")
+'''
+
+
+def test_region_selection_sharded_hip_driver_under_torchrun_world1(dev, tmp_path):
+    """halo_amd.pool.region_selection_sharded with the REAL driver (HIP RegionSelection, return_tables) and RCCL: one rank
+    under torch.distributed.run; files and the gathered (packed, all-gathered, unpacked) tables equal the oracle's."""
+    import socket
+    from conftest import ROOT
+    script = tmp_path / "sharded.py"
+    script.write_text(SHARDED_SCRIPT.format(root=ROOT, tmp=str(tmp_path)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = _run_script(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), str(script)], env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
