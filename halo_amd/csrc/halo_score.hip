@@ -60,17 +60,35 @@ __global__ void __launch_bounds__(TPB) k_minmax_finalize(const double *__restric
 }
 
 // ---------------------------------------------------------------- logits -> entropy / prediction
+// p[c] / s for all classes of a pixel.  hipcc expands every float32 division into  v_div_scale x2, v_rcp_f32, one
+// Newton step, q = n r, two fma corrections (the second one is v_div_fmas), v_div_fixup  -- 11 instructions, the
+// denominator half of which is the same for all O_T classes.  v_div_scale rescales only when the numerator is below
+// 2^-104 or the quotient would be denormal; when every exp(x - max) of the wave is >= 2^-92 (x - max >= -64, and
+// s in [1, O_T]) nothing is rescaled and the sequence below, with the reciprocal computed once, returns the identical,
+// correctly rounded bits in 5 instructions per class.  Otherwise (logit gaps above 64) the wave takes the plain division.
 template <int O_T>
 __device__ __forceinline__ void softmax_regs(float (&p)[O_T])
 {
-    float m = p[0];
+    float m = p[0], lo = p[0];
 #pragma unroll
-    for (int c = 1; c < O_T; ++c) m = p[c] > m ? p[c] : m;
+    for (int c = 1; c < O_T; ++c) { m = p[c] > m ? p[c] : m; lo = p[c] < lo ? p[c] : lo; }
+    const bool plain = !(lo - m >= -64.0f);                 // also true for NaN / infinite logits
     float s = 0.0f;
 #pragma unroll
     for (int c = 0; c < O_T; ++c) { p[c] = det_expf(p[c] - m); s = s + p[c]; }
+    if (__any(plain)) {
 #pragma unroll
-    for (int c = 0; c < O_T; ++c) p[c] = p[c] / s;
+        for (int c = 0; c < O_T; ++c) p[c] = p[c] / s;
+    } else {
+        float r = __builtin_amdgcn_rcpf(s);
+        r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) {
+            float q = p[c] * r;
+            q = __builtin_fmaf(__builtin_fmaf(-s, q, p[c]), r, q);
+            p[c] = __builtin_fmaf(__builtin_fmaf(-s, q, p[c]), r, q);
+        }
+    }
 }
 
 // One pixel, classes in registers.  Writes ent (per unc_type) and pred (per pur_type).

@@ -1371,3 +1371,26 @@ def test_region_selection_sharded_hip_driver_under_torchrun_world1(dev, tmp_path
     r = _run_script(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                      "--master-port", str(port), str(script)], env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_softmax_shared_reciprocal_path_and_plain_division_path_bitwise(dev):
+    """softmax's p/s runs through a reciprocal shared by the classes of a pixel when every exp(x - max) is far from the
+    denormal range, and through the plain division otherwise: both must give the oracle's (IEEE) bits.  Logit gaps from
+    0 to 150 exercise both paths, mixed within and across waves, for the fused, stand-alone and generic-class kernels."""
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(81)
+    H, W, C = 48, 128, 6
+    emb = (rng.standard_normal((1, C, H, W)) * 0.2)
+    for O in (19, 16, 7):
+        logit = rng.standard_normal((1, O, H, W)).astype(np.float32)
+        logit[:, :, :, 32:64] *= 30.0                              # gaps around 60-100: some pixels on each side of the switch
+        logit[:, :, :, 64:96] *= 80.0                              # far beyond: denormal / zero probabilities
+        logit[:, 0, 10, 100:128] = 1e30                            # overflowing differences
+        logit[:, 1, 11, 100:128] = -np.inf
+        gt = rng.integers(0, O, (H, W)).astype(np.int64)
+        for unc, pur in (("entropy", "radius"), ("entropy", "ripu"), ("oracle_acc", "oracle_ripu")):
+            so, io, uo = ho.floating_region_score(logit, emb, unc, pur, False, gt, size=3, purity_type=pur)
+            s, i, u = score_maps(t(logit, dev), t(emb, dev), unc, pur, False, t(gt, dev)[None], size=3)
+            assert bits_equal(u[0].cpu().numpy(), uo), (O, unc, pur)
+            assert bits_equal(i[0].cpu().numpy(), io) and bits_equal(s[0].cpu().numpy(), so), (O, unc, pur)
