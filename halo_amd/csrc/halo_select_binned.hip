@@ -23,7 +23,8 @@
 //   k_sel_sweep    ONE workgroup per image walks the bins: filter a bin's candidates against the
 //                  pick grid (4 waves, one candidate per lane), then wave 0 takes the survivors
 //                  in exact (value, w, h) order with a register-resident arg-max loop
-//   k_sel_apply    one wave per pick writes its windows (score = -inf, active, selected, active_mask)
+//   k_sel_apply    one wave per pick writes its (h, w, value) row of the pick table and its windows
+//                  (score = -inf, active, selected, active_mask)
 // Order inside a bin never matters (the resolve step is an exact arg-max over the bin's survivors),
 // bins are monotone in the value, so the result is the reference's sequence bit for bit.
 //
