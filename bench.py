@@ -323,7 +323,7 @@ def spawn_ranks(n):
 
 def main():
     a = parse()
-    if a.gpus > 1 and "RANK" not in os.environ:
+    if "RANK" not in os.environ and (a.gpus > 1 or os.environ.get("HALO_BENCH_SPAWN")):    # the env forces the launcher at N = 1 (test hook)
         sys.exit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -1183,6 +1183,21 @@ def test_bench_self_spawn_refuses_more_gpus_than_visible(dev):
     assert r.returncode != 0 and "ROCm device" in (r.stdout + r.stderr)
 
 
+def test_bench_self_spawn_launches_its_ranks_and_relays_one_line(dev):
+    """The code path of `python bench.py --gpus N` (N > 1) on the one GPU there is: HALO_BENCH_SPAWN forces the built-in
+    launcher at N = 1 -- a torch.distributed.run CHILD started before the parent touches the GPU, RCCL in the child,
+    exactly one JSON line relayed, the child's exit code returned."""
+    import json
+    from conftest import ROOT
+    r = _run_script([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--height", "64", "--width", "128", "--channels", "16", "--steps", "3",
+                     "--warmup", "1", "--batch", "4", "--ring", "8", "--cpu-images", "0"], env={"HALO_BENCH_SPAWN": "1"})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "RCCL all-gather" in d["config"]["sharding"]
+
+
 def test_bench_pool_images_and_branches_on_a_small_shape(dev):
     import json
     from conftest import ROOT
