@@ -25,8 +25,9 @@ PROJ_EPS = 1e-3
 def _no_grad_only(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            "halo_amd hyperbolic kernels are inference-only (no autograd); wrap the call in "
-            "torch.no_grad() or keep the PyTorch path for training")
+            "this halo_amd op (logmap / poincare_distance[_origin] / bilinear_align_corners) is inference-only: no caller "
+            "in the reference differentiates it; wrap the call in torch.no_grad().  HyperMapper.expmap and "
+            "HyperMLR.forward ARE differentiable (HIP backward kernels)")
 
 
 def _split(shape, dim):
