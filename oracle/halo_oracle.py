@@ -46,10 +46,31 @@ def build(force=False):
 _lib = None
 
 
+def usable_cpus():
+    """Cores this process may really use: min(visible, affinity, cgroup quota).  The GPU boxes show 256 CPUs under
+    a 16-core quota; an OpenMP team as wide as the machine then spends most of its time throttled."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
+        try:
+            C.CDLL("libgomp.so.1").omp_set_num_threads(usable_cpus())
+        except OSError:
+            pass
         _lib.halo_o_expf.restype = C.c_float
         _lib.halo_o_expf.argtypes = [C.c_float]
         _lib.halo_o_logf.restype = C.c_float
