@@ -26,6 +26,14 @@ COMBOS = {
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    # the GPU boxes show 256 CPUs under a 16-core cgroup quota: thread pools as wide as the machine get throttled
+    # (a 1-minute suite was seen taking 7); size torch's intra-op pool and the oracle's OpenMP team to what is usable
+    try:
+        import torch
+        from oracle import halo_oracle
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), halo_oracle.usable_cpus())))
+    except Exception:
+        pass
 
 
 def case_files():
