@@ -328,6 +328,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), effective_cpus())))      # host pools no wider than the cgroup quota
     assert torch.cuda.is_available(), "bench.py needs ROCm devices"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
