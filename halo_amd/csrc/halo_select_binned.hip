@@ -460,17 +460,49 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
 
     for (unsigned i = tid * 16; i < g.grid_bytes; i += SW_TPB * 16) *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
-    const unsigned ntot = nf ? foff[nf] : 0u;
     __syncthreads();
 
     int np = 0;                                  // maintained by wave 0
     int fin = 0;                                 // 0 running, 1 done, 2 bail
-    unsigned fw0 = 0, fwn = 0;                   // fwin holds foff[fw0 .. fw0 + fwn]
-    // prefetched candidate of position `ppos + tid`
-    unsigned ppos = 0;
-    unsigned long long nkey = tid < ntot ? ckey[tid] : 0ull;
-    unsigned npos = tid < ntot ? cpos[tid] : 0u;
     const int r = g.mrad, cs = g.cs;
+
+    // ---- the candidate stream.  Bins are cut into chunks of <= 256 candidates (one per thread); an iterator over the
+    // bin offsets (staged FWIN at a time in LDS) runs THREE chunks ahead of the one being filtered, and each chunk's
+    // (key, pos) loads are issued as soon as it is known -- beside a bandwidth-bound kernel a memory round trip takes
+    // microseconds, a chunk only ~1 us.  The three register sets rotate by unrolling the loop body three times, so the
+    // compiler's counted s_waitcnt vmcnt waits for the oldest set only.
+    struct Chunk { unsigned start, cnt; bool last, valid; };
+    unsigned fw0 = 0, fwn = 0;                   // fwin holds foff[fw0 .. fw0 + fwn]
+    unsigned it_f = 0xffffffffu, it_c = 0, it_e = 0;         // iterator: bin, next chunk start, bin end
+    auto next_chunk = [&]() {
+        Chunk c;
+        c.start = 0; c.cnt = 0; c.last = false; c.valid = false;
+        while (it_c >= it_e) {                   // advance to the next non-empty bin
+            ++it_f;
+            if (it_f >= nf) { it_f = nf; return c; }
+            if (fwn == 0 || it_f + 1 > fw0 + fwn) {          // stage the next window of bin offsets (uniform: every thread gets here together)
+                lds_barrier();
+                fw0 = it_f;
+                fwn = nf - it_f < (unsigned)FWIN ? nf - it_f : (unsigned)FWIN;
+                for (unsigned i = tid; i <= fwn; i += SW_TPB) fwin[i] = foff[fw0 + i];
+                __syncthreads();
+            }
+            it_c = fwin[it_f - fw0];
+            it_e = fwin[it_f - fw0 + 1];
+        }
+        c.start = it_c;
+        c.cnt = it_e - it_c < (unsigned)SW_TPB ? it_e - it_c : (unsigned)SW_TPB;
+        it_c += c.cnt;
+        c.last = it_c >= it_e;
+        c.valid = true;
+        return c;
+    };
+    struct Regs { unsigned long long key; unsigned pos; };
+    auto issue = [&](const Chunk &c, Regs &d) {      // unconditional loads (clamped index): no exec-mask branch, so the waits stay counted
+        const unsigned idx = c.valid ? c.start + ((unsigned)tid < c.cnt ? (unsigned)tid : c.cnt - 1u) : 0u;
+        d.key = ckey[idx];
+        d.pos = cpos[idx];
+    };
 
 #ifdef HALO_SWEEP_STAMPS
     unsigned long long t_f = 0, t_a = 0, t_r = 0, t_b = 0, t0 = __builtin_amdgcn_s_memtime(), nb = 0, t_surv = 0, t_smax = 0;
@@ -478,63 +510,42 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
 #else
 #define STAMP(acc)
 #endif
-    for (unsigned f = 0; f < nf && !fin; ++f) {
-        if (f + 1 > fw0 + fwn || fwn == 0) {     // stage the next window of bin offsets
-            lds_barrier();
-            fw0 = f;
-            fwn = nf - f < (unsigned)FWIN ? nf - f : (unsigned)FWIN;
-            for (unsigned i = tid; i <= fwn; i += SW_TPB) fwin[i] = foff[fw0 + i];
-            __syncthreads();
-        }
-        const unsigned lo = fwin[f - fw0], hi = fwin[f - fw0 + 1];
-        if (hi == lo) continue;
-        // ---- filter the bin's candidates against the pick grid, survivors -> LDS list
-        for (unsigned cs0 = lo; cs0 < hi; cs0 += SW_TPB) {
-            const unsigned cnt = hi - cs0 < (unsigned)SW_TPB ? hi - cs0 : (unsigned)SW_TPB;
-            unsigned long long key;
-            unsigned pos;
-            if (ppos == cs0) { key = nkey; pos = npos; }
-            else {                                // (first chunk after a skipped prefetch position; not the steady state)
-                key = cs0 + tid < ntot ? ckey[cs0 + tid] : 0ull;
-                pos = cs0 + tid < ntot ? cpos[cs0 + tid] : 0u;
-            }
-            ppos = cs0 + cnt;                     // the next chunk starts where this one ends
-            nkey = ppos + tid < ntot ? ckey[ppos + tid] : 0ull;
-            npos = ppos + tid < ntot ? cpos[ppos + tid] : 0u;
-
-            const int x = (int)(pos >> 16), y = (int)(pos & 0xffffu);
-            const int cx = (int)__umulhi((unsigned)x, g.cmul), cy = (int)__umulhi((unsigned)y, g.cmul);
-            const int lx = x - cx * cs, ly = y - cy * cs;
-            bool alive = (unsigned)tid < cnt;
-            const int cell0 = cy * g.gstride + cx;                           // padded address of cell (cy-1, cx-1)
+    // one chunk: filter against the pick grid, survivors -> LDS list; at the end of a bin wave 0 resolves the survivors
+    auto step = [&](const Chunk &c, const Regs &d) {
+        const unsigned long long key = d.key;
+        const unsigned pos = d.pos;
+        const int x = (int)(pos >> 16), y = (int)(pos & 0xffffu);
+        const int cx = (int)__umulhi((unsigned)x, g.cmul), cy = (int)__umulhi((unsigned)y, g.cmul);
+        const int lx = x - cx * cs, ly = y - cy * cs;
+        bool alive = (unsigned)tid < c.cnt;
+        const int cell0 = cy * g.gstride + cx;                               // padded address of cell (cy-1, cx-1)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int addr = cell0 + a * g.gstride;
-                const unsigned w0 = gridw[addr >> 2], w1 = gridw[(addr >> 2) + 1];
-                const unsigned win = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(addr & 3) * 8u);
-                const int oy = (a - 1) * cs - ly + r;                        // ddy + r = oy + dy
+        for (int a = 0; a < 3; ++a) {
+            const int addr = cell0 + a * g.gstride;
+            const unsigned w0 = gridw[addr >> 2], w1 = gridw[(addr >> 2) + 1];
+            const unsigned win = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(addr & 3) * 8u);
+            const int oy = (a - 1) * cs - ly + r;                            // ddy + r = oy + dy
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb) {
-                    const unsigned c = (win >> (8 * bb)) & 0xffu;
-                    const unsigned q = c - 1u;
-                    const int ddy = oy + (int)(q >> 4), ddx = (bb - 1) * cs - lx + r + (int)(q & 15u);
-                    const bool hit = c != 0u && (unsigned)ddy <= (unsigned)(2 * r) && (unsigned)ddx <= (unsigned)(2 * r);
-                    alive = alive && !hit;
-                }
-            }
-            const unsigned long long mask = __ballot(alive);
-            if (mask) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&ctl[0], (unsigned)__builtin_popcountll(mask));
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (alive && slot < (unsigned)SW_SURV) { skey[slot] = key; spos[slot] = pos; }
+            for (int bb = 0; bb < 3; ++bb) {
+                const unsigned cc = (win >> (8 * bb)) & 0xffu;
+                const unsigned q = cc - 1u;
+                const int ddy = oy + (int)(q >> 4), ddx = (bb - 1) * cs - lx + r + (int)(q & 15u);
+                const bool hit = cc != 0u && (unsigned)ddy <= (unsigned)(2 * r) && (unsigned)ddx <= (unsigned)(2 * r);
+                alive = alive && !hit;
             }
         }
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&ctl[0], (unsigned)__builtin_popcountll(mask));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (alive && slot < (unsigned)SW_SURV) { skey[slot] = key; spos[slot] = pos; }
+        }
+        if (!c.last) return;
         STAMP(t_f)
         lds_barrier();
         STAMP(t_a)
-        // ---- resolve: wave 0 takes the survivors in exact order
         if (wave == 0) {
             const unsigned sc = ctl[0];
 #ifdef HALO_SWEEP_STAMPS
@@ -556,6 +567,22 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
 #ifdef HALO_SWEEP_STAMPS
         ++nb;
 #endif
+    };
+    Chunk c0 = next_chunk(), c1, c2;
+    Regs d0, d1, d2;
+    issue(c0, d0);
+    c1 = next_chunk(); issue(c1, d1);
+    c2 = next_chunk(); issue(c2, d2);
+    while (true) {
+        if (!c0.valid || fin) break;
+        step(c0, d0);
+        c0 = next_chunk(); issue(c0, d0);
+        if (!c1.valid || fin) break;
+        step(c1, d1);
+        c1 = next_chunk(); issue(c1, d1);
+        if (!c2.valid || fin) break;
+        step(c2, d2);
+        c2 = next_chunk(); issue(c2, d2);
     }
 #ifdef HALO_SWEEP_STAMPS
     if (tid == 0) {      // diagnostic build only: phase cycle sums of wave 0 into the header's padding words
@@ -636,7 +663,8 @@ BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t 
 {
     BinPlan p;
     memset(&p, 0, sizeof(p));
-    if (B <= 0 || H <= 0 || W <= 0 || n_regions <= 0 || H > 65535 || W > 65535 || mrad < 0 || mrad > 14) return p;
+    // mask radius 0 (a pick suppresses only itself) has 1-pixel cells, whose reciprocal multiplier 2^32 does not fit: serial kernel
+    if (B <= 0 || H <= 0 || W <= 0 || n_regions <= 0 || H > 65535 || W > 65535 || mrad < 1 || mrad > 14) return p;
     BinGeom &g = p.g;
     g.H = (int)H; g.W = (int)W; g.n_regions = (int)n_regions; g.arad = (int)arad; g.mrad = (int)mrad;
     g.cs = (int)mrad + 1;

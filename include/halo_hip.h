@@ -162,7 +162,7 @@ int halo_quantize_radius(const void *feat, int feat_dtype, int64_t feat_bstride,
  */
 /* method: HALO_SELECT_AUTO runs the value-binned sweep (visit pixels in descending value order, test each
  * against the picks so far -- no per-pick pass over the map) and leaves what it cannot finish (NaN / +inf
- * in the map, large plateaus of exact ties, pick grid larger than LDS, mask radius above 14) to the serial
+ * in the map, large plateaus of exact ties, pick grid larger than LDS, mask radius 0 or above 14) to the serial
  * tile-table kernel on the same stream; HALO_SELECT_SERIAL runs only the latter; HALO_SELECT_BINNED
  * fails with HALO_E_UNSUPPORTED where the sweep does not serve the geometry.  All three give identical results.
  * workspace: halo_select_workspace_bytes(B, H, W, n_regions, mask_radius). */

@@ -1409,3 +1409,31 @@ def test_softmax_shared_reciprocal_path_and_plain_division_path_bitwise(dev):
             s, i, u = score_maps(t(logit, dev), t(emb, dev), unc, pur, False, t(gt, dev)[None], size=3)
             assert bits_equal(u[0].cpu().numpy(), uo), (O, unc, pur)
             assert bits_equal(i[0].cpu().numpy(), io) and bits_equal(s[0].cpu().numpy(), so), (O, unc, pur)
+
+
+def test_binned_selection_repeats_identically(dev):
+    """The sweep's inner order is not fixed (atomics place candidates inside a bin in arrival order, a bin's picks are
+    committed by parallel lanes): 25 repetitions per map -- noise maps, where neighbours within one bin do conflict, smooth
+    maps, every mask radius the sweep serves on these sizes -- must all give the oracle's picks and masks."""
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(91)
+    for (H, W, mrad, n, kind, dt) in ((96, 160, 1, 300, "noise", np.float64), (96, 160, 2, 200, "noise", np.float32),
+                                      (128, 192, 3, 150, "smooth", np.float64), (200, 320, 5, 120, "noise", np.float32),
+                                      (200, 320, 9, 60, "smooth", np.float64), (64, 64, 14, 9, "noise", np.float64)):
+        s0 = rng.standard_normal((H, W)) if kind == "noise" else ho.bilinear(rng.standard_normal((1, H // 4, W // 4)), (H, W))[0]
+        s0 = np.ascontiguousarray(s0.astype(dt))
+        gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+        act_o = np.zeros((H, W), bool); sel_o = np.zeros((H, W), bool); am_o = np.full((H, W), 255, np.int64)
+        so = s0.copy()
+        _, _, _, _, po = ho.select_pixels_to_label(so, n, 1, mrad, act_o, sel_o, am_o, gt, True)
+        gtd = t(gt, dev)[None]
+        for rep in range(25):
+            s = t(s0, dev)[None].clone()
+            act = torch.zeros((1, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+            am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+            picks, npk = greedy_select(s, n, 1, mrad, act, sel, am, gtd, method="binned")
+            k = int(npk[0])
+            assert k == len(po) and bits_equal(picks[0, :k].cpu().numpy(), po), (H, W, mrad, kind, rep)
+            assert np.array_equal(act[0].cpu().numpy(), act_o) and np.array_equal(am[0].cpu().numpy(), am_o), (H, W, mrad, kind, rep)
+            assert bits_equal(s[0].cpu().numpy(), so), (H, W, mrad, kind, rep)
