@@ -95,15 +95,24 @@ __global__ void __launch_bounds__(256) k_sel_range(const T *__restrict__ score, 
     const T *sc = score + (size_t)b * hw;
     unsigned long long kmin_inv = 0, kmax = 0;
     unsigned nval = 0, bad = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long long)gridDim.x * 256) {
-        const unsigned long long k = order_key((double)sc[i]);
-        const bool isbad = k >= KEY_POS_INF;                         // +inf or NaN
-        const bool ok = !isbad && k != KEY_NEG_INF;
-        bad |= isbad ? 1u : 0u;
-        nval += ok ? 1u : 0u;
-        const unsigned long long ki = ok ? ~k : 0ull, kx = ok ? k : 0ull;
-        kmin_inv = ki > kmin_inv ? ki : kmin_inv;
-        kmax = kx > kmax ? kx : kmax;
+    // four independent loads per iteration: beside a bandwidth-bound kernel a round trip takes microseconds, and a thread's
+    // iterations would otherwise pay them one after the other
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += 4 * stride) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i + u * stride < hw ? (double)sc[i + u * stride] : __longlong_as_double(0xfff0000000000000ll);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long k = order_key(v[u]);
+            const bool isbad = k >= KEY_POS_INF;                         // +inf or NaN
+            const bool ok = !isbad && k != KEY_NEG_INF;
+            bad |= isbad ? 1u : 0u;
+            nval += ok ? 1u : 0u;
+            const unsigned long long ki = ok ? ~k : 0ull, kx = ok ? k : 0ull;
+            kmin_inv = ki > kmin_inv ? ki : kmin_inv;
+            kmax = kx > kmax ? kx : kmax;
+        }
     }
     kmin_inv = wave_max_u64(kmin_inv);
     kmax = wave_max_u64(kmax);
@@ -131,12 +140,18 @@ __global__ void __launch_bounds__(256) k_sel_hist1(const T *__restrict__ score, 
     for (int j = threadIdx.x; j < NB1; j += 256) h[j] = 0;
     __syncthreads();
     const T *sc = score + (size_t)b * hw;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long long)gridDim.x * 256) {
-        const double v = (double)sc[i];
-        const unsigned long long k = order_key(v);
-        if (k < KEY_POS_INF && k != KEY_NEG_INF) {
-            double t;
-            atomicAdd(&h[coarse_bin(v, r, t)], 1u);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += 4 * stride) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i + u * stride < hw ? (double)sc[i + u * stride] : __longlong_as_double(0xfff0000000000000ll);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long k = order_key(v[u]);
+            if (k < KEY_POS_INF && k != KEY_NEG_INF) {
+                double t;
+                atomicAdd(&h[coarse_bin(v[u], r, t)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -229,32 +244,49 @@ __global__ void __launch_bounds__(256) k_sel_compact(const T *__restrict__ score
     const T *sc = score + (size_t)b * g.H * g.W;
     unsigned *fhist = ws.fhist + (size_t)b * g.nfmax;
     uint4 *tmp = ws.tmp + (size_t)b * g.captot;
+    // four row segments per iteration: their loads, their histogram atomics and ONE staging-list append per wave are in
+    // flight together (beside a bandwidth-bound kernel each dependent round trip costs microseconds)
     for (int y = blockIdx.x; y < g.H; y += gridDim.x)
-        for (int x0 = 0; x0 < g.W; x0 += 256) {
-            const int x = x0 + tid;
-            const bool in = x < g.W;
-            const double v = in ? (double)sc[(size_t)y * g.W + x] : 0.0;
-            const unsigned long long k = order_key(v);
-            bool cand = in && k < KEY_POS_INF && k != KEY_NEG_INF;
-            double t = 0.0;
-            const int j = cand ? coarse_bin(v, r, t) : 0;
-            cand = cand && (unsigned)j >= t1;
-            unsigned f = 0;
-            if (cand) {
-                const unsigned mj = s_m[j];
-                unsigned s = (unsigned)((t - (double)j) * (double)mj);       // sub-bin inside the coarse bin, monotone in v
-                s = s > mj - 1 ? mj - 1 : s;
-                f = s_base[j] + (mj - 1 - s);
-                atomicAdd(&fhist[f], 1u);
+        for (int x0 = 0; x0 < g.W; x0 += 4 * 256) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + u * 256 + tid;
+                v[u] = x < g.W ? (double)sc[(size_t)y * g.W + x] : __longlong_as_double(0xfff0000000000000ll);    // -inf: never a candidate
             }
-            const unsigned long long mask = __ballot(cand);
-            if (mask) {
+            unsigned long long k[4], mask[4];
+            unsigned f[4], total = 0;
+            bool cand[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                k[u] = order_key(v[u]);
+                cand[u] = k[u] < KEY_POS_INF && k[u] != KEY_NEG_INF;
+                double t = 0.0;
+                const int j = cand[u] ? coarse_bin(v[u], r, t) : 0;
+                cand[u] = cand[u] && (unsigned)j >= t1;
+                f[u] = 0;
+                if (cand[u]) {
+                    const unsigned mj = s_m[j];
+                    unsigned sb = (unsigned)((t - (double)j) * (double)mj);      // sub-bin inside the coarse bin, monotone in v
+                    sb = sb > mj - 1 ? mj - 1 : sb;
+                    f[u] = s_base[j] + (mj - 1 - sb);
+                    atomicAdd(&fhist[f[u]], 1u);
+                }
+                mask[u] = __ballot(cand[u]);
+                total += (unsigned)__builtin_popcountll(mask[u]);
+            }
+            if (total) {
                 unsigned base = 0;
-                if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(&hdr->ncand, (unsigned)__builtin_popcountll(mask));
-                base = __shfl(base, (int)__builtin_ctzll(mask), 64);
-                if (cand) {
-                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (slot < g.captot) tmp[slot] = make_uint4((unsigned)k, (unsigned)(k >> 32), ((unsigned)x << 16) | (unsigned)y, f);
+                if (lane == 0) base = atomicAdd(&hdr->ncand, total);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (cand[u]) {
+                        const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
+                        const int x = x0 + u * 256 + tid;
+                        if (slot < g.captot) tmp[slot] = make_uint4((unsigned)k[u], (unsigned)(k[u] >> 32), ((unsigned)x << 16) | (unsigned)y, f[u]);
+                    }
+                    base += (unsigned)__builtin_popcountll(mask[u]);
                 }
             }
         }
@@ -310,11 +342,21 @@ __global__ void __launch_bounds__(256) k_sel_scatter(BinWs ws, BinGeom g)
     unsigned *fcur = ws.fcur + (size_t)b * g.nfmax;
     unsigned long long *ckey = ws.ckey + (size_t)b * g.captot;
     unsigned *cpos = ws.cpos + (size_t)b * g.captot;
-    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        const uint4 c = tmp[e];
-        const unsigned slot = foff[c.w] + atomicAdd(&fcur[c.w], 1u);
-        ckey[slot] = ((unsigned long long)c.y << 32) | c.x;
-        cpos[slot] = c.z;
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += 4 * stride) {
+        uint4 c[4];
+        unsigned slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = e + u * stride < n ? tmp[e + u * stride] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) slot[u] = e + u * stride < n ? atomicAdd(&fcur[c[u].w], 1u) : 0u;     // four returns in flight
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e + u * stride < n) {
+                const unsigned sl = foff[c[u].w] + slot[u];
+                ckey[sl] = ((unsigned long long)c[u].y << 32) | c[u].x;
+                cpos[sl] = c[u].z;
+            }
     }
 }
 
