@@ -55,4 +55,4 @@ for loaded in (False, True):
         torch.cuda.synchronize()
         print(f"survivors total {int(hdr[6])} (avg {int(hdr[6]) / max(nb, 1):.1f} per bin, max {int(hdr[5])})")
         print(f"{'beside streaming' if loaded else 'alone':17s} bins {nb:5d}  cycles/bin: filter {f / nb:7.0f}  barrier A {a / nb:6.0f}  resolve {r / nb:7.0f}  "
-              f"barrier B {b / nb:6.0f}   total {tot / 1e6:.2f} M cycles (s_memtime ticks, 100 MHz? see note)  np {int(hdr[11])}")
+              f"barrier B {b / nb:6.0f}   total {tot / 1e6:.2f} M shader cycles (s_memtime)  np {int(hdr[11])}")
