@@ -7,8 +7,9 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
+    """newest match (gpurun merges every call's output into the same directory tree)"""
     f = glob.glob(os.path.join(SRC, pattern))
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def copy_json(name, dst):
