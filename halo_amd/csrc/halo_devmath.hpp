@@ -12,18 +12,25 @@
 // (core/active/floating_region.py:72,119,152) and the float64 torch.log inside geoopt's
 // artanh (used by dist0, core/utils/hyperbolic.py:83).
 #pragma once
+#ifndef HALO_DEVMATH_HOST_CHECK      // tests/native/devmath_host_check.cpp evaluates these recipes on the host
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace halo {
 
 __device__ __forceinline__ float pow2f_(int k) { return __uint_as_float((uint32_t)(k + 127) << 23); }
 
-__device__ __forceinline__ float det_expf(float x)
+// All of these are straight-line code: the special cases (NaN, out of range, zero, infinity) are patched in with selects
+// at the end instead of returning early, so that a pixel's classes compile into one basic block the scheduler can
+// interleave and pack (early returns cost three scalar exec-mask instructions per test and a pipeline bubble per block:
+// ~600 branches per fused-entropy pass).  In-range inputs take exactly the operations of the oracle's branchy statement
+// (oracle/halo_oracle_math.h); tests/native/devmath_host_check.cpp compares the two on the host, bit for bit.
+// The *_core functions are the main path alone, for callers that have already excluded the special cases.
+
+// expf for finite x in [-104, 89]
+__device__ __forceinline__ float det_expf_core(float x)
 {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return __uint_as_float(0x7f800000u);
-    if (x < -103.97208404541015625f) return 0.0f;
     float k = __builtin_rintf(x * 1.44269502162933349609375f);
     float r = __builtin_fmaf(k, -0.693359375f, x);
     r = __builtin_fmaf(k, 2.12194440e-4f, r);
@@ -40,19 +47,24 @@ __device__ __forceinline__ float det_expf(float x)
     return (y * pow2f_(k1)) * pow2f_(k2);
 }
 
-__device__ __forceinline__ float det_logf(float x)
+__device__ __forceinline__ float det_expf(float x)
 {
-    if (x != x) return x;
-    if (x < 0.0f) return __uint_as_float(0x7fc00000u);
-    if (x == 0.0f) return __uint_as_float(0xff800000u);
-    uint32_t u = __float_as_uint(x);
-    if (u == 0x7f800000u) return x;
-    int e = 0;
-    if (u < 0x00800000u) { x = x * 8388608.0f; u = __float_as_uint(x); e = -23; }
-    e += (int)(u >> 23) - 126;
+    // The reduction runs on a clamped copy (in-range x is unchanged; NaN becomes a bound), so every intermediate is finite.
+    // Beyond the oracle's cut-offs (x > 88.7228... -> +inf, x < -103.972... -> 0) the clamped value lands there by itself:
+    // y * 2^64 * 2^64 overflows for every xc in (88.7228, 89], y * 2^-75 * 2^-75 with y < 1 rounds to zero for every xc in
+    // [-104, -103.972) -- the host check walks every such float32 input.
+    const float res = det_expf_core(__builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f));
+    return x != x ? x : res;
+}
+
+// logf of the positive normal float whose bits are u, plus e0 * ln 2
+__device__ __forceinline__ float logf_core_(uint32_t u, int e0)
+{
+    int e = e0 + ((int)(u >> 23) - 126);
     float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
-    if (m < 0.707106769084930419921875f) { e -= 1; m = (m + m) - 1.0f; }
-    else { m = m - 1.0f; }
+    const bool low = m < 0.707106769084930419921875f;
+    e -= low ? 1 : 0;
+    m = (low ? m + m : m) - 1.0f;
     float z = m * m;
     float p = 7.0376836292e-2f;
     p = __builtin_fmaf(p, m, -1.1514610310e-1f);
@@ -71,20 +83,31 @@ __device__ __forceinline__ float det_logf(float x)
     return __builtin_fmaf(fe, 0.693359375f, r);
 }
 
-__device__ __forceinline__ double det_log(double x)
+// logf for positive normal finite x
+__device__ __forceinline__ float det_logf_core(float x) { return logf_core_(__float_as_uint(x), 0); }
+
+__device__ __forceinline__ float det_logf(float x)
+{
+    const uint32_t u0 = __float_as_uint(x);
+    const bool sub = u0 < 0x00800000u;                       // positive subnormal (or +0, patched below)
+    const float xs = sub ? x * 8388608.0f : x;
+    float res = logf_core_(__float_as_uint(xs), sub ? -23 : 0);
+    const float ninf = __uint_as_float(0xff800000u), qnan = __uint_as_float(0x7fc00000u);   // named, so that clang emits selects
+    res = u0 == 0x7f800000u ? x : res;
+    res = x == 0.0f ? ninf : res;
+    res = x < 0.0f ? qnan : res;
+    return x != x ? x : res;
+}
+
+// log of the positive normal double whose bits are u, plus k0 * ln 2
+__device__ __forceinline__ double log_core_(uint64_t u, int k0)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                  Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                  Lg7 = 1.479819860511658591e-01;
-    if (x != x) return x;
-    if (x < 0.0) return __longlong_as_double(0x7ff8000000000000ll);
-    if (x == 0.0) return __longlong_as_double(0xfff0000000000000ll);
-    uint64_t u = (uint64_t)__double_as_longlong(x);
-    if (u == 0x7ff0000000000000ull) return x;
-    int k = 0;
-    if (u < 0x0010000000000000ull) { x = x * 18014398509481984.0; u = (uint64_t)__double_as_longlong(x); k = -54; }
+    int k = k0;
     uint32_t hx = (uint32_t)(u >> 32);
     hx += 0x3ff00000u - 0x3fe6a09eu;
     k += (int)(hx >> 20) - 0x3ff;
@@ -102,6 +125,22 @@ __device__ __forceinline__ double det_log(double x)
     return __builtin_fma(dk, ln2_hi, (f - (hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo))));
 }
 
+// log for positive normal finite x
+__device__ __forceinline__ double det_log_core(double x) { return log_core_((uint64_t)__double_as_longlong(x), 0); }
+
+__device__ __forceinline__ double det_log(double x)
+{
+    const uint64_t u0 = (uint64_t)__double_as_longlong(x);
+    const bool sub = u0 < 0x0010000000000000ull;             // positive subnormal (or +0, patched below)
+    const double xs = sub ? x * 18014398509481984.0 : x;
+    double res = log_core_((uint64_t)__double_as_longlong(xs), sub ? -54 : 0);
+    const double ninf = __longlong_as_double(0xfff0000000000000ll), qnan = __longlong_as_double(0x7ff8000000000000ll);
+    res = u0 == 0x7ff0000000000000ull ? x : res;
+    res = x == 0.0 ? ninf : res;
+    res = x < 0.0 ? qnan : res;
+    return x != x ? x : res;
+}
+
 // asinh for the HyperMLR epilogue: sign(x) * log1p(t),  t = |x| + x^2 / (1 + sqrt(1 + x^2))  (= |x| + sqrt(1+x^2) - 1
 // without cancellation), log1p(t) = log(u) + (t - (u - 1)) / u with u = 1 + t.  One formula for every magnitude the
 // logits can reach (|x| < 1e150), about half the instructions of the library's asinh, error <= 2 ulp.
@@ -110,7 +149,7 @@ __device__ __forceinline__ double asinh_det(double x)
     const double a = __builtin_fabs(x), a2 = a * a;
     const double t = a + a2 / (1.0 + __builtin_sqrt(1.0 + a2));
     const double u = 1.0 + t;
-    const double r = det_log(u) + (t - (u - 1.0)) / u;
+    const double r = det_log_core(u) + (t - (u - 1.0)) / u;    // u >= 1; for infinite or NaN u the second term is NaN anyway
     return x != x ? x : __builtin_copysign(r, x);
 }
 
@@ -120,7 +159,8 @@ __device__ __forceinline__ double artanh_clamped(double z)
     const double lim = 1.0 - 1e-7;
     if (z > lim) z = lim;
     if (z < -lim) z = -lim;
-    return (det_log(1.0 + z) - det_log(1.0 - z)) * 0.5;
+    const double r = (det_log_core(1.0 + z) - det_log_core(1.0 - z)) * 0.5;    // both arguments in [1e-7, 2)
+    return z != z ? z : r;
 }
 
 // geoopt dist0 = 2 * artan_k(||x||), k = -c:  ks = sqrt(|k| + 1e-15), rks = 1/ks (host doubles)
@@ -137,7 +177,8 @@ __device__ __forceinline__ float dist0_from_ssq(float ssq, double ks, double rks
     if (z > lim) z = lim;
     if (z < -lim) z = -lim;
     double zd = (double)z;
-    float a = (float)((det_log(1.0 + zd) - det_log(1.0 - zd)) * 0.5);
+    const double r = (det_log_core(1.0 + zd) - det_log_core(1.0 - zd)) * 0.5;
+    float a = (float)(zd != zd ? zd : r);
     return 2.0f * ((float)rks * a);
 }
 

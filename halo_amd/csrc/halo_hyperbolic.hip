@@ -841,12 +841,9 @@ extern "C" int halo_expmap0_project(const void *x, int x_dtype, double *y, int64
         if (lds > 96 * 1024) pshift = 0;
     }
     if (pshift) {
-        static bool attr_set = false;
-        if (lds > 64 * 1024 && !attr_set) {
-            if (hipFuncSetAttribute((const void *)k_expmap0_project_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-                return fail(HALO_E_LAUNCH, "halo_expmap0_project: cannot raise the dynamic LDS limit");
-            attr_set = true;
-        }
+        static LdsLimitSeen seen;
+        if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_expmap0_project_tile, 96 * 1024))
+            return fail(HALO_E_LAUNCH, "halo_expmap0_project: cannot raise the dynamic LDS limit");
         const long long tiles = (inner + (1ll << pshift) - 1) >> pshift;
         hipLaunchKernelGGL(k_expmap0_project_tile, dim3((unsigned)(outer * tiles)), dim3(HTPB), lds, st, (const float *)x, y,
                            (long long)outer, (int)C, (long long)inner, pshift, ks, rks, maxnorm);
@@ -921,12 +918,9 @@ extern "C" int halo_hypermlr_logits(const double *x, const double *P, const doub
             gx = gx > 256 ? 256 : gx;                                              // one resident workgroup per CU, persistent over tiles
 #define HALO_MLRP(T, NT_)                                                                                                          \
     {                                                                                                                             \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) {                                                                                                          \
-            if (hipFuncSetAttribute((const void *)k_hypermlr_mfma_res<T, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
-                return fail(HALO_E_LAUNCH, "halo_hypermlr_logits: cannot raise the dynamic LDS limit");                            \
-            attr_set = true;                                                                                                      \
-        }                                                                                                                         \
+        static LdsLimitSeen seen;                                                                                                 \
+        if (!raise_lds_limit(seen, (const void *)k_hypermlr_mfma_res<T, NT_>, 160 * 1024))                                        \
+            return fail(HALO_E_LAUNCH, "halo_hypermlr_logits: cannot raise the dynamic LDS limit");                               \
         hipLaunchKernelGGL((k_hypermlr_mfma_res<T, NT_>), dim3((unsigned)gx), dim3(MLRP_TPB), lds, st, x, (const double *)consts, (int)O, \
                            (int)C, wstride, (long long)hw, tiles_per_img, ntiles, c, (T *)out);                                   \
     }

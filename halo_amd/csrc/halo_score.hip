@@ -60,61 +60,158 @@ __global__ void __launch_bounds__(TPB) k_minmax_finalize(const double *__restric
 }
 
 // ---------------------------------------------------------------- logits -> entropy / prediction
-// p[c] / s for all classes of a pixel.  hipcc expands every float32 division into  v_div_scale x2, v_rcp_f32, one
-// Newton step, q = n r, two fma corrections (the second one is v_div_fmas), v_div_fixup  -- 11 instructions, the
-// denominator half of which is the same for all O_T classes.  v_div_scale rescales only when the numerator is below
-// 2^-104 or the quotient would be denormal; when every exp(x - max) of the wave is >= 2^-92 (x - max >= -64, and
-// s in [1, O_T]) nothing is rescaled and the sequence below, with the reciprocal computed once, returns the identical,
-// correctly rounded bits in 5 instructions per class.  Otherwise (logit gaps above 64) the wave takes the plain division.
-template <int O_T>
-__device__ __forceinline__ void softmax_regs(float (&p)[O_T])
+// Softmax, entropy and arg-max over the classes of a pixel (floating_region.py:72-76, 119, 152).  Two statements of the
+// same arithmetic:
+//
+//  * the general one (px_general: rolled loops over the class planes in memory; softmax_general: registers): the full
+//    det_expf / det_logf and a plain division p[c] / s, which hipcc expands into v_div_scale x2, v_rcp_f32, one Newton
+//    step, q = n r, two fma corrections (the second one is v_div_fmas), v_div_fixup -- 11 instructions;
+//  * the lean one (softmax_lean + finish_px<LEAN>), unrolled over the classes in registers, taken when every lane of the
+//    wave has finite logits whose spread is at most 64.  Then x - max lies in [-64, 0], so det_expf needs neither its
+//    clamp nor its NaN patch (det_expf_core); every exp is >= 2^-93 and s is in [1, O_T], so v_div_scale would rescale
+//    nothing (it does only when the numerator is below 2^-104 or the quotient would be denormal) and the division
+//    sequence with the reciprocal computed once per pixel returns the identical, correctly rounded bits in 5
+//    instructions per class; the probabilities lie in (0, 1], so p + 1e-6 is a positive normal number and the entropy
+//    may use det_logf_core.  About 60 VALU operations per class and pixel instead of 95 plus 8 exec-mask branches.
+//
+// The NP pixels of a lane share the decision and therefore one basic block, in which the scheduler interleaves their
+// independent chains (that fills the two-cycle hazard slots between v_cmp / v_cndmask pairs).  Built without SLP
+// vectorisation (_build.py): packed v_pk_fma_f32 would save 10 % of the instructions and cost 40 VGPRs.
+
+// General statement for one pixel whose class planes start at lp (stride hw).  is_prob: the planes already hold softmax
+// probabilities (helper-method API).
+__device__ __forceinline__ void px_general(const float *__restrict__ lp, int O, long long hw, int is_prob, int unc_type,
+                                           int pur_type, long long g, float &ent, int &pred)
 {
-    float m = p[0], lo = p[0];
+    float m = 0.0f, s = 1.0f;
+    if (!is_prob) {
+        m = lp[0];
+#pragma unroll 1
+        for (int c = 1; c < O; ++c) { float x = lp[(size_t)c * hw]; m = x > m ? x : m; }
+        s = 0.0f;
+#pragma unroll 1
+        for (int c = 0; c < O; ++c) s = s + det_expf(lp[(size_t)c * hw] - m);
+    }
+    float a = 0.0f, best = 0.0f, pg = 0.0f;
+    int am = 0;               // torch.argmax: first maximal class
+#pragma unroll 1
+    for (int c = 0; c < O; ++c) {
+        const float p = is_prob ? lp[(size_t)c * hw] : det_expf(lp[(size_t)c * hw] - m) / s;
+        if (c == 0 || p > best) { best = p; am = c; }
+        if (c == (int)g) pg = p;
+        a = a + (-p) * det_logf(p + 1e-6f);
+    }
+    if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) ent = a / (float)2.9444389791664403;   // math.log(19): hard-coded in the reference (:74-76)
+    else if (unc_type == HALO_UNC_ORACLE_ACC) ent = 1.0f - (g == 255 ? best : pg);
+    else ent = 0.0f;
+    pred = pur_type == HALO_PUR_ORACLE_RIPU ? (g == 255 ? am : (int)g) : am;
+}
+
+// Lean softmax of NP pixels in registers.  Returns false -- p untouched -- when some lane of the wave needs the general
+// statement.  NaN logits hide from the two running extrema (a comparison with NaN is false), hence the sum t: it is NaN
+// iff a NaN (or both infinities) is among the classes; infinite logits make lo - m infinite or NaN.
+template <int O_T, int NP>
+__device__ __forceinline__ bool softmax_lean(float (&p)[NP][O_T])
+{
+    float m[NP], lo[NP], t[NP];
 #pragma unroll
-    for (int c = 1; c < O_T; ++c) { m = p[c] > m ? p[c] : m; lo = p[c] < lo ? p[c] : lo; }
-    const bool plain = !(lo - m >= -64.0f);                 // also true for NaN / infinite logits
-    float s = 0.0f;
+    for (int j = 0; j < NP; ++j) m[j] = lo[j] = t[j] = p[j][0];
 #pragma unroll
-    for (int c = 0; c < O_T; ++c) { p[c] = det_expf(p[c] - m); s = s + p[c]; }
-    if (__any(plain)) {
+    for (int c = 1; c < O_T; ++c) {
 #pragma unroll
-        for (int c = 0; c < O_T; ++c) p[c] = p[c] / s;
-    } else {
-        float r = __builtin_amdgcn_rcpf(s);
-        r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
-#pragma unroll
-        for (int c = 0; c < O_T; ++c) {
-            float q = p[c] * r;
-            q = __builtin_fmaf(__builtin_fmaf(-s, q, p[c]), r, q);
-            p[c] = __builtin_fmaf(__builtin_fmaf(-s, q, p[c]), r, q);
+        for (int j = 0; j < NP; ++j) {
+            m[j] = p[j][c] > m[j] ? p[j][c] : m[j];
+            lo[j] = p[j][c] < lo[j] ? p[j][c] : lo[j];
+            t[j] = t[j] + p[j][c];
         }
+    }
+    bool general = false;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) general = general || !(lo[j] - m[j] >= -64.0f) || t[j] != t[j];
+    if (__any(general)) return false;
+    float s[NP], r[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) s[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < O_T; ++c) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { p[j][c] = det_expf_core(p[j][c] - m[j]); s[j] = s[j] + p[j][c]; }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        r[j] = __builtin_amdgcn_rcpf(s[j]);
+        r[j] = __builtin_fmaf(__builtin_fmaf(-s[j], r[j], 1.0f), r[j], r[j]);
+    }
+#pragma unroll
+    for (int c = 0; c < O_T; ++c) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            float q = p[j][c] * r[j];
+            q = __builtin_fmaf(__builtin_fmaf(-s[j], q, p[j][c]), r[j], q);
+            p[j][c] = __builtin_fmaf(__builtin_fmaf(-s[j], q, p[j][c]), r[j], q);
+        }
+    }
+    return true;
+}
+
+// General softmax in registers, for logits that exist nowhere in memory (the fused low-resolution path).
+template <int O_T, int NP>
+__device__ __forceinline__ void softmax_general(float (&p)[NP][O_T])
+{
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        float m = p[j][0], s = 0.0f;
+#pragma unroll
+        for (int c = 1; c < O_T; ++c) m = p[j][c] > m ? p[j][c] : m;
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) { p[j][c] = det_expf(p[j][c] - m); s = s + p[j][c]; }
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) p[j][c] = p[j][c] / s;
     }
 }
 
-// One pixel, classes in registers.  Writes ent (per unc_type) and pred (per pur_type).
-template <int O_T>
-__device__ __forceinline__ void logit_px(float (&p)[O_T], int unc_type, int pur_type, long long g, float &ent, int &pred)
+// From the probabilities of NP pixels: ent (per unc_type) and pred (per pur_type).  LEAN: p came from softmax_lean.
+template <int O_T, int NP, bool LEAN>
+__device__ __forceinline__ void finish_px(float (&p)[NP][O_T], int unc_type, int pur_type, const long long (&g)[NP],
+                                          float (&ent)[NP], int (&pred)[NP])
 {
-    softmax_regs<O_T>(p);
-    int am = 0;               // torch.argmax: first maximal class
-    float best = p[0];
+    int am[NP];               // torch.argmax: first maximal class
+    float best[NP];
 #pragma unroll
-    for (int c = 1; c < O_T; ++c) { const bool gtb = p[c] > best; am = gtb ? c : am; best = gtb ? p[c] : best; }
+    for (int j = 0; j < NP; ++j) { am[j] = 0; best[j] = p[j][0]; }
+#pragma unroll
+    for (int c = 1; c < O_T; ++c)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { const bool gtb = p[j][c] > best[j]; am[j] = gtb ? c : am[j]; best[j] = gtb ? p[j][c] : best[j]; }
     if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) {
-        float a = 0.0f;
+        float a[NP];
 #pragma unroll
-        for (int c = 0; c < O_T; ++c) a = a + (-p[c]) * det_logf(p[c] + 1e-6f);
-        ent = a / (float)2.9444389791664403;   // math.log(19): hard-coded in the reference (:74-76)
+        for (int j = 0; j < NP; ++j) a[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < O_T; ++c) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const float q = p[j][c] + 1e-6f;
+                a[j] = a[j] + (-p[j][c]) * (LEAN ? det_logf_core(q) : det_logf(q));
+            }
+            }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) ent[j] = a[j] / (float)2.9444389791664403;   // math.log(19): hard-coded in the reference (:74-76)
     } else if (unc_type == HALO_UNC_ORACLE_ACC) {
-        const int gi = g == 255 ? am : (int)g;
-        float pg = 0.0f;
 #pragma unroll
-        for (int c = 0; c < O_T; ++c) pg = c == gi ? p[c] : pg;
-        ent = 1.0f - pg;
+        for (int j = 0; j < NP; ++j) {
+            const int gi = g[j] == 255 ? am[j] : (int)g[j];
+            float pg = 0.0f;
+#pragma unroll
+            for (int c = 0; c < O_T; ++c) pg = c == gi ? p[j][c] : pg;
+            ent[j] = 1.0f - pg;
+        }
     } else {
-        ent = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) ent[j] = 0.0f;
     }
-    pred = pur_type == HALO_PUR_ORACLE_RIPU ? (g == 255 ? am : (int)g) : am;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pred[j] = pur_type == HALO_PUR_ORACLE_RIPU ? (g[j] == 255 ? am[j] : (int)g[j]) : am[j];
 }
 
 template <int O_T, int VEC>
@@ -141,10 +238,14 @@ __global__ void __launch_bounds__(TPB) k_logit_maps(const float *__restrict__ lo
     }
     float e[VEC];
     int pr[VEC];
+    long long g[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const long long g = need_gt ? gt[(size_t)b * hw + i0 + j] : 0;
-        logit_px<O_T>(v[j], unc_type, pur_type, g, e[j], pr[j]);
+    for (int j = 0; j < VEC; ++j) g[j] = need_gt ? gt[(size_t)b * hw + i0 + j] : 0;
+    if (softmax_lean<O_T, VEC>(v)) {
+        finish_px<O_T, VEC, true>(v, unc_type, pur_type, g, e, pr);
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < VEC; ++j) px_general(lp + j, O_T, hw, 0, unc_type, pur_type, g[j], e[j], pr[j]);
     }
     float *ep = ent + (size_t)b * hw + i0;
     if constexpr (VEC == 4) {
@@ -167,32 +268,13 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_generic(const float *__restr
     const int b = blockIdx.y;
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= hw) return;
-    const float *lp = logit + (size_t)b * bstride + i;
-    float m = 0.0f, s = 1.0f;
-    if (!is_prob) {      // is_prob: the tensor already holds softmax probabilities (helper-method API)
-        m = lp[0];
-        for (int c = 1; c < O; ++c) { float x = lp[(size_t)c * hw]; m = x > m ? x : m; }
-        s = 0.0f;
-        for (int c = 0; c < O; ++c) s = s + det_expf(lp[(size_t)c * hw] - m);
-    }
     const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
     const long long g = need_gt ? gt[(size_t)b * hw + i] : 0;
-    float a = 0.0f, best = 0.0f, pg = 0.0f;
-    int am = 0;
-    for (int c = 0; c < O; ++c) {
-        const float p = is_prob ? lp[(size_t)c * hw] : det_expf(lp[(size_t)c * hw] - m) / s;
-        if (c == 0 || p > best) { best = p; am = c; }
-        if (c == (int)g) pg = p;
-        a = a + (-p) * det_logf(p + 1e-6f);
-    }
     float e;
-    if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) e = a / (float)2.9444389791664403;
-    else if (unc_type == HALO_UNC_ORACLE_ACC) {
-        if (g == 255) pg = best;
-        e = 1.0f - pg;
-    } else e = 0.0f;
+    int pr;
+    px_general(logit + (size_t)b * bstride + i, O, hw, is_prob, unc_type, pur_type, g, e, pr);
     ent[(size_t)b * hw + i] = e;
-    if (pred) pred[(size_t)b * hw + i] = (short)(pur_type == HALO_PUR_ORACLE_RIPU ? (g == 255 ? am : (int)g) : am);
+    if (pred) pred[(size_t)b * hw + i] = (short)pr;
 }
 
 // ---------------------------------------------------------------- features -> radius / norm (HBM roofline)
@@ -222,9 +304,11 @@ template <typename T> struct VecLoad<T, 1> {
 
 // MODE 0: poincare_distance_origin (pur 'radius' / 'hyper'), MODE 1: decoder_out.norm(dim=1) ('euc_norm')
 // FO > 0: also compute the per-pixel entropy of the FO-class logits of the same pixels (what
-// k_logit_maps does for unc 'entropy'/'pixel_entropy').  That work is ~1.7k VALU instructions per
-// pixel against 2 KiB of HBM traffic, so it runs in the memory shadow of the other resident waves
-// instead of costing a kernel of its own.
+// k_logit_maps does for unc 'entropy'/'pixel_entropy').  That work is ~1.2k VALU instructions per
+// pixel against 1-2 KiB of HBM traffic, so it runs in the memory shadow of the other resident waves
+// instead of costing a kernel of its own: with the entropy arithmetic compiled out the kernel takes
+// the same time (6.10 vs 6.13 ms per 16 float32 images), with the logit loads compiled out it takes
+// the time of the feature walk alone -- the fused entropy costs exactly its 76 bytes per pixel.
 template <typename T, int VEC, int MODE, int UNROLL, int FO>
 __global__ void __launch_bounds__(FTPB) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
                                                      long long hw, double ks, double rks, T *__restrict__ out,
@@ -232,76 +316,78 @@ __global__ void __launch_bounds__(FTPB) k_feat_reduce(const T *__restrict__ feat
                                                      long long lbstride, int unc_type, float *__restrict__ ent)
 {
     const int b = blockIdx.y;
-    const long long i0 = ((long long)blockIdx.x * FTPB + threadIdx.x) * VEC;
+    // every address below is (block-uniform base, kept in SGPRs) + (this lane's offset inside the block, one VGPR)
+    const long long blk0 = (long long)blockIdx.x * (FTPB * VEC);
+    const unsigned lane0 = threadIdx.x * VEC;
+    const long long i0 = blk0 + lane0;
     const bool live = i0 < hw;
     T acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = (T)0;
-    // fused entropy of this lane's pixels (FO > 0).  Odd blocks run it BEFORE the channel loop, even
+    // fused entropy of this block's pixels (FO > 0).  Odd blocks run it BEFORE the channel loop, even
     // blocks after it, so that at any moment about half of a CU's resident waves are in their VALU
     // phase and half are streaming -- identical blocks launched together would otherwise move
     // through the two phases in lockstep and the VALU work would not hide behind the loads.
     auto entropy_part = [&]() {
         if constexpr (FO > 0) {
-            const float *lp = logit + (size_t)b * lbstride + i0;
-            if constexpr (VEC == 4) {
-                // four pixels per lane: two passes of two pixels keep the class values of only two pixels
-                // live (38 instead of 76 VGPRs), which is worth 3 more resident waves per SIMD
-                float e[4];
-#pragma unroll 1
-                for (int half = 0; half < 2; ++half) {
-                    float lv[2][FO];
+            const float *lp = logit + (size_t)b * lbstride + blk0;
+            float *eb = ent + (size_t)b * hw + blk0;
+            // NP = two pixels at a time (four per lane: two parts), so that the class values of only two pixels are live
+            // (38 VGPRs).  The entropy has its own pixel-to-lane map: part k covers the k-th run of FTPB * NP consecutive
+            // pixels of the block, lane t the t-th pair of it, so that a wave's load of a class plane is one contiguous
+            // 512-byte run (the walk's map -- 4 consecutive pixels per lane -- would use half of every line it touches).
+            constexpr int NP = VEC >= 2 ? 2 : 1;
 #pragma unroll
-                    for (int c2 = 0; c2 < FO; ++c2) {
-                        const float2 q = *reinterpret_cast<const float2 *>(lp + (size_t)c2 * hw + 2 * half);
-                        lv[0][c2] = q.x; lv[1][c2] = q.y;
+            for (int part = 0; part < VEC / NP; ++part) {
+                const unsigned off = part * (FTPB * NP) + threadIdx.x * NP;
+                if (blk0 + off < hw) {
+                    float lv[NP][FO];
+                    const float *plane = lp;               // advanced by scalar adds: the plane bases stay in SGPRs
+#pragma unroll
+                    for (int c2 = 0; c2 < FO; ++c2, plane += hw) {
+                        if constexpr (NP == 2) {
+                            const float2 q = *reinterpret_cast<const float2 *>(plane + off);
+                            lv[0][c2] = q.x; lv[1][c2] = q.y;
+                        } else {
+                            lv[0][c2] = plane[off];
+                        }
                     }
-                    int pr;
-                    float e0, e1;
-                    logit_px<FO>(lv[0], unc_type, HALO_PUR_NONE, 0, e0, pr);
-                    logit_px<FO>(lv[1], unc_type, HALO_PUR_NONE, 0, e1, pr);
-                    e[2 * half] = e0; e[2 * half + 1] = e1;
-                    if (half == 0) { e[2] = 0.0f; e[3] = 0.0f; }
-                    *reinterpret_cast<float2 *>(ent + (size_t)b * hw + i0 + 2 * half) = make_float2(e0, e1);
-                }
-            } else {
-                float lv[VEC][FO];
+                    float e[NP];
+                    int pr[NP];
+                    long long gz[NP];
 #pragma unroll
-                for (int c2 = 0; c2 < FO; ++c2) {
-                    if constexpr (VEC == 2) {
-                        const float2 q = *reinterpret_cast<const float2 *>(lp + (size_t)c2 * hw);
-                        lv[0][c2] = q.x; lv[1][c2] = q.y;
+                    for (int j = 0; j < NP; ++j) gz[j] = 0;
+                    if (softmax_lean<FO, NP>(lv)) {
+                        finish_px<FO, NP, true>(lv, unc_type, HALO_PUR_NONE, gz, e, pr);
                     } else {
-                        lv[0][c2] = lp[(size_t)c2 * hw];
+#pragma unroll 1
+                        for (int j = 0; j < NP; ++j) px_general(lp + off + j, FO, hw, 0, unc_type, HALO_PUR_NONE, 0, e[j], pr[j]);
                     }
+                    if constexpr (NP == 2) *reinterpret_cast<float2 *>(eb + off) = make_float2(e[0], e[1]);
+                    else eb[off] = e[0];
                 }
-                float e[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) { int pr; logit_px<FO>(lv[j], unc_type, HALO_PUR_NONE, 0, e[j], pr); }
-                float *ep = ent + (size_t)b * hw + i0;
-                if constexpr (VEC == 2) *reinterpret_cast<float2 *>(ep) = make_float2(e[0], e[1]);
-                else ep[0] = e[0];
+                __builtin_amdgcn_sched_barrier(0);      // keep the next part's loads (and registers) out of this one
             }
         }
     };
     const bool ent_first = (blockIdx.x & 1) != 0;
     double mn = 0.0, mx = 0.0;
-    if (live) {
-        if (ent_first) entropy_part();
-        const T *p = feat + (size_t)b * bstride + i0;
+    // the channel walk: two copies of this short code (before or after the entropy), one of the long entropy code
+    auto walk = [&]() {
+        const T *p = feat + (size_t)b * bstride + blk0;      // advanced by scalar adds: the plane bases stay in SGPRs
         int c = 0;
         for (; c + UNROLL <= C; c += UNROLL) {
             T v[UNROLL][VEC];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) VecLoad<T, VEC>::ld(p + (size_t)(c + u) * hw, v[u]);
+            for (int u = 0; u < UNROLL; ++u, p += hw) VecLoad<T, VEC>::ld(p + lane0, v[u]);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[j] = fma_t(v[u][j], v[u][j], acc[j]);
         }
-        for (; c < C; ++c) {
+        for (; c < C; ++c, p += hw) {
             T v[VEC];
-            VecLoad<T, VEC>::ld(p + (size_t)c * hw, v);
+            VecLoad<T, VEC>::ld(p + lane0, v);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = fma_t(v[j], v[j], acc[j]);
         }
@@ -312,14 +398,20 @@ __global__ void __launch_bounds__(FTPB) k_feat_reduce(const T *__restrict__ feat
             else if constexpr (sizeof(T) == 8) r[j] = __builtin_sqrt(acc[j]);
             else r[j] = __builtin_sqrtf(acc[j]);
         }
-        T *op = out + (size_t)b * hw + i0;
+        T *op = (out + (size_t)b * hw + blk0) + lane0;
         if constexpr (VEC == 2) *reinterpret_cast<double2 *>(op) = make_double2(r[0], r[1]);
         else if constexpr (VEC == 4) *reinterpret_cast<float4 *>(op) = make_float4(r[0], r[1], r[2], r[3]);
         else op[0] = r[0];
         mn = mx = (double)r[0];
 #pragma unroll
         for (int j = 1; j < VEC; ++j) { mn = nan_min(mn, (double)r[j]); mx = nan_max(mx, (double)r[j]); }
-        if (!ent_first) entropy_part();
+    };
+    if constexpr (FO > 0) {
+        if (live && !ent_first) walk();
+        entropy_part();
+        if (live && ent_first) walk();
+    } else {
+        if (live) walk();
     }
     // dead lanes of the last block take thread 0's value (always live) so they cannot disturb min/max
     __shared__ double seed[2];
@@ -787,19 +879,24 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__
     const float w00 = ty.l0 * tx.l0, w01 = ty.l0 * tx.l1, w10 = ty.l1 * tx.l0, w11 = ty.l1 * tx.l1;
     const float *lb = logit + (size_t)b * bstride;
     const size_t a00 = (size_t)ty.i0 * w + tx.i0, a01 = (size_t)ty.i0 * w + tx.i1, a10 = (size_t)ty.i1 * w + tx.i0, a11 = (size_t)ty.i1 * w + tx.i1;
-    float p[O_T];
+    float p[1][O_T];
 #pragma unroll
     for (int c = 0; c < O_T; ++c) {
         const float *pl = lb + (size_t)c * h * w;
-        p[c] = lerp4<float>(pl[a00], pl[a01], pl[a10], pl[a11], w00, w01, w10, w11);
+        p[0][c] = lerp4<float>(pl[a00], pl[a01], pl[a10], pl[a11], w00, w01, w10, w11);
     }
     const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
-    const long long g = need_gt ? gt[(size_t)b * hw + i] : 0;
-    float e;
-    int pr;
-    logit_px<O_T>(p, unc_type, pur_type, g, e, pr);
-    ent[(size_t)b * hw + i] = e;
-    if (pred) pred[(size_t)b * hw + i] = (short)pr;
+    const long long g[1] = {need_gt ? gt[(size_t)b * hw + i] : 0};
+    float e[1];
+    int pr[1];
+    if (softmax_lean<O_T, 1>(p)) {
+        finish_px<O_T, 1, true>(p, unc_type, pur_type, g, e, pr);
+    } else {
+        softmax_general<O_T, 1>(p);
+        finish_px<O_T, 1, false>(p, unc_type, pur_type, g, e, pr);
+    }
+    ent[(size_t)b * hw + i] = e[0];
+    if (pred) pred[(size_t)b * hw + i] = (short)pr[0];
 }
 
 // any class count: materialise the interpolated logits of a strip into scratch, then the generic kernel
@@ -831,7 +928,7 @@ static void launch_feat(const T *feat, long long bstride, int C, long long hw, i
                         T *out, double *partials, int nblk, hipStream_t st, const FusedLogit *fl = nullptr)
 {
     dim3 grid(nblk, B), block(FTPB);
-    constexpr int UNROLL = 8;
+    constexpr int UNROLL = 8;      // channel planes in flight per lane (16: no gain beside the selection kernels, 6 % slower alone)
 #define HALO_FEAT(M, FO_)                                                                                               \
     hipLaunchKernelGGL((k_feat_reduce<T, VEC, M, UNROLL, FO_>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, \
                        partials, fl ? fl->logit : nullptr, fl ? fl->bstride : 0ll, fl ? fl->unc_type : 0, fl ? fl->ent : nullptr)

@@ -255,12 +255,9 @@ static int launch_serial(const SelGeom &g, size_t lds, dim3 grid, hipStream_t st
                          uint8_t *active, uint8_t *selected, int64_t *active_mask, const int64_t *gt, double *picks,
                          int32_t *n_picked, const SelHdr *resume)
 {
-    static bool attr_set = false;       // per instantiation: tile tables above 64 KiB need the dynamic-LDS limit raised
-    if (lds > 64 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute((const void *)k_greedy_select<T, A, B_, EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-            return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static LdsLimitSeen seen;           // per instantiation: tile tables above 64 KiB need the dynamic-LDS limit raised
+    if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_greedy_select<T, A, B_, EPT>, 128 * 1024))
+        return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL((k_greedy_select<T, A, B_, EPT>), grid, dim3(SEL_TPB), lds, st, (T *)score, g, n_regions, arad, mrad, active,
                        selected, (long long *)active_mask, (const long long *)gt, picks, n_picked, resume);
     return HALO_OK;

@@ -784,12 +784,9 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     hipLaunchKernelGGL(k_sel_scan2, dim3((unsigned)B), blk, 0, st, ws, g);
     const unsigned gs = (unsigned)(cdiv(g.captot, 256) < 256 ? cdiv(g.captot, 256) : 256);
     hipLaunchKernelGGL(k_sel_scatter, dim3(gs, (unsigned)B), blk, 0, st, ws, g);
-    static bool attr_set = false;
-    if (!attr_set) {       // the pick grid may need more than the default 64 KiB of dynamic LDS
-        if (hipFuncSetAttribute((const void *)k_sel_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static LdsLimitSeen seen;      // the pick grid may need more than the default 64 KiB of dynamic LDS
+    if (!raise_lds_limit(seen, (const void *)k_sel_sweep, 160 * 1024))
+        return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(k_sel_sweep, dim3((unsigned)B), dim3(SW_TPB), p.lds_bytes, st, ws, g, n_picked);
     const dim3 ga((unsigned)cdiv(g.n_regions, 4), (unsigned)B);
     if (dtype == HALO_F64)

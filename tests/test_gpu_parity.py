@@ -1403,6 +1403,9 @@ def test_softmax_shared_reciprocal_path_and_plain_division_path_bitwise(dev):
         logit[:, :, :, 64:96] *= 80.0                              # far beyond: denormal / zero probabilities
         logit[:, 0, 10, 100:128] = 1e30                            # overflowing differences
         logit[:, 1, 11, 100:128] = -np.inf
+        logit[:, 2, 12, 96:128] = np.nan                           # a NaN that is not class 0 hides from the running max / min
+        logit[:, 0, 13, 64:80] = np.nan
+        logit[:, 3, 14, 0:8] = np.inf
         gt = rng.integers(0, O, (H, W)).astype(np.int64)
         for unc, pur in (("entropy", "radius"), ("entropy", "ripu"), ("oracle_acc", "oracle_ripu")):
             so, io, uo = ho.floating_region_score(logit, emb, unc, pur, False, gt, size=3, purity_type=pur)
