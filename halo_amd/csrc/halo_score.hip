@@ -752,10 +752,73 @@ __device__ __forceinline__ T lerp4(T v00, T v01, T v10, T v11, T w00, T w01, T w
     return fma_t(v11, w11, a);
 }
 
-constexpr int LR_STAGE_IT = 2, LR_STAGE_G = 4;      // window elements per lane with precomputed offsets (<= 128 taps), channels per group
-constexpr int LR_TW = 64, LR_TH = 16, LR_PPT = 4;   // 64 x 16 output pixels per 256-thread block, 4 rows per thread
+constexpr int LR_STAGE_IT = 3, LR_STAGE_G = 4;      // window elements per lane with precomputed offsets (<= 192 taps), channels per group
+constexpr int LR_TW = 64, LR_TH = 16, LR_PPT = 4;   // 64 x 16 output pixels per 256-thread block; a wave owns 4 consecutive rows x 64 columns
+
+// One channel chunk of the window for a lane's LR_PPT vertically adjacent pixels, when their upper tap rows are
+// R + {0, PAT bit 0, PAT bit 1, PAT bit 2} (wave-uniform, compile-time): the lane reads the 2 or 3 source rows once per
+// channel -- 4 or 6 LDS words instead of the 16 of four independent pixels -- and every pixel picks its rows by register
+// name.  The LDS pipe (128 bytes per clock and CU, shared by the four SIMDs) is what bounds this kernel, not the 5 float64
+// operations per pixel and channel.  Same lerp4 per pixel as the generic loop, so the same bits.
+// The six LDS words of a lane (rows R..R+2, columns q and q + 1).  For 8-byte elements they are read by hand-written
+// ds_read_b64 (2 LDS cycles each, 256 bytes per clock): the compiler fuses each (q, q + 1) pair into one ds_read2_b64,
+// which moves the same 16 bytes per lane in 16 LDS cycles and leaves the kernel bound by the LDS pipe at 2.4x its float64
+// arithmetic (the pair is only 8-byte aligned, so ds_read_b128 is not an option).  The wait is part of the statement, so
+// the values are architecturally ready when the compiler sees them; the latency hides behind the SIMD's other waves.
+template <typename T, int PAT> struct LrRows {
+    T v[3][2];
+    __device__ __forceinline__ void load(const T *__restrict__ tp, int stride)
+    {
+        if constexpr (sizeof(T) == 8) {
+            typedef __attribute__((address_space(3))) const T *lds_ptr;
+            const unsigned a0 = (unsigned)(uintptr_t)(lds_ptr)tp, a1 = a0 + (unsigned)stride * 8u;
+            if constexpr (PAT != 0) {
+                const unsigned a2 = a1 + (unsigned)stride * 8u;
+                asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %7\n\tds_read_b64 %3, %7 offset:8\n\t"
+                             "ds_read_b64 %4, %8\n\tds_read_b64 %5, %8 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]), "=&v"(v[2][1])
+                             : "v"(a0), "v"(a1), "v"(a2)
+                             : "memory");
+            } else {
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1])
+                             : "v"(a0), "v"(a1)
+                             : "memory");
+            }
+        } else {
+            v[0][0] = tp[0]; v[0][1] = tp[1];
+            v[1][0] = tp[stride]; v[1][1] = tp[stride + 1];
+            if constexpr (PAT != 0) { v[2][0] = tp[2 * stride]; v[2][1] = tp[2 * stride + 1]; }
+        }
+    }
+    __device__ __forceinline__ void accumulate(const T (&w00)[LR_PPT], const T (&w01)[LR_PPT], const T (&w10)[LR_PPT],
+                                               const T (&w11)[LR_PPT], T (&acc)[LR_PPT]) const
+    {
+#pragma unroll
+        for (int j = 0; j < LR_PPT; ++j) {
+            const int a = j == 0 ? 0 : (PAT >> (j - 1)) & 1;      // 0 or 1; a + 1 == 2 only when PAT != 0
+            const T x = lerp4<T>(v[a][0], v[a][1], v[a + 1][0], v[a + 1][1], w00[j], w01[j], w10[j], w11[j]);
+            acc[j] = fma_t(x, x, acc[j]);
+        }
+    }
+};
+template <typename T, int PAT>
+__device__ __forceinline__ void lr_rows_chunk(const T *__restrict__ tp, int cc, int plane, int stride, const T (&w00)[LR_PPT],
+                                              const T (&w01)[LR_PPT], const T (&w10)[LR_PPT], const T (&w11)[LR_PPT], T (&acc)[LR_PPT])
+{
+#pragma unroll 1
+    for (int ch = 0; ch < cc; ++ch, tp += plane) {
+        LrRows<T, PAT> A;
+        A.load(tp, stride);
+        A.accumulate(w00, w01, w10, w11, acc);
+    }
+}
 
 // Features: per output pixel  sum_c (interp_c)^2  with the low-res taps of a channel chunk staged in LDS.
+// The staged window carries one extra row and column whose source coordinates are clamped to the grid, so that "the next
+// row / column" is always readable and, at the bottom / right edge of the image, holds the clamped tap the reference uses
+// there (i1 == i0).
 template <typename T, int MODE>
 __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ feat, long long bstride, int C, int h, int w,
                                                         int H, int W, T sh, T sw, int max_rows, int max_cols, int CC,
@@ -764,29 +827,44 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
     T *tile = reinterpret_cast<T *>(lr_smem);                    // [CC][max_rows][max_cols]
-    const int b = blockIdx.z;
-    const int X0 = blockIdx.x * LR_TW, Y0 = blockIdx.y * LR_TH;
-    const int lx = threadIdx.x & (LR_TW - 1), ly = threadIdx.x / LR_TW;      // ly in 0..3
+    // Tile <-> block: workgroups go to the 8 XCDs round-robin in launch order, each XCD with its own L2.  Tiles that are
+    // neighbours along x share the source lines at their common border (a tile's 19-element window rows straddle two
+    // 128-byte lines), so in launch order every line would be fetched by two XCDs.  Give the blocks that share an XCD
+    // (id % 8) one contiguous eighth of the row-major tile list instead -- bijective for any tile count.
+    const unsigned ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty * gridDim.z;
+    const unsigned lin = blockIdx.x + ntx * (blockIdx.y + nty * blockIdx.z);
+    const unsigned xq = ntiles / 8, xr = ntiles % 8, xk = lin % 8;
+    const unsigned tile_id = (xk < xr ? xk * (xq + 1) : xr * (xq + 1) + (xk - xr) * xq) + lin / 8;
+    const int bx = (int)(tile_id % ntx), by = (int)((tile_id / ntx) % nty);
+    const int b = (int)(tile_id / (ntx * nty));
+    const int X0 = bx * LR_TW, Y0 = by * LR_TH;
+    const int lx = threadIdx.x & (LR_TW - 1), ly = threadIdx.x / LR_TW;      // ly = wave in 0..3
     const int x = X0 + lx;
     // tap window of this block in the low-res grid
     const int ylast = (Y0 + LR_TH - 1 < H ? Y0 + LR_TH - 1 : H - 1), xlast = (X0 + LR_TW - 1 < W ? X0 + LR_TW - 1 : W - 1);
     const int ty_lo = make_taps<T>(Y0, sh, h).i0, ty_hi = make_taps<T>(ylast, sh, h).i1;
     const int tx_lo = make_taps<T>(X0, sw, w).i0, tx_hi = make_taps<T>(xlast, sw, w).i1;
-    const int rows = ty_hi - ty_lo + 1, cols = tx_hi - tx_lo + 1;            // <= max_rows / max_cols by construction
+    const int rows = ty_hi - ty_lo + 2, cols = tx_hi - tx_lo + 2;            // with the extra row / column; <= max_rows / max_cols
     const bool xin = x < W;
     const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
     T acc[LR_PPT], w00[LR_PPT], w01[LR_PPT], w10[LR_PPT], w11[LR_PPT];
     int o00[LR_PPT], o10[LR_PPT];
     bool live[LR_PPT];
+    int a0 = 0, pat = 0;
+    bool regular = true;         // wave-uniform: the rows' upper taps are R + {0, 1}
 #pragma unroll
     for (int j = 0; j < LR_PPT; ++j) {
-        const int y = Y0 + ly + j * (LR_TH / LR_PPT);
+        const int y = Y0 + ly * LR_PPT + j;
         live[j] = xin && y < H;
         const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
         w00[j] = ty.l0 * tx.l0; w01[j] = ty.l0 * tx.l1; w10[j] = ty.l1 * tx.l0; w11[j] = ty.l1 * tx.l1;
         o00[j] = (ty.i0 - ty_lo) * max_cols + (tx.i0 - tx_lo);
         o10[j] = (ty.i1 - ty_lo) * max_cols + (tx.i0 - tx_lo);
         acc[j] = (T)0;
+        if (j == 0) a0 = ty.i0;
+        const int d = ty.i0 - a0;                                  // non-decreasing in j
+        regular = regular && (d == 0 || d == 1);
+        if (j > 0) pat |= (d & 1) << (j - 1);
     }
     const int dx1 = tx.i1 - tx.i0;
     const T *fb = feat + (size_t)b * bstride;
@@ -798,47 +876,61 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
     for (int it = 0; it < LR_STAGE_IT; ++it) {
         const int e = (threadIdx.x & 63) + 64 * it;
         const int r = e / cols, q = e % cols;
+        const int sr = ty_lo + r < h - 1 ? ty_lo + r : h - 1, sq = tx_lo + q < w - 1 ? tx_lo + q : w - 1;
         st_ok[it] = e < rows * cols;
-        st_src[it] = (ty_lo + r) * w + (tx_lo + q);
+        st_src[it] = sr * w + sq;
         st_dst[it] = r * max_cols + q;
     }
+    const int upat = __builtin_amdgcn_readfirstlane(regular ? pat : -1);       // the rows of a wave are shared by its lanes
+    // Staging: wave k of the block owns channels k, k + 4, ... of a chunk (CC <= 4 * LR_STAGE_G, so at most LR_STAGE_G
+    // of them), its lanes walk the window with precomputed offsets; all loads are issued before the first LDS write so
+    // that the chunk costs one memory round trip.  (Issuing the loads of chunk n + 1 before the arithmetic of chunk n
+    // gained 7 %, less than the 24 registers it holds are worth to the LDS double buffer of lr_rows_chunk.)
+    const int wv = threadIdx.x >> 6;
     for (int c0 = 0; c0 < C; c0 += CC) {
         const int cc = C - c0 < CC ? C - c0 : CC;
         __syncthreads();                                          // previous chunk fully consumed
-        // stage the chunk: a wave walks the channels (LR_STAGE_G at a time), its lanes walk the window with
-        // precomputed offsets; all loads of a group are issued before the first LDS write so that the
-        // group costs one memory round trip, not one per load
-        for (int ch0 = threadIdx.x >> 6; ch0 < cc; ch0 += (TPB / 64) * LR_STAGE_G) {
-            T v[LR_STAGE_G][LR_STAGE_IT];
+        {
+            T pre[LR_STAGE_G][LR_STAGE_IT];
 #pragma unroll
             for (int gI = 0; gI < LR_STAGE_G; ++gI) {
-                const int ch = ch0 + gI * (TPB / 64);
+                const int ch = wv + gI * (TPB / 64);
                 const T *src = fb + (size_t)(c0 + (ch < cc ? ch : 0)) * h * w;
 #pragma unroll
-                for (int it = 0; it < LR_STAGE_IT; ++it) v[gI][it] = (st_ok[it] && ch < cc) ? src[st_src[it]] : (T)0;
+                for (int it = 0; it < LR_STAGE_IT; ++it) pre[gI][it] = (st_ok[it] && ch < cc) ? src[st_src[it]] : (T)0;
             }
 #pragma unroll
             for (int gI = 0; gI < LR_STAGE_G; ++gI) {
-                const int ch = ch0 + gI * (TPB / 64);
+                const int ch = wv + gI * (TPB / 64);
                 if (ch < cc) {
                     T *dst = tile + ch * plane;
 #pragma unroll
                     for (int it = 0; it < LR_STAGE_IT; ++it)
-                        if (st_ok[it]) dst[st_dst[it]] = v[gI][it];
+                        if (st_ok[it]) dst[st_dst[it]] = pre[gI][it];
                     for (int e = (threadIdx.x & 63) + 64 * LR_STAGE_IT; e < rows * cols; e += 64) {   // very large windows
                         const int r = e / cols, q = e % cols;
-                        dst[r * max_cols + q] = fb[(size_t)(c0 + ch) * h * w + (size_t)(ty_lo + r) * w + (tx_lo + q)];
+                        const int sr = ty_lo + r < h - 1 ? ty_lo + r : h - 1, sq = tx_lo + q < w - 1 ? tx_lo + q : w - 1;
+                        dst[r * max_cols + q] = fb[(size_t)(c0 + ch) * h * w + (size_t)sr * w + sq];
                     }
                 }
             }
         }
         __syncthreads();
-        for (int ch = 0; ch < cc; ++ch) {
-            const T *tp = tile + ch * plane;
+        const T *t0 = tile + o00[0];
+        if (upat == 0) lr_rows_chunk<T, 0>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
+        else if (upat == 4) lr_rows_chunk<T, 4>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
+        else if (upat == 6) lr_rows_chunk<T, 6>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
+        else if (upat == 7) lr_rows_chunk<T, 7>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
+        else {
+            // any other geometry (factors below 3, rows clamped past the image): four independent pixels
+#pragma unroll 1
+            for (int ch = 0; ch < cc; ++ch) {
+                const T *tp = tile + ch * plane;
 #pragma unroll
-            for (int j = 0; j < LR_PPT; ++j) {
-                const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
-                acc[j] = fma_t(v, v, acc[j]);
+                for (int j = 0; j < LR_PPT; ++j) {
+                    const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
+                    acc[j] = fma_t(v, v, acc[j]);
+                }
             }
         }
     }
@@ -847,7 +939,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
 #pragma unroll
     for (int j = 0; j < LR_PPT; ++j) {
         if (!live[j]) continue;
-        const int y = Y0 + ly + j * (LR_TH / LR_PPT);
+        const int y = Y0 + ly * LR_PPT + j;
         T r;
         if constexpr (MODE == 0) r = dist0_from_ssq(acc[j], ks, rks);
         else if constexpr (sizeof(T) == 8) r = __builtin_sqrt(acc[j]);
@@ -860,8 +952,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
     if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }         // thread 0 (pixel X0,Y0) is always live
     __syncthreads();
     if (!have) { mn = seed[0]; mx = seed[1]; }
-    const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    block_minmax<TPB>(mn, mx, partials + blk * 2);
+    block_minmax<TPB>(mn, mx, partials + (size_t)tile_id * 2);
 }
 
 // Logits: interpolate the O class planes at one output pixel, then the same entropy / prediction code.
@@ -1009,15 +1100,12 @@ static int launch_feat_lr(const T *feat, long long bstride, int C, const LrDims 
     int max_rows, max_cols;
     lr_window<T>(H, lr.hf, LR_TH, max_rows);
     lr_window<T>(W, lr.wf, LR_TW, max_cols);
+    ++max_rows; ++max_cols;       // the staged window carries one clamped extra row and column (k_feat_reduce_lr)
     const size_t plane_bytes = (size_t)max_rows * max_cols * sizeof(T);
     if (plane_bytes > 48 * 1024) return fail(HALO_E_UNSUPPORTED, "halo_score_maps_lr: source window too large for LDS (downsampling?)");
-    // a small chunk (<= 16 KiB of LDS per block) keeps 8 blocks resident per CU, so one block's staging
-    // loads overlap the others' interpolation (there is no intra-block double buffering)
-    size_t budget = 16 * 1024;
-    if (const char *e = getenv("HALO_LR_LDS_KB")) budget = (size_t)atoi(e) * 1024;
-    if (budget < plane_bytes) budget = plane_bytes;
-    if (budget > 48 * 1024) budget = 48 * 1024;
-    int CC = (int)(budget / plane_bytes);
+    // channels per chunk: what the block's four waves prefetch in one group each (k_feat_reduce_lr), LDS permitting
+    int CC = (int)((48 * 1024) / plane_bytes);
+    CC = CC > (TPB / 64) * LR_STAGE_G ? (TPB / 64) * LR_STAGE_G : CC;
     CC = CC > C ? C : CC;
     const T sh = H > 1 ? (T)(lr.hf - 1) / (T)(H - 1) : (T)0, sw = W > 1 ? (T)(lr.wf - 1) / (T)(W - 1) : (T)0;
     dim3 grid((unsigned)cdiv(W, LR_TW), (unsigned)cdiv(H, LR_TH), (unsigned)B), block(TPB);
