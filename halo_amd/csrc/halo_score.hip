@@ -310,12 +310,13 @@ template <typename T> struct VecLoad<T, 1> {
 // the same time (6.10 vs 6.13 ms per 16 float32 images), with the logit loads compiled out it takes
 // the time of the feature walk alone -- the fused entropy costs exactly its 76 bytes per pixel.
 //
-// At most 5 waves per SIMD (the attribute pads the register allocation to 88): the kernel needs 79 VGPRs and would run
-// 6, which streams no faster and leaves 32 registers per SIMD lane -- the selection kernels of the other streams
+// At most 4 waves per SIMD (the attribute pads the register allocation to 104): the kernel needs 79 VGPRs and would
+// run 6, which streams no faster and leaves 32 registers per SIMD lane -- the selection kernels of the other streams
 // (k_sel_sweep and k_sel_scatter allocate 40) then wait for several of this kernel's blocks to retire on one CU before
-// they can be placed: one image's selection beside the stream took 5.3 ms instead of 2.4.
+// they can be placed: one image's selection beside the stream took 5.3 ms at 6 waves, 2.4-2.6 at 5 (but 5.6 for four
+// images, every other run), 2.0-2.2 at 4 (2.6 for four images), with the same 11.4-11.5 ms per feature launch.
 template <typename T, int VEC, int MODE, int UNROLL, int FO>
-__global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, 5))) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
+__global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, 4))) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
                                                      long long hw, double ks, double rks, T *__restrict__ out,
                                                      double *__restrict__ partials, const float *__restrict__ logit,
                                                      long long lbstride, int unc_type, float *__restrict__ ent)
