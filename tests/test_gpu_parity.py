@@ -560,7 +560,9 @@ def test_views_and_batch_strides(dev):
                                   ((40, 80), (10, 20), (64, 128)),        # the real pipeline's ratios: x1.6 and x6.4
                                   ((23, 37), (9, 14), (50, 77)),          # odd everything
                                   ((64, 128), (64, 128), (64, 128)),      # identity resize
-                                  ((5, 7), (3, 4), (96, 130))])           # large magnification
+                                  ((5, 7), (3, 4), (96, 130)),            # large magnification
+                                  ((32, 48), (32, 48), (64, 96)),         # x2: four output rows span three source rows (generic loop)
+                                  ((21, 33), (21, 33), (64, 100))])       # x3: every row-sharing pattern, partial tiles
 @pytest.mark.parametrize("unc,pur", [("entropy", "radius"), ("entropy", "hyper"), ("entropy", "ripu"),
                                       ("oracle_acc", "euc_norm")])
 def test_lowres_sources_equal_upsample_then_score(dev, geom, unc, pur):
