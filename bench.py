@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--source", choices=["fullres", "lowres"], default="fullres",
                     help="fullres = SURVEY 8(d) unit of work (default, the BASELINE metric); lowres = the "
                          "RegionSelection boundary: x4 low-res head outputs, upsampling fused into the scorer (N1)")
+    ap.add_argument("--lr-mode", choices=["exact", "gram"], default="exact",
+                    help="--source lowres only: 'gram' evaluates the embedding's radius through per-cell Gram terms (SURVEY 8f N1; "
+                         "not bit-identical to upsample-then-score)")
     ap.add_argument("--cpu-images", type=int, default=8, help="timed images in the CPU-baseline sample, after one "
                                                               "untimed warm-up image (0 = skip)")
     ap.add_argument("--resets", choices=["score", "side"], default="score",
@@ -124,12 +127,13 @@ class Pipeline:
     """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
 
     def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False, branch="halo",
-                 resets="score", sel_priority=-1):
+                 resets="score", sel_priority=-1, lr_mode="exact"):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
         self.R = feat.shape[0]
         self.lowres = lowres
+        self.lr_mode = lr_mode
         self.unc, self.pur, self.norm, self.mrad, self.K = BRANCHES[branch]
         Hh, Ww = gt.shape[-2:]
         self.size = (Hh, Ww)
@@ -194,7 +198,8 @@ class Pipeline:
             # all three output maps of FloatingRegionScore.forward are written (floating_region.py:217)
             if self.lowres:
                 sc, self.imp, self.unc_map = score_maps_lowres(lb, fb, self.size, self.unc, self.pur, self.norm, gb, ksize=3,
-                                                               K=self.K, c=1.0, active=self.active[k][:b], want_maps=True)
+                                                               K=self.K, c=1.0, active=self.active[k][:b], want_maps=True,
+                                                               mode=self.lr_mode)
                 self.score[k][:b].copy_(sc)
             else:
                 _, self.imp, self.unc_map = score_maps(lb, fb, self.unc, self.pur, self.norm, gb, size=3, K=self.K, c=1.0,
@@ -349,7 +354,8 @@ def main():
     if lowres:
         a.cpu_images = 0
     feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch, a.resets, a.sel_priority)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch, a.resets, a.sel_priority,
+                    a.lr_mode)
 
     # per-rank schedule: full batches, plus a partial last one when --pool-images does not divide evenly
     if a.pool_images > 0:
@@ -414,6 +420,7 @@ def main():
         if lowres:      # not the BASELINE unit of work: a different (smaller) input boundary, reported for DESIGN.md
             out["config"]["workload"] = "RegionSelection boundary (N1): x4 low-res head outputs (%dx%d), upsample fused into the scorer, " \
                                         "then the same mask + select; NOT the BASELINE unit of work" % (Hh // 4, Ww // 4)
+            out["config"]["lowres_mode"] = a.lr_mode
         if lowres or not feat_ms:
             out["roofline"] = None
             if lowres:

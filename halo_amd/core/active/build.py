@@ -99,14 +99,16 @@ def acquire_batch(logit, decoder_out, ground_truth, active, selected, active_mas
 
 
 def acquire_batch_lowres(logit_lr, decoder_lr, size, ground_truth, active, selected, active_mask, *, unc_type, pur_type,
-                         normalize, n_regions, active_radius, mask_radius, ksize=None, purity_size=None, K=100, c=1.0):
+                         normalize, n_regions, active_radius, mask_radius, ksize=None, purity_size=None, K=100, c=1.0,
+                         lowres_mode=None):
     """build.py:122-160 for B images: resize of the head outputs fused into the scorer (the C x H x W
     embedding is never materialised), then mask + greedy selection.  Falls back to explicit HIP
     upsampling when the fused kernel declines the geometry (strong downsampling)."""
     ksize = 2 * active_radius + 1 if ksize is None else ksize
     try:
         score, _, _ = score_maps_lowres(logit_lr, decoder_lr, size, unc_type, pur_type, normalize, ground_truth,
-                                        ksize=ksize, purity_size=purity_size, K=K, c=c, active=active, want_maps=False)
+                                        ksize=ksize, purity_size=purity_size, K=K, c=c, active=active, want_maps=False,
+                                        mode=lowres_mode)
     except _lib.HaloUnsupported:
         logit = bilinear_align_corners(logit_lr.float(), size)
         dec = bilinear_align_corners(decoder_lr, size) if pur_type in ("hyper", "radius", "euc_norm") else decoder_lr
@@ -181,7 +183,7 @@ def _side_streams(dev, n):
     return have[:n]
 
 
-def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, slot):
+def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, slot, lowres_mode=None):
     """Enqueue one image of the pool (build.py:113-166) on `stream`: stage its masks, score -> mask -> select,
     copy the results back into pinned host buffers.  Fully asynchronous: `rec.done` fires when the host
     buffers hold the image's final mask / indicator maps."""
@@ -203,7 +205,7 @@ def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active
                              unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
                              n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
                              mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
-                             K=prm.K, c=prm.scorer.mapper.c)
+                             K=prm.K, c=prm.scorer.mapper.c, lowres_mode=lowres_mode)
         # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
         # reference's cast-after-copy, build.py:67-68,162)
         rec.h_mask, rec.h_active, rec.h_selected = slot.buffers(amask.shape)
@@ -275,7 +277,7 @@ def _finish_inner(rec, slots):
 
 
 def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=8, writer_threads=8,
-                    streams=4, return_tables=False):
+                    streams=4, return_tables=False, lowres_mode=None):
     """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
     at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
     every file on disk when the call returns.  Returns None like the reference, or -- keyword-only
@@ -288,7 +290,9 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     for the GPU: a pool of writer threads waits for each image's event, encodes the PNG and writes the
     indicator.  At most `in_flight` images are between "launched" and "copied back to the host" (bounds device
     and pinned memory; each slot owns its pinned staging buffers); `in_flight=0` runs strictly one image at a
-    time like the reference."""
+    time like the reference.  `lowres_mode`: 'exact' (default; environment HALO_LOWRES) scores bit-identically to the
+    reference's upsample-then-score, 'gram' evaluates the radius of a float64 embedding through per-cell Gram terms
+    (floating_region.score_maps_lowres) -- same files on every test vector, not bit-identical maps."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -319,7 +323,8 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
                     slot = slots.get()                               # blocks only while `in_flight` images hold every slot
                     try:
                         rec = _launch_one(prm, logits_lr[i:i + 1], embed_lr[i:i + 1], size, batch["origin_mask"][i],
-                                          batch["origin_label"][i], batch["active"][i], batch["selected"][i], dev, slot)
+                                          batch["origin_label"][i], batch["active"][i], batch["selected"][i], dev, slot,
+                                          lowres_mode)
                     except BaseException:
                         slots.put(slot)
                         backlog.release()

@@ -961,6 +961,120 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
     block_minmax<TPB>(mn, mx, partials + (size_t)tile_id * 2);
 }
 
+// ---- Gram form of the low-resolution radius ("precompute the 4-neighbour Gram terms per low-res cell,
+// then each output pixel costs O(10) not O(C)").  The interpolated embedding of an output pixel is sum_i w_i v_i over the
+// four corner vectors of its low-res cell, so  ||.||^2 = sum_{i<=j} (2 - [i==j]) w_i w_j <v_i, v_j>.  The 10 inner products
+// of a cell are 5 maps over the low-res grid read at the cell's corners (n(.) = neighbour clamped to the grid, exactly
+// the i1 of make_taps):
+//     S(y,x) = <v,v>   Hh(y,x) = <v(y,x), v(y,n(x))>   Vv(y,x) = <v(y,x), v(n(y),x)>
+//     D1(y,x) = <v(y,x), v(n(y),n(x))>   D2(y,x) = <v(y,n(x)), v(n(y),x)>
+// k_gram_lr computes the maps in one pass over the low-res tensor (sequential fma chains over the channels);
+// k_radius_gram evaluates the 10-term form per output pixel.  Mathematically the same number as k_feat_reduce_lr,
+// rounded differently (a few 1e-16 of the largest corner norm; a negative rounding residue is clamped to zero), so this
+// mode is NOT bit-identical to upsample-then-score: it is opt-in (halo_score_maps_lr_gram) and float64 only.
+constexpr int GRAM_MAPS = 5;
+constexpr int GRAM_COLS = 63;          // columns per wave: lane 63 only supplies the right neighbour of lane 62
+
+// value of the next lane (lane 63: unspecified): one full-wave DPP shift per 32-bit half
+__device__ __forceinline__ double next_lane(double v)
+{
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffll), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// A wave owns 63 columns x 2 rows of the low-res grid: per channel it loads its columns of three rows (the third is the
+// lower neighbour of the second) and takes the right neighbours from the next lane -- 3 loads for 126 pixels' 5 products
+// each, where a lane per pixel with four loads made the kernel L1-bound (2.9 TB/s of the tensor).  Blocks that share an
+// XCD take a contiguous eighth of the wave list, so the row shared by two row pairs is fetched by one L2.
+__global__ void __launch_bounds__(TPB) k_gram_lr(const double *__restrict__ feat, long long bstride, int C, int h, int w,
+                                                 double *__restrict__ gram)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const unsigned per = gridDim.x / 8;                       // the host pads the grid's x extent to a multiple of 8
+    const unsigned wid = ((blockIdx.x % 8) * per + blockIdx.x / 8) * (TPB / 64) + (threadIdx.x >> 6);
+    const unsigned nwx = (unsigned)((w + GRAM_COLS - 1) / GRAM_COLS);
+    const int y = 2 * (int)(wid / nwx);
+    if (y >= h) return;                                       // wave-uniform
+    const int xu = (int)(wid % nwx) * GRAM_COLS + lane, x = xu < w - 1 ? xu : w - 1;
+    const int y1 = y + 1 < h - 1 ? y + 1 : h - 1, y2 = y + 2 < h - 1 ? y + 2 : h - 1;
+    const unsigned a0 = (unsigned)(y * w + x), a1 = (unsigned)(y1 * w + x), a2 = (unsigned)(y2 * w + x);
+    const int hwl = h * w;
+    const double *p = feat + (size_t)b * bstride;             // plane base: scalar, advanced by scalar adds
+    double g0[GRAM_MAPS], g1[GRAM_MAPS];
+#pragma unroll
+    for (int k = 0; k < GRAM_MAPS; ++k) g0[k] = g1[k] = 0.0;
+    auto accumulate = [&](double v0, double v1, double v2) {
+        const double r0 = next_lane(v0), r1 = next_lane(v1), r2 = next_lane(v2);
+        g0[0] = __builtin_fma(v0, v0, g0[0]); g0[1] = __builtin_fma(v0, r0, g0[1]); g0[2] = __builtin_fma(v0, v1, g0[2]);
+        g0[3] = __builtin_fma(v0, r1, g0[3]); g0[4] = __builtin_fma(r0, v1, g0[4]);
+        g1[0] = __builtin_fma(v1, v1, g1[0]); g1[1] = __builtin_fma(v1, r1, g1[1]); g1[2] = __builtin_fma(v1, v2, g1[2]);
+        g1[3] = __builtin_fma(v1, r2, g1[3]); g1[4] = __builtin_fma(r1, v2, g1[4]);
+    };
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+        double v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u, p += hwl) { v[u][0] = p[a0]; v[u][1] = p[a1]; v[u][2] = p[a2]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accumulate(v[u][0], v[u][1], v[u][2]);
+    }
+    for (; c < C; ++c, p += hwl) accumulate(p[a0], p[a1], p[a2]);
+    if (lane < GRAM_COLS && xu < w) {
+        double *gb = gram + (size_t)b * GRAM_MAPS * hwl;
+#pragma unroll
+        for (int k = 0; k < GRAM_MAPS; ++k) gb[(size_t)k * hwl + a0] = g0[k];
+        if (y + 1 < h) {
+#pragma unroll
+            for (int k = 0; k < GRAM_MAPS; ++k) gb[(size_t)k * hwl + a1] = g1[k];
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ gram, int h, int w, int H, int W, double sh, double sw,
+                                                     double ks, double rks, double *__restrict__ out, double *__restrict__ partials)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)H * W;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool live = i < hw;
+    double mn = 0.0, mx = 0.0;
+    if (live) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        const Taps<double> ty = make_taps<double>(y, sh, h), tx = make_taps<double>(x, sw, w);
+        const double wt[4] = {ty.l0 * tx.l0, ty.l0 * tx.l1, ty.l1 * tx.l0, ty.l1 * tx.l1};      // the weights of lerp4
+        const size_t hwl = (size_t)h * w;
+        const double *S = gram + (size_t)b * GRAM_MAPS * hwl, *Hh = S + hwl, *Vv = Hh + hwl, *D1 = Vv + hwl, *D2 = D1 + hwl;
+        const size_t c00 = (size_t)ty.i0 * w + tx.i0, c01 = (size_t)ty.i0 * w + tx.i1, c10 = (size_t)ty.i1 * w + tx.i0,
+                     c11 = (size_t)ty.i1 * w + tx.i1;
+        // <v_a, v_b> for corners a <= b in the order (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+        const double G[10] = {S[c00], Hh[c00], Vv[c00], D1[c00], S[c01], D2[c00], Vv[c01], S[c10], Hh[c10], S[c11]};
+        double s = 0.0;
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c2 = a; c2 < 4; ++c2, ++k) {
+                double coef = wt[a] * wt[c2];
+                if (c2 != a) coef = coef + coef;
+                s = __builtin_fma(coef, G[k], s);
+            }
+        s = s < 0.0 ? 0.0 : s;                    // rounding residue of a vanishing sum; NaN stays NaN
+        double r;
+        if constexpr (MODE == 0) r = dist0_from_ssq(s, ks, rks);
+        else r = __builtin_sqrt(s);
+        out[(size_t)b * hw + i] = r;
+        mn = mx = r;
+    }
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }         // thread 0 of every block is live
+    __syncthreads();
+    if (!live) { mn = seed[0]; mx = seed[1]; }
+    block_minmax<TPB>(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
 // Logits: interpolate the O class planes at one output pixel, then the same entropy / prediction code.
 template <int O_T>
 __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__ logit, long long bstride, int h, int w, int H, int W,
@@ -1083,8 +1197,15 @@ extern "C" size_t halo_score_lr_workspace_bytes(int64_t B, int64_t O, int64_t H,
     return base + ((O == 19 || O == 16) ? 0 : (size_t)B * O * H * W * 4 + 512);
 }
 
-// low-res source geometry (halo_score_maps_lr); hl == 0 means "inputs are already full resolution"
-struct LrDims { int hl, wl, hf, wf; };
+extern "C" size_t halo_score_lr_gram_workspace_bytes(int64_t B, int64_t O, int64_t H, int64_t W, int64_t hf, int64_t wf)
+{
+    const size_t base = halo_score_lr_workspace_bytes(B, O, H, W);
+    if (base == 0 || hf <= 0 || wf <= 0) return 0;
+    return base + (size_t)B * 5 * hf * wf * 8 + 512;
+}
+
+// low-res source geometry (halo_score_maps_lr); gram: the embedding's radius through the Gram form (float64 only)
+struct LrDims { int hl, wl, hf, wf; bool gram; };
 
 template <typename T>
 static void lr_window(int out_size, int in_size, int tile, int &max_span)
@@ -1157,6 +1278,9 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     double *part_unc = ar.take<double>((size_t)B * nblk1 * 2);
     double *stats = ar.take<double>((size_t)B * 4);
     float *lr_logit_full = lr_generic_O ? ar.take<float>((size_t)B * O * hw) : nullptr;
+    const bool gram_mode = lr && lr->gram && need_feat;
+    if (gram_mode && feat_dtype != HALO_F64) return fail(HALO_E_UNSUPPORTED, "halo_score_maps_lr_gram: float64 embeddings only");
+    double *gram = gram_mode ? ar.take<double>((size_t)B * GRAM_MAPS * lr->hf * lr->wf) : nullptr;
     if (!ar.ok()) return fail(HALO_E_WORKSPACE, "halo_score_maps: workspace too small");
 
     const bool f64out = (pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM) && feat_dtype == HALO_F64;
@@ -1208,7 +1332,15 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     if (need_feat) {
         if (ev_feat_start) (void)hipEventRecord((hipEvent_t)ev_feat_start, st);
         const int mode = pur_type == HALO_PUR_EUC_NORM ? 1 : 0;
-        if (lr) {
+        if (gram_mode) {
+            const long long nwaves = cdiv(lr->wf, GRAM_COLS) * cdiv(lr->hf, 2);
+            hipLaunchKernelGGL(k_gram_lr, dim3((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B), block, 0, st, (const double *)feat,
+                               (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram);
+            const double shd = H > 1 ? (double)(lr->hf - 1) / (double)(H - 1) : 0.0, swd = W > 1 ? (double)(lr->wf - 1) / (double)(W - 1) : 0.0;
+            nblk_imp = nblk1;
+            if (mode == 0) hipLaunchKernelGGL(k_radius_gram<0>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
+            else hipLaunchKernelGGL(k_radius_gram<1>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
+        } else if (lr) {
             const int rc = feat_dtype == HALO_F64
                 ? launch_feat_lr<double>((const double *)feat, feat_bstride, (int)C, *lr, (int)H, (int)W, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st)
                 : launch_feat_lr<float>((const float *)feat, feat_bstride, (int)C, *lr, (int)H, (int)W, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st);
@@ -1350,7 +1482,24 @@ extern "C" int halo_score_maps_lr(const float *logit_lr, int64_t logit_bstride, 
     if (hl <= 0 || wl <= 0) return fail(HALO_E_ARG, "halo_score_maps_lr: bad low-res logit size");
     const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
     if (need_feat && (hf <= 0 || wf <= 0)) return fail(HALO_E_ARG, "halo_score_maps_lr: bad low-res embedding size");
-    LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf};
+    LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf, false};
+    return score_impl(logit_lr, logit_bstride, feat_lr, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
+                      normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream, nullptr,
+                      nullptr, &lr);
+}
+
+extern "C" int halo_score_maps_lr_gram(const float *logit_lr, int64_t logit_bstride, int64_t hl, int64_t wl, const void *feat_lr,
+                                       int feat_dtype, int64_t feat_bstride, int64_t hf, int64_t wf, const int64_t *gt,
+                                       const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
+                                       int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
+                                       void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (hl <= 0 || wl <= 0) return fail(HALO_E_ARG, "halo_score_maps_lr_gram: bad low-res logit size");
+    const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
+    if (need_feat && (hf <= 0 || wf <= 0)) return fail(HALO_E_ARG, "halo_score_maps_lr_gram: bad low-res embedding size");
+    if (need_feat && workspace_bytes < halo_score_lr_gram_workspace_bytes(B, O, H, W, hf, wf))
+        return fail(HALO_E_WORKSPACE, "halo_score_maps_lr_gram: workspace too small");
+    LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf, true};
     return score_impl(logit_lr, logit_bstride, feat_lr, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
                       normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream, nullptr,
                       nullptr, &lr);

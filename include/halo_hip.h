@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 2
+#define HALO_ABI_VERSION 3
 
 enum { HALO_F32 = 0, HALO_F64 = 1 };
 
@@ -132,6 +132,20 @@ int halo_score_maps_lr(const float *logit_lr, int64_t logit_bstride, int64_t hl,
                        const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
                        int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
                        void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream);
+
+/* halo_score_maps_lr with the embedding's radius / norm evaluated through the Gram form SURVEY 8f N1 describes:
+ * ||sum_i w_i v_i||^2 = sum_{i<=j} (2 - [i==j]) w_i w_j <v_i, v_j> over the four corner vectors of an output pixel's low-res
+ * cell -- the inner products are computed once (one pass over feat_lr; 5 maps over the low-res grid hold them), each
+ * output pixel then costs 10 terms instead of C.  Same mathematics, different rounding (|difference| of the sum of squares: a few 1e-16 of the
+ * largest corner norm^2), so this call is NOT bit-identical to upsample + halo_score_maps; float64 feat_lr only
+ * (HALO_E_UNSUPPORTED otherwise).  Everything else (logits, normalisation, -inf masking) as halo_score_maps_lr.
+ * workspace: halo_score_lr_gram_workspace_bytes(B, O, H, W, hf, wf). */
+size_t halo_score_lr_gram_workspace_bytes(int64_t B, int64_t O, int64_t H, int64_t W, int64_t hf, int64_t wf);
+int halo_score_maps_lr_gram(const float *logit_lr, int64_t logit_bstride, int64_t hl, int64_t wl, const void *feat_lr,
+                            int feat_dtype, int64_t feat_bstride, int64_t hf, int64_t wf, const int64_t *gt,
+                            const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
+                            int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
+                            void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Helper methods of FloatingRegionScore that are public by convention:
  *  - compute_region_uncertainty(unc_type, logit, p, ground_truth) / compute_pixel_entropy(p)

@@ -375,8 +375,12 @@ class _Fake(torch.nn.Module):
         return o
 
 
-def test_region_selection_driver_two_rounds(golden, dev):
-    """RegionSelection (build.py:71-186) through its PNG / torch.save persistence, two rounds."""
+@pytest.mark.parametrize("lowres", ["exact", "gram"])
+def test_region_selection_driver_two_rounds(golden, dev, monkeypatch, lowres):
+    """RegionSelection (build.py:71-186) through its PNG / torch.save persistence, two rounds -- the files the
+    REFERENCE wrote for the same inputs, with the fused low-res scorer in its exact mode and (HALO_LOWRES=gram) in the
+    Gram mode, whose radius map is rounded differently."""
+    monkeypatch.setenv("HALO_LOWRES", lowres)
     from PIL import Image
     from halo_amd.core.active.build import RegionSelection
     d = golden("region_selection")
@@ -587,6 +591,56 @@ def test_lowres_sources_equal_upsample_then_score(dev, geom, unc, pur):
                                           gt[0], size=3, purity_type=pur, K=50)
     so[act[0]] = -np.inf
     assert bits_equal(a[0][0].cpu().numpy(), so) and bits_equal(a[1][0].cpu().numpy(), io) and bits_equal(a[2][0].cpu().numpy(), uo)
+
+
+@pytest.mark.parametrize("geom", [((16, 32), (16, 32), (64, 128)), ((40, 80), (10, 20), (64, 128)), ((23, 37), (9, 14), (50, 77)),
+                                  ((64, 128), (64, 128), (64, 128)), ((5, 7), (3, 4), (96, 130)), ((32, 48), (32, 48), (64, 96))])
+@pytest.mark.parametrize("pur", ["radius", "euc_norm", "hyper"])
+def test_lowres_gram_mode_tracks_the_exact_mode(dev, geom, pur):
+    """mode='gram' (per-cell Gram terms, 10 products per output pixel instead of C) is the same number as
+    the exact fused path rounded differently: the radius / norm maps agree to 1e-12 (float64; tolerance stated here),
+    the uncertainty map -- untouched by the mode -- bit for bit, and the selection made from either score map is the same."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from oracle import halo_oracle as ho
+    (hl, wl), (hf, wf), (H, W) = geom
+    rng = np.random.default_rng(hl * 77 + hf)
+    B, C, O = 2, 24, 19
+    logit_lr = rng.standard_normal((B, O, hl, wl)).astype(np.float32)
+    emb_lr = ho.expmap((rng.standard_normal((B, C, hf, wf)) * 0.3).astype(np.float32), 1.0, dim=1)
+    lg, em = t(logit_lr, dev), t(emb_lr, dev)
+    a = score_maps_lowres(lg, em, (H, W), "entropy", pur, False, None, ksize=3, K=50, mode="exact")
+    g = score_maps_lowres(lg, em, (H, W), "entropy", pur, False, None, ksize=3, K=50, mode="gram")
+    assert bits_equal(a[2].cpu().numpy(), g[2].cpu().numpy())                     # uncertainty: same kernels
+    if pur == "hyper":      # quantiser bins of the radius: a bin can only move where the radius sits on a bin edge to 1e-12
+        assert (a[1] != g[1]).float().mean().item() < 1e-3
+        return
+    ia, ig = a[1].cpu().numpy(), g[1].cpu().numpy()
+    assert ia.dtype == np.float64 and np.max(np.abs(ia - ig)) <= 1e-12 * max(1.0, np.max(np.abs(ia)))
+    n = 40
+    for sc in (a[0], g[0]):
+        assert sc.dtype == torch.float64
+    res = []
+    for sc in (a[0].clone(), g[0].clone()):
+        act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+        gt = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
+        picks, npk = greedy_select(sc, n, 1, 3, act, sel, am, gt)
+        res.append((picks[:, :, :2].cpu().numpy().copy(), npk.cpu().numpy().copy(), act.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_lowres_gram_mode_declines_float32_embeddings_quietly_and_validates_its_name(dev):
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    rng = np.random.default_rng(12)
+    lg = t(rng.standard_normal((1, 19, 20, 30)).astype(np.float32), dev)
+    em = t((rng.standard_normal((1, 10, 12, 18)) * 0.2).astype(np.float32), dev)
+    a = score_maps_lowres(lg, em, (60, 92), "entropy", "radius", True, None, ksize=3, mode="exact")
+    g = score_maps_lowres(lg, em, (60, 92), "entropy", "radius", True, None, ksize=3, mode="gram")     # float32: exact path
+    for x, y in zip(a, g):
+        assert bits_equal(x.cpu().numpy(), y.cpu().numpy())
+    with pytest.raises(ValueError):
+        score_maps_lowres(lg, em, (60, 92), "entropy", "radius", True, None, ksize=3, mode="fast")
 
 
 def test_lowres_sources_f32_embedding_and_other_class_counts(dev):

@@ -63,7 +63,7 @@ def main():
     os.makedirs(DST, exist_ok=True)
     d = copy_json("bench_default.json", "r02_bench_default.json")
     copy_json("bench_under_rocprof.json", "r02_bench_under_rocprof.json")
-    for v in ("f32", "lowres", "c512", "ripu", "hyper", "pool2975"):
+    for v in ("f32", "lowres", "lowres_gram", "c512", "ripu", "hyper", "pool2975"):
         copy_json("bench_%s.json" % v, "r02_bench_%s.json" % v)
     stats_csv("trace/*/*_kernel_stats.csv", "r02_kernel_stats.csv")
     stats_csv("trace_ripu/*/*_kernel_stats.csv", "r02_kernel_stats_ripu.csv", 25)
@@ -72,13 +72,14 @@ def main():
     stats_csv("trace_feat_alone/*/*_kernel_stats.csv", "r02_kernel_stats_feat_alone.csv", 12)
     stats_csv("trace_lowres/*/*_kernel_stats.csv", "r02_kernel_stats_lowres.csv", 25)
     stats_csv("trace_f32/*/*_kernel_stats.csv", "r02_kernel_stats_f32.csv", 25)
+    stats_csv("trace_lowres_gram/*/*_kernel_stats.csv", "r02_kernel_stats_lowres_gram.csv", 25)
     lr = counters("pmc_lowres/*/*counter_collection.csv")
     if lr:
         json.dump({"round": 2, "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_lowres.py",
                    "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs",
                    "per_kernel_avg_per_launch": {short(k): {n: sum(v) / len(v) for n, v in c.items()} for k, c in lr.items() if "_lr" in k}},
                   open(os.path.join(DST, "r02_pmc_lowres.json"), "w"), indent=1)
-    for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt"):
+    for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]

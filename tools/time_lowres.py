@@ -19,9 +19,11 @@ for (hl, wl, hf, wf, tag) in ((256, 512, 256, 512, "x4 synthetic"), (640, 1280, 
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
-    fused = t(lambda: score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, want_maps=False))
+    fused = t(lambda: score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, want_maps=False, mode="exact"))
+    gram = t(lambda: score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, want_maps=False, mode="gram"))
     def explicit():
         a = bilinear_align_corners(lg, (H, W)); b = bilinear_align_corners(em, (H, W))
         return score_maps(a, b, "entropy", "radius", True, None, want_maps=False)
     expl = t(explicit)
-    print(f"{tag}: fused {fused / B:.3f} ms/image, upsample+score {expl / B:.3f} ms/image, ratio {expl / fused:.1f}x")
+    print(f"{tag}: fused {fused / B:.3f} ms/image (Gram mode {gram / B:.3f}), upsample+score {expl / B:.3f} ms/image, "
+          f"ratio {expl / fused:.1f}x ({expl / gram:.1f}x)")
