@@ -630,6 +630,20 @@ def test_lowres_gram_mode_tracks_the_exact_mode(dev, geom, pur):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
+def test_lowres_gram_mode_on_degenerate_grids(dev):
+    """single-row / single-column / single-pixel embeddings, odd sizes around the 63-column wave width"""
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    rng = np.random.default_rng(13)
+    for (hf, wf), (H, W) in (((1, 1), (9, 11)), ((1, 5), (8, 40)), ((7, 1), (30, 6)), ((3, 63), (12, 250)), ((2, 64), (9, 257)),
+                             ((5, 127), (20, 509)), ((1, 200), (3, 801))):
+        lg = t(rng.standard_normal((1, 19, 4, 6)).astype(np.float32), dev)
+        em = t(rng.standard_normal((1, 9, hf, wf)) * 0.2, dev)
+        a = score_maps_lowres(lg, em, (H, W), "entropy", "radius", False, None, ksize=3, mode="exact")
+        g = score_maps_lowres(lg, em, (H, W), "entropy", "radius", False, None, ksize=3, mode="gram")
+        ia, ig = a[1].cpu().numpy(), g[1].cpu().numpy()
+        assert np.all(np.isfinite(ig)) and np.max(np.abs(ia - ig)) <= 1e-12 * max(1.0, np.max(np.abs(ia))), ((hf, wf), (H, W))
+
+
 def test_lowres_gram_mode_declines_float32_embeddings_quietly_and_validates_its_name(dev):
     from halo_amd.core.active.floating_region import score_maps_lowres
     rng = np.random.default_rng(12)
