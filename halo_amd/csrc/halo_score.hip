@@ -503,9 +503,11 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const TL *__restrict__ 
 // the same order as the generic kernel above, with no global re-scan per class.
 constexpr int RI_TW = 64, RI_TH = 16;
 
+// partials (optional): per-block min / max of the impurity written, for normalize_map -- saves a pass over the map
 template <typename TL>
 __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__ pred, int H, int W, float logK,
-                                                          float *__restrict__ imp, float *__restrict__ count)
+                                                          float *__restrict__ imp, float *__restrict__ count,
+                                                          double *__restrict__ partials)
 {
     __shared__ int lab[RI_TH + 2][RI_TW + 2 + 2];                  // +2: row stride 68 words
     const int b = blockIdx.z, tid = threadIdx.x;
@@ -520,7 +522,8 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
     __syncthreads();
     const int ly = tid >> 4, lx = (tid & 15) * 4;                  // 16 lanes x 4 pixels per tile row
     const int y = Y0 + ly, xb = X0 + lx;
-    if (y >= H || xb >= W) return;
+    const bool live = y < H && xb < W;
+    double mn = 0.0, mx = 0.0;
     int v[3][6];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int x = xb + j;
-        if (x >= W) break;
+        if (!live || x >= W) break;
         const float cnt = (float)(ny * ((x > 0 ? 1 : 0) + 1 + (x < W - 1 ? 1 : 0)));
         float a = 0.0f;
         int cur = -1;
@@ -550,22 +553,33 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
             a = a + (-d) * det_logf(d + 1e-6f);
             cur = nxt;
         }
-        imp[(size_t)b * hw + (size_t)y * W + x] = a / logK;
+        const float res = a / logK;
+        imp[(size_t)b * hw + (size_t)y * W + x] = res;
         if (count) count[(size_t)b * hw + (size_t)y * W + x] = cnt;
+        if (j == 0) mn = mx = (double)res;
+        else { mn = nan_min(mn, (double)res); mx = nan_max(mx, (double)res); }
     }
+    if (!partials) return;                                          // kernel argument: uniform
+    __shared__ double seed[2];
+    if (tid == 0) { seed[0] = mn; seed[1] = mx; }                   // thread 0 (pixel X0, Y0) is always live
+    __syncthreads();
+    if (!live) { mn = seed[0]; mx = seed[1]; }
+    block_minmax<TPB>(mn, mx, partials + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2);
 }
 
+// Returns the number of min/max partials per image written to `partials` (0: none -- the caller runs k_minmax_f32).
 template <typename TL>
-static void launch_region_impurity(const TL *pred, int64_t B, int64_t H, int64_t W, int k, float logK, float *imp, float *count,
-                                   hipStream_t st)
+static int launch_region_impurity(const TL *pred, int64_t B, int64_t H, int64_t W, int k, float logK, float *imp, float *count,
+                                  hipStream_t st, double *partials = nullptr)
 {
     if (k == 3 && cdiv(H, RI_TH) <= 65535 && B <= 65535 && !getenv("HALO_IMPURITY_GENERIC")) {     // A/B switch
-        hipLaunchKernelGGL((k_region_impurity3<TL>), dim3((unsigned)cdiv(W, RI_TW), (unsigned)cdiv(H, RI_TH), (unsigned)B), dim3(TPB), 0, st,
-                           pred, (int)H, (int)W, logK, imp, count);
-    } else {
-        hipLaunchKernelGGL((k_region_impurity<TL>), dim3((unsigned)cdiv(H * W, TPB), (unsigned)B), dim3(TPB), 0, st, pred, (int)H, (int)W, k,
-                           logK, imp, count);
+        const dim3 grid((unsigned)cdiv(W, RI_TW), (unsigned)cdiv(H, RI_TH), (unsigned)B);
+        hipLaunchKernelGGL((k_region_impurity3<TL>), grid, dim3(TPB), 0, st, pred, (int)H, (int)W, logK, imp, count, partials);
+        return partials ? (int)(grid.x * grid.y) : 0;
     }
+    hipLaunchKernelGGL((k_region_impurity<TL>), dim3((unsigned)cdiv(H * W, TPB), (unsigned)B), dim3(TPB), 0, st, pred, (int)H, (int)W, k,
+                       logK, imp, count);
+    return 0;
 }
 
 // ---------------------------------------------------------------- entropy_conv + /count (floating_region.py:42-51,90,204)
@@ -1156,6 +1170,7 @@ static void launch_feat(const T *feat, long long bstride, int C, long long hw, i
 
 using namespace halo;
 
+static_assert(RI_TW == LR_TW && RI_TH == LR_TH, "k_region_impurity3 writes one min/max partial per tile of the same shape");
 static size_t partial_slots(int64_t H, int64_t W)
 {
     const size_t a = (size_t)cdiv(H * W, FTPB), b = (size_t)(cdiv(W, LR_TW) * cdiv(H, LR_TH));
@@ -1362,14 +1377,17 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
         if (feat_dtype == HALO_F64) hipLaunchKernelGGL((k_quantize<double, short>), grid1, block, 0, st, (const double *)imp_raw, stats, hw, (int)K, pred);
         else hipLaunchKernelGGL((k_quantize<float, short>), grid1, block, 0, st, (const float *)imp_raw, stats, hw, (int)K, pred);
     }
+    // the impurity's min / max are only needed by normalize_map: per-block partials straight from the 3x3 histogram kernel,
+    // a separate pass for the other sources of the map, nothing at all when the branch does not normalise (ripu.yaml)
     if (hist) {
         const float logK = (float)log((double)(pur_type == HALO_PUR_HYPER ? K : O));
-        launch_region_impurity<short>((const short *)pred, B, H, W, pksize, logK, (float *)imp_raw, (float *)nullptr, st);
-        hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
-        nblk_imp = nblk1;
+        const int np = launch_region_impurity<short>((const short *)pred, B, H, W, pksize, logK, (float *)imp_raw, (float *)nullptr, st,
+                                                     normalize ? part_imp : nullptr);
+        nblk_imp = np ? np : nblk1;
+        if (normalize && !np) hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
     } else if (pur_type == HALO_PUR_NONE) {
         hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(B * hw, TPB)), block, 0, st, (float *)imp_raw, (long long)(B * hw), 0.0f);
-        hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
+        if (normalize) hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
         nblk_imp = nblk1;
     }
 
@@ -1379,14 +1397,17 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     if (do_box && ksize == 3 && W % 4 == 0 && aligned16(ent) && aligned16(unc_raw)) {
         nblk_unc = (int)cdiv(hw, TPB * 4);
         hipLaunchKernelGGL(k_box3_unc, dim3((unsigned)nblk_unc, (unsigned)B), block, 0, st, (const float *)ent, (int)H, (int)W,
-                           hist ? pksize : 0, unc_raw, part_unc);
+                           hist ? pksize : 0, unc_raw, normalize ? part_unc : nullptr);
     } else {
-        hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, ent, (int)H, (int)W, ksize, do_box, hist ? pksize : 0, unc_raw, part_unc);
+        hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, ent, (int)H, (int)W, ksize, do_box, hist ? pksize : 0, unc_raw,
+                           normalize ? part_unc : nullptr);
     }
 
-    // ---- global min/max, then normalise + product
-    hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_imp, nblk_imp, stats, 0);
-    hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_unc, nblk_unc, stats, 1);
+    // ---- global min/max (normalize_map only), then normalise + product
+    if (normalize) {
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_imp, nblk_imp, stats, 0);
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_unc, nblk_unc, stats, 1);
+    }
     if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
     return check_launch("halo_score_maps");
