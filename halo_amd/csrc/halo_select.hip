@@ -70,15 +70,9 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
                                                            unsigned char *__restrict__ selected,
                                                            long long *__restrict__ active_mask,
                                                            const long long *__restrict__ gt, double *__restrict__ picks,
-                                                           int *__restrict__ n_picked, const SelHdr *__restrict__ resume)
+                                                           int *__restrict__ n_picked, const SelHdr *__restrict__ resume,
+                                                           int n_images)
 {
-    // Behind the binned selector (halo_select_binned.hip): images it finished are skipped, images it handed
-    // over continue from pick `np` on the map as the reference would have it after those picks.
-    int np0 = 0;
-    if (resume) {
-        if (resume[blockIdx.x].status == SEL_DONE) return;
-        np0 = resume[blockIdx.x].np;
-    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *tkey = reinterpret_cast<unsigned long long *>(smem);
     unsigned *tpos = reinterpret_cast<unsigned *>(smem + (size_t)g.nt * 8);
@@ -89,8 +83,19 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
     // Latency-bound serial loop sharing CUs with bandwidth-bound streaming kernels: take issue
     // priority over them (they only wait on memory anyway).
     __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t hw = (size_t)g.H * g.W;
+    // A workgroup serves images blockIdx.x, blockIdx.x + gridDim.x, ...: one image each when this kernel is the selector;
+    // behind the binned selector (halo_select_binned.hip) the launch has only a couple of workgroups, which skip the
+    // images the sweep finished (normally all of them) and continue the ones it handed over from pick `np`, on the map
+    // as the reference would have it after those picks.  (A 512-thread workgroup with a 48+ KiB table is placed
+    // beside a saturating streaming kernel only when a CU drains: 16 of them took 6-7 ms to place and exit.)
+    for (int b = blockIdx.x; b < n_images; b += gridDim.x) {
+    int np0 = 0;
+    if (resume) {
+        if (resume[b].status == SEL_DONE) continue;
+        np0 = resume[b].np;
+    }
     T *sc = score + (size_t)b * hw;
     unsigned char *act = active + (size_t)b * hw;
     unsigned char *sel = selected + (size_t)b * hw;
@@ -209,6 +214,8 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
         py0 = my0; py1 = my1; px0 = mx0; px1 = mx1;
     }
     if (tid == 0 && n_picked) n_picked[b] = np;
+    __syncthreads();                                                     // the tables are rebuilt for the next image
+    }
 }
 
 }  // namespace halo
@@ -253,13 +260,13 @@ extern "C" size_t halo_select_workspace_bytes(int64_t B, int64_t H, int64_t W, i
 template <typename T, int A, int B_, int EPT>
 static int launch_serial(const SelGeom &g, size_t lds, dim3 grid, hipStream_t st, void *score, int n_regions, int arad, int mrad,
                          uint8_t *active, uint8_t *selected, int64_t *active_mask, const int64_t *gt, double *picks,
-                         int32_t *n_picked, const SelHdr *resume)
+                         int32_t *n_picked, const SelHdr *resume, int n_images)
 {
     static LdsLimitSeen seen;           // per instantiation: tile tables above 64 KiB need the dynamic-LDS limit raised
     if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_greedy_select<T, A, B_, EPT>, 128 * 1024))
         return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL((k_greedy_select<T, A, B_, EPT>), grid, dim3(SEL_TPB), lds, st, (T *)score, g, n_regions, arad, mrad, active,
-                       selected, (long long *)active_mask, (const long long *)gt, picks, n_picked, resume);
+                       selected, (long long *)active_mask, (const long long *)gt, picks, n_picked, resume, n_images);
     return HALO_OK;
 }
 
@@ -300,14 +307,21 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
 
     // ---- serial tile-table kernel: the whole job, or only the images the sweep handed over
     const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * SEL_WAVES * 12 + 64;
-    dim3 grid((unsigned)B);
+    // behind the sweep: two workgroups walk the images (see the kernel); HALO_SEL_RESUME_WGS overrides (tuning aid)
+    unsigned nwg = (unsigned)B;
+    if (resume) {
+        static const int wgs_env = [] { const char *e = getenv("HALO_SEL_RESUME_WGS"); return e ? atoi(e) : 0; }();
+        const unsigned want = wgs_env > 0 ? (unsigned)wgs_env : 2u;
+        nwg = want < (unsigned)B ? want : (unsigned)B;
+    }
+    dim3 grid(nwg);
     int rc = HALO_OK;
 #define HALO_SEL_LAUNCH(T, A, B_)                                                                                                \
     rc = g.nt <= 8 * SEL_TPB                                                                                                     \
              ? launch_serial<T, A, B_, 8>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius, active,    \
-                                          selected, active_mask, gt, picks, n_picked, resume)                                   \
+                                          selected, active_mask, gt, picks, n_picked, resume, (int)B)                          \
              : launch_serial<T, A, B_, 16>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius, active,   \
-                                           selected, active_mask, gt, picks, n_picked, resume);
+                                           selected, active_mask, gt, picks, n_picked, resume, (int)B);
     if (dtype == HALO_F64) {
         if (g.th_shift == 4) { HALO_SEL_LAUNCH(double, 4, 5) }
         else if (g.th_shift == 5) { HALO_SEL_LAUNCH(double, 5, 6) }
