@@ -1120,6 +1120,37 @@ def test_binned_sweep_hand_over_cases_at_scale(dev):
     _select_vs_oracle(dev, sm, n, 1, 5, methods=("auto",), prior=prior, tag="second round")
 
 
+def test_batched_hand_over_more_images_than_resume_workgroups(dev):
+    """Behind the sweep the serial kernel runs with two workgroups that walk the images: a batch of seven maps, five of
+    which hand over (plateaus, NaN, +inf, constant, plateaus again) in between two the sweep finishes, must come out
+    image by image as the oracle's."""
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(45)
+    H, W, n, mrad = 256, 384, 300, 5
+    smooth = ho.bilinear(rng.standard_normal((1, H // 4, W // 4)), (H, W))[0]
+    maps = [smooth.copy(), np.round(smooth * 4) / 4, smooth.copy(), smooth.copy(), np.full((H, W), 0.25), np.round(smooth * 3) / 3,
+            ho.bilinear(rng.standard_normal((1, H // 4, W // 4)), (H, W))[0]]
+    maps[2][10, 20] = np.nan
+    maps[3][200, 300] = np.inf
+    B = len(maps)
+    s0 = np.ascontiguousarray(np.stack(maps))
+    gt = rng.integers(0, 19, (B, H, W)).astype(np.int64)
+    s = t(s0, dev).clone()
+    act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+    am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+    picks, npk = greedy_select(s, n, 1, mrad, act, sel, am, t(gt, dev), method="auto")
+    for b in range(B):
+        so = s0[b].copy()
+        act_o = np.zeros((H, W), bool); sel_o = np.zeros((H, W), bool); am_o = np.full((H, W), 255, np.int64)
+        _, _, _, _, po = ho.select_pixels_to_label(so, n, 1, mrad, act_o, sel_o, am_o, gt[b], True)
+        k = int(npk[b])
+        assert k == len(po) and bits_equal(picks[b, :k].cpu().numpy(), po), b
+        assert bits_equal(s[b].cpu().numpy(), so), b
+        assert np.array_equal(act[b].cpu().numpy(), act_o) and np.array_equal(sel[b].cpu().numpy(), sel_o), b
+        assert np.array_equal(am[b].cpu().numpy(), am_o), b
+
+
 def test_select_1536x2048_uses_a_tile_table_above_64KiB(dev):
     """VERDICT r1 weak #4: 1536x2048 needs ~74 KiB of dynamic LDS in the serial kernel (48 KiB at 1024x2048)."""
     rng = np.random.default_rng(47)
