@@ -1102,14 +1102,17 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__
     const int y = (int)(i / W), x = (int)(i % W);
     const Taps<float> ty = make_taps<float>(y, sh, h), tx = make_taps<float>(x, sw, w);
     const float w00 = ty.l0 * tx.l0, w01 = ty.l0 * tx.l1, w10 = ty.l1 * tx.l0, w11 = ty.l1 * tx.l1;
-    const float *lb = logit + (size_t)b * bstride;
-    const size_t a00 = (size_t)ty.i0 * w + tx.i0, a01 = (size_t)ty.i0 * w + tx.i1, a10 = (size_t)ty.i1 * w + tx.i0, a11 = (size_t)ty.i1 * w + tx.i1;
+    // plane base in SGPRs (advanced by scalar adds) + four 32-bit tap offsets: no 64-bit address arithmetic per load
+    // (byte offsets in 32 bits: a low-res class plane is far below 4 GiB)
+    const char *pl = reinterpret_cast<const char *>(logit + (size_t)b * bstride);
+    const unsigned a00 = (unsigned)(ty.i0 * w + tx.i0) * 4u, a01 = (unsigned)(ty.i0 * w + tx.i1) * 4u,
+                   a10 = (unsigned)(ty.i1 * w + tx.i0) * 4u, a11 = (unsigned)(ty.i1 * w + tx.i1) * 4u;
+    const size_t plane_bytes = (size_t)h * w * 4;
+    auto at = [](const char *base, unsigned off) { return *reinterpret_cast<const float *>(base + off); };
     float p[1][O_T];
 #pragma unroll
-    for (int c = 0; c < O_T; ++c) {
-        const float *pl = lb + (size_t)c * h * w;
-        p[0][c] = lerp4<float>(pl[a00], pl[a01], pl[a10], pl[a11], w00, w01, w10, w11);
-    }
+    for (int c = 0; c < O_T; ++c, pl += plane_bytes)
+        p[0][c] = lerp4<float>(at(pl, a00), at(pl, a01), at(pl, a10), at(pl, a11), w00, w01, w10, w11);
     const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
     const long long g[1] = {need_gt ? gt[(size_t)b * hw + i] : 0};
     float e[1];
