@@ -18,8 +18,8 @@
 
 namespace halo {
 
-constexpr int SEL_TPB = 512;
-constexpr int SEL_WAVES = SEL_TPB / 64;
+constexpr int SEL_TPB_MAIN = 512;        // the selector proper: one workgroup per image
+constexpr int SEL_TPB_RESUME = 256;      // behind the binned sweep: see k_greedy_resume
 
 struct SelGeom { int H, W, th_shift, tw_shift, nty, ntx, nt; };
 
@@ -64,15 +64,15 @@ __device__ __forceinline__ Cand tile_reduce(const T *__restrict__ sc, const SelG
     return wave_best(best);
 }
 
-template <typename T, int TSH, int TSW, int EPT>
-__global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score, SelGeom g, int n_regions, int arad,
-                                                           int mrad, unsigned char *__restrict__ active,
-                                                           unsigned char *__restrict__ selected,
-                                                           long long *__restrict__ active_mask,
-                                                           const long long *__restrict__ gt, double *__restrict__ picks,
-                                                           int *__restrict__ n_picked, const SelHdr *__restrict__ resume,
-                                                           int n_images)
+// The selector's body for a workgroup of TPB threads (WAVES - 1 reducer waves + 1 writer wave).
+template <typename T, int TSH, int TSW, int EPT, int SEL_TPB>
+__device__ __forceinline__ void greedy_select_body(T *__restrict__ score, const SelGeom &g, int n_regions, int arad, int mrad,
+                                                   unsigned char *__restrict__ active, unsigned char *__restrict__ selected,
+                                                   long long *__restrict__ active_mask, const long long *__restrict__ gt,
+                                                   double *__restrict__ picks, int *__restrict__ n_picked,
+                                                   const SelHdr *__restrict__ resume, int n_images)
 {
+    constexpr int SEL_WAVES = SEL_TPB / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *tkey = reinterpret_cast<unsigned long long *>(smem);
     unsigned *tpos = reinterpret_cast<unsigned *>(smem + (size_t)g.nt * 8);
@@ -218,6 +218,31 @@ __global__ void __launch_bounds__(SEL_TPB) k_greedy_select(T *__restrict__ score
     }
 }
 
+template <typename T, int TSH, int TSW, int EPT>
+__global__ void __launch_bounds__(SEL_TPB_MAIN) k_greedy_select(T *__restrict__ score, SelGeom g, int n_regions, int arad, int mrad,
+                                                                unsigned char *__restrict__ active, unsigned char *__restrict__ selected,
+                                                                long long *__restrict__ active_mask, const long long *__restrict__ gt,
+                                                                double *__restrict__ picks, int *__restrict__ n_picked,
+                                                                const SelHdr *__restrict__ resume, int n_images)
+{
+    greedy_select_body<T, TSH, TSW, EPT, SEL_TPB_MAIN>(score, g, n_regions, arad, mrad, active, selected, active_mask, gt, picks, n_picked,
+                                                        resume, n_images);
+}
+
+// The same selector as the stage behind the binned sweep, where it normally finds every image finished: 256 threads --
+// one wave per SIMD -- held to 96 VGPRs (amdgpu_waves_per_eu: the compiler spills what does not fit; this path is rare
+// and slow anyway), which is what k_feat_reduce's cap leaves free on every SIMD, so the workgroup is placed at once
+// instead of waiting milliseconds for a CU to drain.
+template <typename T, int TSH, int TSW, int EPT>
+__global__ void __launch_bounds__(SEL_TPB_RESUME) __attribute__((amdgpu_waves_per_eu(5)))
+k_greedy_resume(T *__restrict__ score, SelGeom g, int n_regions, int arad, int mrad, unsigned char *__restrict__ active,
+                unsigned char *__restrict__ selected, long long *__restrict__ active_mask, const long long *__restrict__ gt,
+                double *__restrict__ picks, int *__restrict__ n_picked, const SelHdr *__restrict__ resume, int n_images)
+{
+    greedy_select_body<T, TSH, TSW, EPT, SEL_TPB_RESUME>(score, g, n_regions, arad, mrad, active, selected, active_mask, gt, picks,
+                                                          n_picked, resume, n_images);
+}
+
 }  // namespace halo
 
 using namespace halo;
@@ -265,7 +290,20 @@ static int launch_serial(const SelGeom &g, size_t lds, dim3 grid, hipStream_t st
     static LdsLimitSeen seen;           // per instantiation: tile tables above 64 KiB need the dynamic-LDS limit raised
     if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_greedy_select<T, A, B_, EPT>, 128 * 1024))
         return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL((k_greedy_select<T, A, B_, EPT>), grid, dim3(SEL_TPB), lds, st, (T *)score, g, n_regions, arad, mrad, active,
+    hipLaunchKernelGGL((k_greedy_select<T, A, B_, EPT>), grid, dim3(SEL_TPB_MAIN), lds, st, (T *)score, g, n_regions, arad, mrad, active,
+                       selected, (long long *)active_mask, (const long long *)gt, picks, n_picked, resume, n_images);
+    return HALO_OK;
+}
+
+template <typename T, int A, int B_, int EPT>
+static int launch_resume(const SelGeom &g, size_t lds, dim3 grid, hipStream_t st, void *score, int n_regions, int arad, int mrad,
+                         uint8_t *active, uint8_t *selected, int64_t *active_mask, const int64_t *gt, double *picks,
+                         int32_t *n_picked, const SelHdr *resume, int n_images)
+{
+    static LdsLimitSeen seen;
+    if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_greedy_resume<T, A, B_, EPT>, 128 * 1024))
+        return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL((k_greedy_resume<T, A, B_, EPT>), grid, dim3(SEL_TPB_RESUME), lds, st, (T *)score, g, n_regions, arad, mrad, active,
                        selected, (long long *)active_mask, (const long long *)gt, picks, n_picked, resume, n_images);
     return HALO_OK;
 }
@@ -306,7 +344,7 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
     }
 
     // ---- serial tile-table kernel: the whole job, or only the images the sweep handed over
-    const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * SEL_WAVES * 12 + 64;
+    const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * (SEL_TPB_MAIN / 64) * 12 + 64;
     // behind the sweep: two workgroups walk the images (see the kernel); HALO_SEL_RESUME_WGS overrides (tuning aid)
     unsigned nwg = (unsigned)B;
     if (resume) {
@@ -317,7 +355,14 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
     dim3 grid(nwg);
     int rc = HALO_OK;
 #define HALO_SEL_LAUNCH(T, A, B_)                                                                                                \
-    rc = g.nt <= 8 * SEL_TPB                                                                                                     \
+    if (resume && A < 6) /* 64 x 128 tiles (maps above 4096^2) need 256 VGPRs: they resume on the main kernel */                 \
+        rc = g.nt <= 16 * SEL_TPB_RESUME                                                                                         \
+                 ? launch_resume<T, A, B_, 16>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius,    \
+                                               active, selected, active_mask, gt, picks, n_picked, resume, (int)B)               \
+                 : launch_resume<T, A, B_, 32>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius,    \
+                                               active, selected, active_mask, gt, picks, n_picked, resume, (int)B);              \
+    else                                                                                                                         \
+    rc = g.nt <= 8 * SEL_TPB_MAIN                                                                                                \
              ? launch_serial<T, A, B_, 8>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius, active,    \
                                           selected, active_mask, gt, picks, n_picked, resume, (int)B)                          \
              : launch_serial<T, A, B_, 16>(g, lds, grid, st, score, (int)n_regions, (int)active_radius, (int)mask_radius, active,   \
