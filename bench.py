@@ -14,8 +14,10 @@ Scoring of batch s+1 (HBM-bound) overlaps the selection of batch s on the slot's
 Workload at N=1: BASELINE.json configs[1] -- a pool of `steps*B` image evaluations (default 32 x 16 =
 512) drawn from a ring of R = 32 distinct resident images, so consecutive steps read different
 images (a 500-image pool does not fit in HBM at 4.3 GB/image); `--pool-images 2975` = configs[2].
-N>1: the pool is sharded image-wise, every rank runs the same per-rank workload (weak scaling)
-and the per-image pick tables are exchanged with ONE RCCL all-gather per step.
+N>1: the pool is sharded image-wise (contiguous blocks, halo_amd.pool.shard_range), every rank runs the same per-rank
+workload (weak scaling; `--pool-images N` gives every rank its own block of the N images) and the per-image pick tables
+are exchanged with ONE RCCL all-gather per ROUND: each step packs its tables into the rank's wire block, the
+collective runs once behind the last step on its own normal-priority stream, inside the timed region.
 `--branch ripu|hyper`, `--feat-dtype f32`, `--channels 512`, `--source lowres` are variants for
 DESIGN.md / profiles/, not the BASELINE unit.
 
@@ -73,17 +75,23 @@ def parse():
                          "not bit-identical to upsample-then-score)")
     ap.add_argument("--cpu-images", type=int, default=8, help="timed images in the CPU-baseline sample, after one "
                                                               "untimed warm-up image (0 = skip)")
-    ap.add_argument("--resets", choices=["score", "side"], default="score",
-                    help="where the per-batch round-1 state resets run: on the scoring stream (default) or on a low-priority "
-                         "housekeeping stream right after the slot's selection (tuning aid)")
+    ap.add_argument("--resets", choices=["undo", "kernel", "fills", "side"], default="undo",
+                    help="how a slot's round-1 state (active = selected = False, active_mask = 255: what the loader hands over in "
+                         "the reference, cityscapes.py:245-251 -- harness work, not part of the unit) is restored before the slot is "
+                         "scored again: undo = halo_undo_picks behind the slot's selection rewrites exactly the windows that "
+                         "selection wrote (default; the state is checked after the run), kernel = halo_reset_round_state rewrites "
+                         "all 17 bytes per pixel on the scoring stream, fills = three torch fills there (round 2), side = the "
+                         "fills on a housekeeping stream")
+    ap.add_argument("--dump-tables", default="", help="rank 0 writes the round's gathered pick tables / counts / owners (pool "
+                                                      "order) to this .npz after the timed region (tests compare world sizes)")
     ap.add_argument("--sel-priority", type=int, default=-1, help="stream priority of the selection streams (-1 = high)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
 
 
-def make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres=False):
-    """Synthetic pool per SURVEY.md 8(d): low-res latent z ~ N(0, 0.1^2), seed 1234+image index;
+def make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres=False):
+    """Synthetic pool per SURVEY.md 8(d): low-res latent z ~ N(0, 0.1^2), seed 1234 + image id (`seeds[r]` for ring slot r);
     embed = expmap0_project(z); logit = HyperMLR(embed), P/A ~ kaiming_uniform(a=sqrt 5) seed 7;
     both upsampled x4 (align_corners) -- all by this package's own kernels, untimed."""
     from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners
@@ -97,7 +105,7 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres=False):
     gt = torch.empty((R, Hh, Ww), dtype=torch.int64, device=dev)
     with torch.no_grad():
         for r in range(R):
-            g = torch.Generator(device=dev).manual_seed(1234 + rank * R + r)
+            g = torch.Generator(device=dev).manual_seed(1234 + int(seeds[r]))
             z = torch.randn((1, C, h, w), generator=g, device=dev, dtype=torch.float32) * 0.1
             emb = mapper.expmap(z, dim=1)
             lg = mlr._hyper_logits(emb, out_dtype=torch.float32)
@@ -124,10 +132,11 @@ BRANCHES = {   # name -> (unc_type, pur_type, normalize, mask radius, K)
 
 
 class Pipeline:
-    """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`."""
+    """Two-stream pipeline: score(batch s+1) on `s_score` overlaps select(batch s) on `s_sel`; the round's tables
+    collect in one wire block that is exchanged ONCE, behind the last step."""
 
-    def __init__(self, dev, feat, logit, gt, B, n_regions, world, depth, use_dist=False, lowres=False, branch="halo",
-                 resets="score", sel_priority=-1, lr_mode="exact"):
+    def __init__(self, dev, feat, logit, gt, B, n_regions, rows, depth, lowres=False, branch="halo",
+                 resets="undo", sel_priority=-1, lr_mode="exact"):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
@@ -143,6 +152,7 @@ class Pipeline:
         D = self.D = depth
         self.s_score = torch.cuda.Stream(dev)
         self.s_sel = [torch.cuda.Stream(dev, priority=sel_priority) for _ in range(D)]   # -1: dispatch ahead of scoring
+        self.s_comm = torch.cuda.Stream(dev)                # the round's one exchange: normal priority, its own stream
         from halo_amd.core.active.floating_region import score_dtype
         sdt = score_dtype(self.pur, feat)
         self.score = [torch.empty((B, Hh, Ww), dtype=sdt, device=dev) for _ in range(D)]
@@ -155,44 +165,54 @@ class Pipeline:
         self.scored = [torch.cuda.Event() for _ in range(D)]
         self.selected_done = [torch.cuda.Event() for _ in range(D)]
         self.ev = []                       # (start, stop) HIP events around k_feat_reduce
-        self.world = world
-        self.use_dist = use_dist
         self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]
         self.counts = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(D)]
-        self.gathered = [None] * D         # (tables, counts, owner) of the whole step, every rank
+        # this rank's block of the round's wire format (halo_amd/pool.py), padded to ceil(N / world) rows
+        self.wire = torch.zeros((rows, 3 * n_regions + 1), dtype=torch.int32, device=dev)
         self.step_no = 0
-        self.last = None
         self.slot_lo = [None] * D          # which ring slice each slot last processed
         self.ref_tables = {}               # ring offset -> pick table seen first (the ring repeats: tables must too)
         self.tables_consistent = True
         self.min_picked = n_regions
+        self.exchange_ms = None
 
-    def step(self, timed, b=None):
-        """One batch of `b` (default B) images: score on s_score, then mask + select (+ the all-gather) on the slot's stream."""
+    def _restore_state(self, k):
+        from halo_amd.pool import reset_round_state
+        if self.resets == "kernel":
+            reset_round_state(self.active[k], self.selected[k], self.amask[k])
+        else:
+            self.active[k].zero_()
+            self.selected[k].zero_()
+            self.amask[k].fill_(255)
+
+    def step(self, timed, b=None, lo=None, row=None):
+        """One batch of `b` (default B) images starting at ring slot `lo`: score on s_score, then mask + select on the
+        slot's stream; `row` (timed steps): where the batch's tables go in the round's wire block."""
         from halo_amd.core.active.build import greedy_select
         from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
-        from halo_amd.pool import gather_tables
+        from halo_amd.pool import pack_tables_into, undo_picks
         B, R = self.B, self.R
         b = B if b is None else b
         k = self.step_no % self.D
-        lo = (self.step_no * B) % R
-        if lo + B > R:
+        if lo is None:
+            lo = (self.step_no * B) % R
+        if lo + b > R:
             lo = 0
         fb, lb, gb = self.feat[lo:lo + b], self.logit[lo:lo + b], self.gt[lo:lo + b]
         evs = None
         timed_kernel = timed and not self.lowres and self.pur in ("radius", "euc_norm", "hyper")
         if timed_kernel:
             evs = (self.lib.halo_event_create(), self.lib.halo_event_create())
-            self.ev.append(evs)
+            self.ev.append(evs + (b,))
         with torch.cuda.stream(self.s_score):
             # round-1 state for this batch (the loader's job in the reference, cityscapes.py:245-251).
-            # Kept on the scoring stream by default: moving the three fills to the slot's select stream measured
+            # Kept on the scoring stream by default: moving the fills to the slot's select stream measured
             # 5-8 % SLOWER end to end (they then run at high priority beside the feature stream).
-            if self.resets == "score" or self.step_no < self.D:
+            if self.resets in ("kernel", "fills"):
                 self.s_score.wait_event(self.selected_done[k])      # buffers k free again
-                self.active[k].zero_()
-                self.selected[k].zero_()
-                self.amask[k].fill_(255)
+                self._restore_state(k)
+            elif self.resets == "undo" or self.step_no < self.D:
+                self.s_score.wait_event(self.selected_done[k])      # undo: the restore ran behind the slot's selection
             else:
                 self.s_score.wait_event(self.reset_done[k])
             # all three output maps of FloatingRegionScore.forward are written (floating_region.py:217)
@@ -212,24 +232,54 @@ class Pipeline:
                                        self.amask[k][:b], gb)
             self.tables[k][:b].copy_(picks)
             self.counts[k][:b].copy_(npk)
-            if self.use_dist:      # the path's one exchange step: per-image pick tables to every rank, ONE collective
-                self.gathered[k] = gather_tables(self.tables[k][:b], self.counts[k][:b], self.world * b)
+            if row is not None:        # the round's exchange format, one launch per step; the collective itself runs once
+                pack_tables_into(self.wire[row:row + b], picks, npk)
+            if self.resets == "undo":
+                undo_picks(picks, npk, 1, self.mrad, self.active[k][:b], self.selected[k][:b], self.amask[k][:b])
             self.selected_done[k].record(self.s_sel[k])
         if self.resets == "side":
             with torch.cuda.stream(self.s_house):
                 self.s_house.wait_event(self.selected_done[k])
-                self.active[k].zero_()
-                self.selected[k].zero_()
-                self.amask[k].fill_(255)
+                self._restore_state(k)
                 self.reset_done[k].record(self.s_house)
-        self.last = (k, lo, b)
         self.slot_lo[k] = (lo, b)
         self.step_no += 1
+
+    def finish_round(self, n_images, host_backend=False):
+        """The path's one exchange step: behind the last selection of the round, ONE all-gather of the
+        rank's wire block on the communication stream.  Returns (tables, counts) of the whole pool in pool order."""
+        from halo_amd.pool import gather_wire
+        with torch.cuda.stream(self.s_comm):
+            for e in self.selected_done:
+                self.s_comm.wait_event(e)
+            if host_backend:
+                self.s_comm.synchronize()
+                t0 = time.perf_counter()
+                out = gather_wire(self.wire, n_images, self.n)
+                self.s_comm.synchronize()
+                self.exchange_ms = (time.perf_counter() - t0) * 1e3
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.s_comm)
+                out = gather_wire(self.wire, n_images, self.n)
+                e1.record(self.s_comm)
+                self._exchange_events = (e0, e1)
+        return out
 
     def drain(self):
         self.s_score.synchronize()
         for st in self.s_sel:
             st.synchronize()
+        self.s_house.synchronize()
+        self.s_comm.synchronize()
+        ee = getattr(self, "_exchange_events", None)
+        if ee is not None:
+            self.exchange_ms = ee[0].elapsed_time(ee[1])
+            self._exchange_events = None
+        if self.resets == "undo" and self.step_no >= self.D:      # the restore must have left exactly the loader's round-1 state
+            for k in range(self.D):
+                assert not bool(self.active[k].any()) and not bool(self.selected[k].any()) and bool((self.amask[k] == 255).all()), \
+                    "halo_undo_picks did not restore the round-1 state of slot %d" % k
         # self-check under concurrency (outside the timed region): the same ring images must give the same
         # pick tables whichever slot / step / overlap pattern processed them
         for k, ent in enumerate(self.slot_lo):
@@ -246,9 +296,9 @@ class Pipeline:
     def feat_kernel_ms(self):
         import ctypes
         out = []
-        for a, b in self.ev:
+        for a, b, nimg in self.ev:
             ms = ctypes.c_float(0)
-            if self.lib.halo_event_elapsed_ms(a, b, ctypes.byref(ms)) == 0:
+            if self.lib.halo_event_elapsed_ms(a, b, ctypes.byref(ms)) == 0 and nimg == self.B:      # full batches only
                 out.append(ms.value)
             self.lib.halo_event_destroy(a)
             self.lib.halo_event_destroy(b)
@@ -306,14 +356,27 @@ def cpu_baseline(feat, logit, gt, n_images, n_regions, branch):
     return float(np.median(times)), cores, picks
 
 
+def visible_devices():
+    """Number of ROCm devices a child process of this one would see -- asked of a short-lived CHILD, so that the
+    launcher parent never brings up the HIP runtime (on ROCm torch.cuda.device_count() falls back to hipGetDeviceCount
+    when amdsmi is absent, which initialises HIP/HSA in the caller)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through
-    torch.distributed.run and relay their output.  Nothing in this process has touched the GPU yet
-    (device_count() does not initialise it), and it only waits for the children -- no exec."""
+    torch.distributed.run and relay their output.  This process never touches the GPU (the device count comes from a
+    child too) and only waits for the children -- no exec."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
-    if have < n:
+    share = bool(os.environ.get("HALO_BENCH_SHARE_GPU"))
+    have = visible_devices()
+    if have < (1 if share else n):
         sys.exit("bench.py: --gpus %d but only %d ROCm device(s) visible" % (n, have))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -333,16 +396,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), effective_cpus())))      # host pools no wider than the cgroup quota
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    # host pools no wider than this rank's share of the cgroup quota (8 ranks x 16 threads on a 16-core quota only throttle)
+    host_threads = max(1, effective_cpus() // local_world)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), host_threads)))
     assert torch.cuda.is_available(), "bench.py needs ROCm devices"
-    dev = torch.device("cuda", local)
+    # HALO_BENCH_BACKEND=gloo + HALO_BENCH_SHARE_GPU=1: the hardware test of the N > 1 code on a ONE-GPU box -- every rank
+    # on device 0, the wire block staged through the host.  Never set for a measurement.
+    backend = os.environ.get("HALO_BENCH_BACKEND", "nccl")
+    share_gpu = bool(os.environ.get("HALO_BENCH_SHARE_GPU"))
+    dev = torch.device("cuda", local % torch.cuda.device_count() if share_gpu else local)
     torch.cuda.set_device(dev)
     # launched by torch.distributed.run (RANK set): one process per GPU over RCCL, also at world 1
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    device_ids = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         assert dist.get_world_size() == world
+        if not share_gpu:      # one process per GPU: two ranks on one device would halve every number silently
+            from halo_amd.pool import assert_distinct_devices
+            device_ids = assert_distinct_devices(dev.index)
+    host_backend = use_dist and backend != "nccl"
     fdtype = torch.float64 if a.feat_dtype == "f64" else torch.float32
     a.depth = max(1, a.depth)
     Hh, Ww, C, B = a.height, a.width, a.channels, a.batch
@@ -353,18 +431,26 @@ def main():
     lowres = a.source == "lowres"
     if lowres:
         a.cpu_images = 0
-    feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, rank, lowres)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, world, a.depth, use_dist, lowres, a.branch, a.resets, a.sel_priority,
-                    a.lr_mode)
 
-    # per-rank schedule: full batches, plus a partial last one when --pool-images does not divide evenly
-    if a.pool_images > 0:
-        from halo_amd.pool import shard_range
-        per_rank = shard_range(a.pool_images, 0, world)[1]            # every rank runs the largest block (weak scaling)
-        sched = [B] * (per_rank // B) + ([per_rank % B] if per_rank % B else [])
-        a.steps = len(sched)
+    # ---- the pool and this rank's block of it (halo_amd.pool.shard_range: contiguous ceil(N/world) images per rank)
+    from halo_amd.pool import shard_range
+    pool_mode = a.pool_images > 0
+    n_pool = a.pool_images if pool_mode else world * a.steps * B
+    lo_r, hi_r = shard_range(n_pool, rank, world)
+    rows = math.ceil(n_pool / world)
+    n_local = hi_r - lo_r
+    # full batches, plus a partial last one when the block does not divide evenly
+    sched = [B] * (n_local // B) + ([n_local % B] if n_local % B else [])
+    if pool_mode:
+        # pool image g has content id g % R on EVERY rank (so the pool's results do not depend on the world size and
+        # any rank can check any other rank's rows); rank r's ring is that base ring rotated by its block's offset
+        seeds = [(lo_r + s_) % R for s_ in range(R)]
+        a.steps = math.ceil(rows / B)                                  # steps of the largest block
     else:
-        sched = [B] * a.steps
+        seeds = [rank * R + s_ for s_ in range(R)]                      # every rank its own R images
+    feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, rows, a.depth, lowres, a.branch, a.resets, a.sel_priority, a.lr_mode)
+
     for _ in range(a.warmup):
         pipe.step(False)
     pipe.drain()
@@ -372,17 +458,44 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    row = 0
     for b in sched:
-        pipe.step(True, b)
+        pipe.step(True, b, lo=row % R, row=row)
+        row += b
+    tables, counts = pipe.finish_round(n_pool, host_backend)           # ONE collective per round
     pipe.drain()
     torch.cuda.synchronize(dev)
+    dt_rank = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    rank_dts = [dt_rank]
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if host_backend else dev
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        allt = torch.zeros((world,), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allt, torch.tensor([dt_rank], dtype=torch.float64, device=cdev))
+        rank_dts = [float(x) for x in allt.cpu()]
+
+    # ---- what the exchange delivered (outside the timed region): this rank's rows are its local tables, and -- pool
+    # mode -- every other rank's rows equal this rank's own results for the same content
+    assert tables.shape[0] == n_pool and counts.shape[0] == n_pool
+    k_last = (pipe.step_no - 1) % pipe.D
+    if sched:
+        b_last = sched[-1]
+        assert torch.equal(tables[hi_r - b_last:hi_r], pipe.tables[k_last][:b_last]), "gathered table differs from the local one"
+        assert torch.equal(counts[hi_r - b_last:hi_r], pipe.counts[k_last][:b_last])
+    assert int(counts.min()) == n_regions, "a gathered image has fewer picks than regions"
+    exchange_checked = 0
+    if pool_mode and n_local > 0:
+        g_ = torch.arange(n_pool, device=dev)
+        j_ = (g_ - lo_r) % R                                            # local image with the same content id
+        known = j_ < n_local
+        exchange_checked = int(known.sum())
+        ref = tables[(lo_r + j_)[known]]
+        assert torch.equal(tables[known], ref), "rows gathered from other ranks differ from this rank's results for the same images"
 
     feat_ms = pipe.feat_kernel_ms()
     assert pipe.min_picked == n_regions, "selection stopped early"
@@ -391,7 +504,7 @@ def main():
     if rank == 0:
         esz = 8 if fdtype == torch.float64 else 4
         ssz = pipe.score[0].element_size()
-        images = world * sum(sched)
+        images = n_pool
         value = images / dt
         # k_feat_reduce per launch: features read + radius map written + (fused) logits read + entropy map written
         launch_bytes = B * Hh * Ww * (C * esz + esz + O * 4 + 4)
@@ -402,7 +515,8 @@ def main():
         out = {
             "metric": "acquisition-scored images/sec (1024x2048, C=256, 19 cls)",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if pool_mode else "weak",       # --pool-images fixes the total work, --steps the per-GPU work
             "vs_baseline": None, "dtype": a.feat_dtype, "data": "synthetic",
             "config": {"workload": "configs[%d]: synthetic pool, %dx%d, C=%d %s embedding, %d classes, %s branch "
                                    "(%s x %s, %s, 3x3), %d regions/image, radius 1, mask radius %d"
@@ -410,13 +524,22 @@ def main():
                                       "normalised" if norm else "not normalised", n_regions, mrad),
                        "images_per_step_per_gpu": B, "batches_in_flight": a.depth, "resident_ring": R, "image_evaluations": images,
                        "outputs_written": "score, region_impurity, prediction_uncertainty (+ masks, pick tables)",
-                       "sharding": "image-wise, %d rank(s)%s" % (world, ", one RCCL all-gather of pick tables per step" if use_dist else "")},
+                       "sharding": "image-wise, %d rank(s), contiguous blocks of %d image(s)%s"
+                                   % (world, rows, (", one %s all-gather of pick tables per round" % ("RCCL" if backend == "nccl" else backend))
+                                      if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms)},
             "path_algorithmic_GBps": round(path_bytes_per_image * value / world / 1e9, 1),
             "pipeline_tables_consistent": bool(pipe.tables_consistent),
+            "exchange": {"collectives_per_round": 1 if use_dist else 0, "ms": None if pipe.exchange_ms is None else round(pipe.exchange_ms, 3),
+                         "bytes_per_rank": int(pipe.wire.numel() * 4), "rows_checked_against_local_results": exchange_checked},
+            "state_resets": a.resets, "host_threads_per_rank": host_threads,
         }
+        per_rank = [(shard_range(n_pool, r_, world)[1] - shard_range(n_pool, r_, world)[0]) / rank_dts[r_] for r_ in range(world)]
+        out["per_rank_images_per_s"] = {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)}
+        if device_ids is not None:
+            out["devices"] = device_ids
         if lowres:      # not the BASELINE unit of work: a different (smaller) input boundary, reported for DESIGN.md
             out["config"]["workload"] = "RegionSelection boundary (N1): x4 low-res head outputs (%dx%d), upsample fused into the scorer, " \
                                         "then the same mask + select; NOT the BASELINE unit of work" % (Hh // 4, Ww // 4)
@@ -453,12 +576,10 @@ def main():
             out["parity_vs_cpu"] = bool(np.array_equal(pk[0, :int(nk[0])].cpu().numpy(), picks_cpu[0]))
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+    if rank == 0 and a.dump_tables:
+        np.savez(a.dump_tables, tables=tables.cpu().numpy(), counts=counts.cpu().numpy(), n_pool=n_pool, world=world)
     if use_dist:
-        k, lo, b = pipe.last
-        g = pipe.gathered[k]
-        if g is not None:      # every rank holds the whole step's tables; its own block must be its local result
-            assert torch.equal(g[0][rank * b:(rank + 1) * b], pipe.tables[k][:b]), "all-gathered table differs from the local one"
-            assert torch.equal(g[1][rank * b:(rank + 1) * b], pipe.counts[k][:b])
+        dist.barrier()
         dist.destroy_process_group()
 
 

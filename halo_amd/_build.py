@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libhalo_hip.so")
-SOURCES = ["halo_api.hip", "halo_score.hip", "halo_select.hip", "halo_select_binned.hip", "halo_hyperbolic.hip", "halo_loss.hip"]
+SOURCES = ["halo_api.hip", "halo_score.hip", "halo_select.hip", "halo_select_binned.hip", "halo_hyperbolic.hip", "halo_loss.hip", "halo_pool.hip"]
 HEADERS = ["halo_common.hpp", "halo_devmath.hpp", "halo_select_common.hpp", "halo_select_plan.hpp", os.path.join("..", "..", "include", "halo_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

@@ -55,6 +55,10 @@ SIGNATURES = {
     "halo_event_record": (_int, [_vp, _vp]),
     "halo_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "halo_event_destroy": (_int, [_vp]),
+    "halo_pack_pick_tables": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "halo_reset_round_state": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "halo_undo_picks": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "halo_device_identity": (_int, [_int, C.c_char_p, _sz]),
     "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "halo_greedy_select": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _sz, _int, _vp]),
@@ -62,7 +66,7 @@ SIGNATURES = {
 
 # must equal HALO_ABI_VERSION of include/halo_hip.h; bumped whenever an exported signature changes, so a stale
 # library with the same symbol names but older argument lists is refused instead of being called with shifted arguments
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _handle = None

@@ -59,6 +59,21 @@ __global__ void __launch_bounds__(TPB) k_minmax_finalize(const double *__restric
     block_minmax<TPB>(mn, mx, stats + b * 4 + slot * 2);
 }
 
+// both maps of normalize_map in one launch: blockIdx.y = slot (0: impurity partials, 1: uncertainty partials).  1024
+// threads: the kernel is a dependent chain of loads on 2 B blocks, i.e. pure latency -- fewer trips per thread.
+constexpr int FIN_TPB = 1024;
+__global__ void __launch_bounds__(FIN_TPB) k_minmax_finalize2(const double *__restrict__ part0, int nblk0, const double *__restrict__ part1,
+                                                               int nblk1, double *__restrict__ stats)
+{
+    const int b = blockIdx.x, slot = blockIdx.y;
+    const int nblk = slot ? nblk1 : nblk0;
+    const double2 *p = reinterpret_cast<const double2 *>((slot ? part1 : part0) + (size_t)b * nblk * 2);
+    const double2 p0 = p[0];
+    double mn = p0.x, mx = p0.y;
+    for (int i = threadIdx.x; i < nblk; i += FIN_TPB) { const double2 q = p[i]; mn = nan_min(mn, q.x); mx = nan_max(mx, q.y); }
+    block_minmax<FIN_TPB>(mn, mx, stats + b * 4 + slot * 2);
+}
+
 // ---------------------------------------------------------------- logits -> entropy / prediction
 // Softmax, entropy and arg-max over the classes of a pixel (floating_region.py:72-76, 119, 152).  Two statements of the
 // same arithmetic:
@@ -629,8 +644,61 @@ __global__ void __launch_bounds__(TPB) k_box_unc(const float *__restrict__ ent, 
 }
 
 // 3 x 3 fast path (the only window the reference's drivers use: RADIUS_K = 1, build.py:83-88):
-// 4 consecutive pixels per lane, three float4 row loads plus the two edge neighbours, same
-// row-major tap order (out-of-image taps add +0) as the generic kernel.
+// 4 consecutive pixels per lane, three float4 row loads; the two edge neighbours of a row come from the adjacent lanes'
+// registers (full-wave DPP shifts) and are loaded only by the first / last lane of a wave.  Same row-major tap order
+// (out-of-image taps add +0) as the generic kernel.
+__device__ __forceinline__ float lane_prev(float v)      // value of lane - 1 (lane 0: unspecified)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v)      // value of lane + 1 (lane 63: unspecified)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+// a / count, count = in-bounds size of the pk x pk purity window (pk = 0: count 1, and a / 1 is a, bit for bit)
+__device__ __forceinline__ float box3_over_count(float a, int H, int W, int y, int xx, int pk)
+{
+    if (pk <= 0) return a;
+    const int rr = pk / 2;
+    const int y0 = y - rr < 0 ? 0 : y - rr, y1 = y + rr >= H ? H - 1 : y + rr;
+    const int x0 = xx - rr < 0 ? 0 : xx - rr, x1 = xx + rr >= W ? W - 1 : xx + rr;
+    return a / (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+}
+
+// Box sums / count of the 4 pixels (y, x..x+3) of image plane `ep`; x % 4 == 0, W % 4 == 0.  Every lane of the wave
+// calls it (dead lanes with live = false: they only take part in the lane shifts).
+__device__ __forceinline__ void box3_row4(const float *__restrict__ ep, int H, int W, int y, int x, bool live, int pk, float (&o)[4])
+{
+    const int lane = threadIdx.x & 63;
+    float r[3][6];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        const bool in = live && yy >= 0 && yy < H;
+        const float *row = ep + (size_t)(in ? yy : 0) * W;
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (in) q = *reinterpret_cast<const float4 *>(row + x);
+        // the neighbours' registers hold the same row (a lane's left neighbour in the wave is the 4 pixels before it)
+        float left = lane_prev(q.w), right = lane_next(q.x);
+        if (lane == 0) left = (in && x > 0) ? row[x - 1] : 0.0f;
+        if (lane == 63) right = (in && x + 4 < W) ? row[x + 4] : 0.0f;
+        r[dy][0] = (in && x > 0) ? left : 0.0f;
+        r[dy][1] = q.x; r[dy][2] = q.y; r[dy][3] = q.z; r[dy][4] = q.w;
+        r[dy][5] = (in && x + 4 < W) ? right : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a = a + r[dy][j + dx];
+        o[j] = box3_over_count(a, H, W, y, x + j, pk);
+    }
+}
+
+// unc may be NULL: then only the per-block min / max are produced (k_combine_box3 recomputes the sums it normalises)
 __global__ void __launch_bounds__(TPB) k_box3_unc(const float *__restrict__ ent, int H, int W, int pk,
                                                   float *__restrict__ unc, double *__restrict__ partials)
 {
@@ -639,42 +707,11 @@ __global__ void __launch_bounds__(TPB) k_box3_unc(const float *__restrict__ ent,
     const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
     const bool live = i0 < hw;
     double mn = 0.0, mx = 0.0;
+    const int y = live ? (int)(i0 / W) : 0, x = live ? (int)(i0 % W) : 0;          // W % 4 == 0: the 4 pixels share a row
+    float o[4];
+    box3_row4(ent + (size_t)b * hw, H, W, y, x, live, pk, o);
     if (live) {
-        const int y = (int)(i0 / W), x = (int)(i0 % W);          // W % 4 == 0: the 4 pixels share a row
-        const float *ep = ent + (size_t)b * hw;
-        float r[3][6];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = y + dy - 1;
-            if (yy >= 0 && yy < H) {
-                const float *row = ep + (size_t)yy * W;
-                const float4 q = *reinterpret_cast<const float4 *>(row + x);
-                r[dy][0] = x > 0 ? row[x - 1] : 0.0f;
-                r[dy][1] = q.x; r[dy][2] = q.y; r[dy][3] = q.z; r[dy][4] = q.w;
-                r[dy][5] = x + 4 < W ? row[x + 4] : 0.0f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) r[dy][j] = 0.0f;
-            }
-        }
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a = 0.0f;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) a = a + r[dy][j + dx];
-            float cnt = 1.0f;
-            if (pk > 0) {
-                const int rr = pk / 2, xx = x + j;
-                const int y0 = y - rr < 0 ? 0 : y - rr, y1 = y + rr >= H ? H - 1 : y + rr;
-                const int x0 = xx - rr < 0 ? 0 : xx - rr, x1 = xx + rr >= W ? W - 1 : xx + rr;
-                cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
-            }
-            o[j] = a / cnt;
-        }
-        *reinterpret_cast<float4 *>(unc + (size_t)b * hw + i0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (unc) *reinterpret_cast<float4 *>(unc + (size_t)b * hw + i0) = make_float4(o[0], o[1], o[2], o[3]);
         mn = mx = (double)o[0];
 #pragma unroll
         for (int j = 1; j < 4; ++j) { mn = nan_min(mn, (double)o[j]); mx = nan_max(mx, (double)o[j]); }
@@ -685,6 +722,81 @@ __global__ void __launch_bounds__(TPB) k_box3_unc(const float *__restrict__ ent,
     __syncthreads();
     if (!live) { mn = seed[0]; mx = seed[1]; }
     block_minmax<TPB>(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
+// The min / max pass of the fused tail: the same sums as box3_row4 (same taps, same order), nothing stored.  A wave owns a
+// strip of 256 columns x BM_RPT rows and slides a three-row window down it: BM_RPT + 2 row loads for BM_RPT rows of sums
+// (k_box3_unc: 3 per row) and ONE reduction per BM_RPT * 4 pixels of a lane, in float32 (exact; widened at the end).
+constexpr int BM_RPT = 4, BM_TW = 256, BM_TH = BM_RPT * (TPB / 64);
+
+__device__ __forceinline__ float nan_minf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+__device__ __forceinline__ float nan_maxf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+
+__global__ void __launch_bounds__(TPB) k_box3_minmax(const float *__restrict__ ent, int H, int W, int pk, double *__restrict__ partials)
+{
+    const int b = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * BM_TW + lane * 4, y0 = blockIdx.y * BM_TH + wv * BM_RPT;
+    const float *ep = ent + (size_t)b * H * W;
+    const bool xin = x < W;
+    auto load_row = [&](int yy, float (&r)[6]) {
+        const bool in = xin && yy >= 0 && yy < H;
+        const float *row = ep + (size_t)(in ? yy : 0) * W;
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (in) q = *reinterpret_cast<const float4 *>(row + x);
+        float left = lane_prev(q.w), right = lane_next(q.x);
+        if (lane == 0) left = (in && x > 0) ? row[x - 1] : 0.0f;
+        if (lane == 63) right = (in && x + 4 < W) ? row[x + 4] : 0.0f;
+        r[0] = (in && x > 0) ? left : 0.0f;
+        r[1] = q.x; r[2] = q.y; r[3] = q.z; r[4] = q.w;
+        r[5] = (in && x + 4 < W) ? right : 0.0f;
+    };
+    float r0[6], r1[6], r2[6];
+    load_row(y0 - 1, r0);
+    load_row(y0, r1);
+    float mn = 0.0f, mx = 0.0f;
+    bool have = false;
+#pragma unroll
+    for (int k = 0; k < BM_RPT; ++k) {
+        const int y = y0 + k;
+        load_row(y + 1, r2);                 // every lane of the wave, also past the image: the lane shifts are wave-wide
+        if (xin && y < H) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = 0.0f;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a = a + r0[j + dx];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a = a + r1[j + dx];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a = a + r2[j + dx];
+                const float o = box3_over_count(a, H, W, y, x + j, pk);
+                if (!have) { mn = mx = o; have = true; }
+                else { mn = nan_minf(mn, o); mx = nan_maxf(mx, o); }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { r0[q] = r1[q]; r1[q] = r2[q]; }
+    }
+    // lanes without a pixel take the block's first pixel (lane 0 of wave 0 always has one)
+    __shared__ float seedf[2];
+    __shared__ float smn[TPB / 64], smx[TPB / 64];
+    if (threadIdx.x == 0) { seedf[0] = mn; seedf[1] = mx; }
+    __syncthreads();
+    if (!have) { mn = seedf[0]; mx = seedf[1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = nan_minf(mn, __shfl_xor(mn, off));
+        mx = nan_maxf(mx, __shfl_xor(mx, off));
+    }
+    if (lane == 0) { smn[wv] = mn; smx[wv] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < TPB / 64; ++i) { mn = nan_minf(mn, smn[i]); mx = nan_maxf(mx, smx[i]); }
+        double *out2 = partials + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2;
+        out2[0] = (double)mn;
+        out2[1] = (double)mx;
+    }
 }
 
 // per-block min/max of an existing f32 map (impurity of the histogram branches)
@@ -738,6 +850,67 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
     score[o] = s;
     if (imp_out) imp_out[o] = im;
     if (unc_out) unc_out[o] = un;
+}
+
+
+// k_combine with the 3 x 3 box sum of the uncertainty recomputed from the entropy map (box3_row4: the same operations
+// that produced the min / max, so the same bits) instead of read from a stored copy: one kernel and one 4-byte map
+// less in the step's tail.  4 pixels per lane, 16-byte loads and stores.
+template <typename TI>
+__global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp_raw, const float *__restrict__ ent,
+                                                      const double *__restrict__ stats, const unsigned char *__restrict__ active,
+                                                      int H, int W, int pk, int normalize, TI *__restrict__ score,
+                                                      TI *__restrict__ imp_out, float *__restrict__ unc_out)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)H * W;
+    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
+    const bool live = i0 < hw;
+    const int y = live ? (int)(i0 / W) : 0, x = live ? (int)(i0 % W) : 0;
+    float un[4];
+    box3_row4(ent + (size_t)b * hw, H, W, y, x, live, pk, un);
+    if (!live) return;
+    const size_t o = (size_t)b * hw + i0;
+    TI im[4];
+    if constexpr (sizeof(TI) == 8) {
+        const double2 q0 = *reinterpret_cast<const double2 *>(imp_raw + o), q1 = *reinterpret_cast<const double2 *>(imp_raw + o + 2);
+        im[0] = q0.x; im[1] = q0.y; im[2] = q1.x; im[3] = q1.y;
+    } else {
+        const float4 q = *reinterpret_cast<const float4 *>(imp_raw + o);
+        im[0] = q.x; im[1] = q.y; im[2] = q.z; im[3] = q.w;
+    }
+    if (normalize) {
+        const float umn = (float)stats[b * 4 + 2], umx = (float)stats[b * 4 + 3];
+        const float uden = (float)((double)umx - (double)umn);
+        const TI imn = (TI)stats[b * 4 + 0], imx = (TI)stats[b * 4 + 1];
+        TI iden;
+        if constexpr (sizeof(TI) == 8) iden = imx - imn;
+        else iden = (float)((double)imx - (double)imn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { un[j] = (un[j] - umn) / uden; im[j] = (im[j] - imn) / iden; }
+    }
+    const unsigned am = active ? *reinterpret_cast<const unsigned *>(active + o) : 0u;
+    TI sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = im[j] * (TI)un[j];
+        if ((am >> (8 * j)) & 0xffu) {
+            if constexpr (sizeof(TI) == 8) sc[j] = __longlong_as_double(0xfff0000000000000ll);
+            else sc[j] = __uint_as_float(0xff800000u);
+        }
+    }
+    if constexpr (sizeof(TI) == 8) {
+        *reinterpret_cast<double2 *>(score + o) = make_double2(sc[0], sc[1]);
+        *reinterpret_cast<double2 *>(score + o + 2) = make_double2(sc[2], sc[3]);
+        if (imp_out) {
+            *reinterpret_cast<double2 *>(imp_out + o) = make_double2(im[0], im[1]);
+            *reinterpret_cast<double2 *>(imp_out + o + 2) = make_double2(im[2], im[3]);
+        }
+    } else {
+        *reinterpret_cast<float4 *>(score + o) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+        if (imp_out) *reinterpret_cast<float4 *>(imp_out + o) = make_float4(im[0], im[1], im[2], im[3]);
+    }
+    if (unc_out) *reinterpret_cast<float4 *>(unc_out + o) = make_float4(un[0], un[1], un[2], un[3]);
 }
 
 
@@ -1293,7 +1466,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     double *imp_raw = ar.take<double>((size_t)B * hw);
     short *pred = ar.take<short>((size_t)B * hw);
     double *part_imp = ar.take<double>((size_t)B * partial_slots(H, W) * 2);
-    double *part_unc = ar.take<double>((size_t)B * nblk1 * 2);
+    double *part_unc = ar.take<double>((size_t)B * partial_slots(H, W) * 2);
     double *stats = ar.take<double>((size_t)B * 4);
     float *lr_logit_full = lr_generic_O ? ar.take<float>((size_t)B * O * hw) : nullptr;
     const bool gram_mode = lr && lr->gram && need_feat;
@@ -1397,8 +1570,21 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     // ---- box-sum of the uncertainty, / count
     const int do_box = (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_ORACLE_ACC) ? 1 : 0;
     int nblk_unc = nblk1;
-    if (do_box && ksize == 3 && W % 4 == 0 && aligned16(ent) && aligned16(unc_raw)) {
-        nblk_unc = (int)cdiv(hw, TPB * 4);
+    const bool box3 = do_box && ksize == 3 && W % 4 == 0 && aligned16(ent) && aligned16(unc_raw);
+    // 3 x 3 window + 16-byte aligned maps: the box sum is recomputed inside the combine kernel (no stored copy);
+    // HALO_NO_FUSE_TAIL=1 keeps the round-2 sequence (A/B switch, identical results)
+    const bool fuse_tail = box3 && B <= 65535 && cdiv(H, BM_TH) <= 65535 && aligned16(imp_raw) && aligned16(score) && (!impurity || aligned16(impurity)) &&
+                           (!uncertainty || aligned16(uncertainty)) && (!active || ((uintptr_t)active & 3) == 0) &&
+                           getenv("HALO_NO_FUSE_TAIL") == nullptr;
+    const int nblk_c3 = (int)cdiv(hw, TPB * 4);
+    if (fuse_tail) {
+        if (normalize) {            // only the min / max are needed before the combine kernel
+            const dim3 gridm((unsigned)cdiv(W, BM_TW), (unsigned)cdiv(H, BM_TH), (unsigned)B);
+            nblk_unc = (int)(gridm.x * gridm.y);
+            hipLaunchKernelGGL(k_box3_minmax, gridm, block, 0, st, (const float *)ent, (int)H, (int)W, hist ? pksize : 0, part_unc);
+        }
+    } else if (box3) {
+        nblk_unc = nblk_c3;
         hipLaunchKernelGGL(k_box3_unc, dim3((unsigned)nblk_unc, (unsigned)B), block, 0, st, (const float *)ent, (int)H, (int)W,
                            hist ? pksize : 0, unc_raw, normalize ? part_unc : nullptr);
     } else {
@@ -1407,11 +1593,14 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     }
 
     // ---- global min/max (normalize_map only), then normalise + product
-    if (normalize) {
-        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_imp, nblk_imp, stats, 0);
-        hipLaunchKernelGGL(k_minmax_finalize, dim3((unsigned)B), block, 0, st, part_unc, nblk_unc, stats, 1);
-    }
-    if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
+    if (normalize)
+        hipLaunchKernelGGL(k_minmax_finalize2, dim3((unsigned)B, 2u), dim3(FIN_TPB), 0, st, (const double *)part_imp, nblk_imp,
+                           (const double *)part_unc, nblk_unc, stats);
+    if (fuse_tail) {
+        dim3 gridc((unsigned)nblk_c3, (unsigned)B);
+        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty);
+        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty);
+    } else if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
     return check_launch("halo_score_maps");
 }

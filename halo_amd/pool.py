@@ -44,12 +44,39 @@ def pack_tables(picks, n_picked, rows):
     b, n = picks.shape[0], picks.shape[1]
     wire = torch.zeros((rows, 3 * n + 1), dtype=torch.int32, device=picks.device)
     if b:
-        pos = ((picks[:, :, 0].to(torch.int64) << 16) | picks[:, :, 1].to(torch.int64)).to(torch.int32)   # sides <= 65535
-        body = wire[:b, :3 * n].view(b, n, 3)
-        body[:, :, 0] = pos
-        body[:, :, 1:] = picks[:, :, 2].contiguous().view(torch.int32).view(b, n, 2)     # the score's bits, unchanged
-        wire[:b, 3 * n] = n_picked.to(torch.int32)
+        pack_tables_into(wire[:b], picks, n_picked)
     return wire
+
+
+def pack_tables_into(wire_rows, picks, n_picked):
+    """Write the wire rows of `picks` (b, n, 3) / `n_picked` (b,) into `wire_rows` (b, 3n+1) int32 in place.  Device tensors
+    go through ONE kernel launch on the current stream (halo_pack_pick_tables); host tensors (the gloo tests' stand-in
+    drivers) through the equivalent index arithmetic."""
+    b, n = picks.shape[0], picks.shape[1]
+    assert wire_rows.shape == (b, 3 * n + 1) and wire_rows.dtype == torch.int32 and wire_rows.stride(1) == 1
+    if b == 0:
+        return wire_rows
+    if picks.is_cuda:
+        from . import _lib
+        dev = _lib.require_device(picks, n_picked, wire_rows)
+        pk = picks if (picks.dtype == torch.float64 and picks.is_contiguous()) else picks.to(torch.float64).contiguous()
+        npk = n_picked if (n_picked.dtype == torch.int32 and n_picked.is_contiguous()) else n_picked.to(torch.int32).contiguous()
+        rc = _lib.lib().halo_pack_pick_tables(_lib.ptr(pk), _lib.ptr(npk), b, n, _lib.ptr(wire_rows), wire_rows.stride(0),
+                                              _lib.stream_ptr(dev))
+        _lib.check(rc, "halo_pack_pick_tables")
+        return wire_rows
+    pos = ((picks[:, :, 0].to(torch.int64) << 16) | picks[:, :, 1].to(torch.int64)).to(torch.int32)   # sides <= 65535
+    body = wire_rows[:, :3 * n].view(b, n, 3) if wire_rows.is_contiguous() else None
+    if body is None:
+        tmp = torch.zeros((b, 3 * n + 1), dtype=torch.int32)
+        pack_tables_into(tmp, picks, n_picked)
+        wire_rows.copy_(tmp)
+        return wire_rows
+    body[:, :, 0] = pos
+    sc = torch.empty((b, n), dtype=torch.float64).copy_(picks[:, :, 2])         # fresh storage: unit strides whatever the slice's
+    body[:, :, 1:] = sc.view(torch.int32).view(b, n, 2)                          # the score's bits, unchanged
+    wire_rows[:, 3 * n] = n_picked.to(torch.int32)
+    return wire_rows
 
 
 def unpack_tables(wire, n):
@@ -59,7 +86,8 @@ def unpack_tables(wire, n):
     tables = torch.empty((rows, n, 3), dtype=torch.float64, device=wire.device)
     tables[:, :, 0] = (body[:, :, 0] >> 16) & 0xffff
     tables[:, :, 1] = body[:, :, 0] & 0xffff
-    tables[:, :, 2] = body[:, :, 1:].contiguous().view(torch.float64).view(rows, n)
+    sc = torch.empty((rows, n, 2), dtype=torch.int32, device=wire.device).copy_(body[:, :, 1:])
+    tables[:, :, 2] = sc.view(torch.float64).view(rows, n)
     return tables, wire[:, 3 * n].clone()
 
 
@@ -79,11 +107,79 @@ def gather_tables(picks, n_picked, n_images=None, group=None):
     owner = torch.arange(n_images, device=picks.device, dtype=torch.int64).div(max(per, 1), rounding_mode="floor").to(torch.int32)
     if not (dist.is_available() and dist.is_initialized()):
         return picks, n_picked.to(torch.int32), owner
-    wire = pack_tables(picks, n_picked, per)
-    out = torch.empty((world * per, 3 * n + 1), dtype=torch.int32, device=picks.device)
-    dist.all_gather_into_tensor(out, wire, group=group)
-    tables, counts = unpack_tables(out[:n_images], n)       # the padding rows all sit behind the last rank's block
+    tables, counts = gather_wire(pack_tables(picks, n_picked, per), n_images, n, group)
     return tables, counts, owner
+
+
+def gather_wire(wire, n_images, n, group=None):
+    """The round's ONE collective on an already packed block: `wire` (ceil(N/world), 3n+1) int32 holds this rank's rows
+    (pack_tables_into), zero padded.  Returns (tables (N, n, 3) float64, counts (N,) int32) in pool order on every rank.
+    Device tensors go to RCCL as they are; under a host backend (gloo: the CPU tests, and the two-ranks-on-one-GPU
+    hardware test) a device block is staged through the host and the result is returned on the device."""
+    world, _ = _world(group)
+    per = math.ceil(n_images / world)
+    assert wire.shape == (per, 3 * n + 1) and wire.dtype == torch.int32 and wire.is_contiguous()
+    if not (dist.is_available() and dist.is_initialized()):
+        return unpack_tables(wire[:n_images], n)
+    host_backend = wire.is_cuda and dist.get_backend(group) != "nccl"
+    src = wire.cpu() if host_backend else wire
+    out = torch.empty((world * per, 3 * n + 1), dtype=torch.int32, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    if host_backend:
+        out = out.to(wire.device)
+    return unpack_tables(out[:n_images], n)                 # the padding rows all sit behind the last rank's block
+
+
+def reset_round_state(active, selected, active_mask):
+    """The loader's round-1 state (core/datasets/cityscapes.py:245-251) written on the device in one pass:
+    active = selected = False, active_mask = 255.  Contiguous device tensors of one shape, in place."""
+    from . import _lib
+    dev = _lib.require_device(active, selected, active_mask)
+    assert active.dtype == torch.bool and selected.dtype == torch.bool and active_mask.dtype == torch.int64
+    assert active.shape == selected.shape == active_mask.shape
+    assert active.is_contiguous() and selected.is_contiguous() and active_mask.is_contiguous()
+    rc = _lib.lib().halo_reset_round_state(_lib.ptr(active), _lib.ptr(selected), _lib.ptr(active_mask), active.numel(),
+                                           _lib.stream_ptr(dev))
+    _lib.check(rc, "halo_reset_round_state")
+
+
+def undo_picks(picks, n_picked, active_radius, mask_radius, active, selected, active_mask):
+    """Restore the round-1 state of (B,H,W) `active` / `selected` / `active_mask` after a selection that STARTED from it,
+    from that selection's pick table: only the windows select_pixels_to_label wrote (build.py:52-62) are rewritten."""
+    from . import _lib
+    dev = _lib.require_device(picks, n_picked, active, selected, active_mask)
+    B, H, W = active.shape
+    assert picks.dtype == torch.float64 and picks.is_contiguous() and picks.shape[0] == B and picks.shape[2] == 3
+    assert n_picked.dtype == torch.int32 and n_picked.is_contiguous()
+    assert active.dtype == torch.bool and selected.dtype == torch.bool and active_mask.dtype == torch.int64
+    assert active.is_contiguous() and selected.is_contiguous() and active_mask.is_contiguous()
+    rc = _lib.lib().halo_undo_picks(_lib.ptr(picks), _lib.ptr(n_picked), B, H, W, picks.shape[1], int(active_radius),
+                                    int(mask_radius), _lib.ptr(active), _lib.ptr(selected), _lib.ptr(active_mask),
+                                    _lib.stream_ptr(dev))
+    _lib.check(rc, "halo_undo_picks")
+
+
+def device_identity(index):
+    """'pci=<bus id> uuid=<hex>' of HIP device `index` (asked of the HIP runtime the kernels run on)."""
+    import ctypes
+    from . import _lib
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(_lib.lib().halo_device_identity(int(index), buf, 128), "halo_device_identity")
+    return buf.value.decode("ascii", "replace")
+
+
+def assert_distinct_devices(device_index, group=None):
+    """One process per GPU: every rank of `group` (one node) must hold a different physical device.  Exchanges the
+    identity strings with one all_gather_object; raises on a duplicate.  Returns the list (rank order)."""
+    world, rank = _world(group)
+    me = device_identity(device_index)
+    if world == 1:
+        return [me]
+    ids = [None] * world
+    dist.all_gather_object(ids, me, group=group)
+    if len(set(ids)) != world:
+        raise RuntimeError("ranks share a GPU: %s" % ", ".join("rank %d -> %s" % (r, i) for r, i in enumerate(ids)))
+    return ids
 
 
 def global_budget_select(tables, counts, total_regions):

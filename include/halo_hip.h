@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 3
+#define HALO_ABI_VERSION 4
 
 enum { HALO_F32 = 0, HALO_F64 = 1 };
 
@@ -186,6 +186,25 @@ int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, 
                        int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
                        int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                        void *workspace, size_t workspace_bytes, int method, void *stream);
+
+/* ---- pool side of the round: image-wise sharding, ONE all-gather of pick tables (the reference runs the
+ * round on rank 0 only, core/train_learners.py:307-326) ----
+ *  - halo_pack_pick_tables: picks (B,n_regions,3) f64 + n_picked (B) i32 (as halo_greedy_select writes them) -> B rows of
+ *    the int32 wire block of halo_amd/pool.py: per pick (h << 16) | w and the two words of the float64 score, then the
+ *    pick count at word 3*n_regions; wire_row_stride >= 3*n_regions + 1, in int32 elements.
+ *  - halo_reset_round_state: the loader's round-1 state for n_pixels pixels (core/datasets/cityscapes.py:245-251):
+ *    active = selected = False, active_mask = 255.
+ *  - halo_undo_picks: the same state restored after a selection whose state WAS the round-1 state, from its pick
+ *    table: only the windows select_pixels_to_label wrote (build.py:52-62) are rewritten.
+ *  - halo_device_identity: "pci=<bus id> uuid=<32 hex digits>" of a HIP device ordinal, NUL-terminated, len >= 64
+ *    (the ranks of a node must hold distinct devices). */
+int halo_pack_pick_tables(const double *picks, const int32_t *n_picked, int64_t B, int64_t n_regions, int32_t *wire,
+                          int64_t wire_row_stride, void *stream);
+int halo_reset_round_state(uint8_t *active, uint8_t *selected, int64_t *active_mask, int64_t n_pixels, void *stream);
+int halo_undo_picks(const double *picks, const int32_t *n_picked, int64_t B, int64_t H, int64_t W, int64_t n_regions,
+                    int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected, int64_t *active_mask,
+                    void *stream);
+int halo_device_identity(int device, char *buf, size_t len);
 
 /* ---- training-side window losses, float32 tensors, float64 sums on the device ----
  *  - NegativeLearningLoss (core/loss/negative_learning_loss.py:6-16): sums = {sum -mask*log(1-p+1e-6), sum mask},

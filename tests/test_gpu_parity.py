@@ -904,6 +904,39 @@ def test_fused_and_unfused_entropy_paths_agree_bitwise(dev):
             assert bits_equal(x.cpu().numpy(), y.cpu().numpy())
 
 
+def test_fused_tail_equals_the_round2_tail_bitwise(dev):
+    """Round 3: the 3x3 box sum recomputed inside the combine kernel (k_combine_box3, edge taps through lane shifts) and
+    the single finalize launch vs the round-2 sequence k_box3_unc -> 2 x finalize -> k_combine (HALO_NO_FUSE_TAIL=1), and
+    both against the oracle: every branch that box-sums, normalised or not, with and without the prior-pick mask,
+    widths that are and are not multiples of a wave's 256 pixels (rows that start inside a wave), single-row images."""
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(77)
+    for (H, W, C) in ((64, 256, 8), (40, 72, 8), (33, 132, 5), (1, 8, 4), (3, 4, 4), (128, 1024, 4)):
+        for dt in (np.float64, np.float32):
+            logit = rng.standard_normal((2, 19, H, W)).astype(np.float32)
+            emb = (rng.standard_normal((2, C, H, W)) * 0.05).astype(dt)
+            gt = rng.integers(0, 19, (2, H, W)).astype(np.int64)
+            act = rng.random((2, H, W)) < 0.1
+            for unc, pur, norm in (("entropy", "radius", True), ("entropy", "radius", False), ("entropy", "ripu", False),
+                                   ("entropy", "hyper", True), ("oracle_acc", "oracle_ripu", True), ("entropy", "none", True),
+                                   ("entropy", "euc_norm", True)):
+                for a in (None, act):
+                    args = (t(logit, dev), t(emb, dev), unc, pur, norm, t(gt, dev))
+                    kw = dict(size=3, K=7, active=None if a is None else t(a, dev))
+                    new = score_maps(*args, **kw)
+                    old = _with_env({"HALO_NO_FUSE_TAIL": "1"}, lambda: score_maps(*args, **kw))
+                    for x, y in zip(new, old):
+                        assert bits_equal(x.cpu().numpy(), y.cpu().numpy()), (H, W, dt, unc, pur, norm, a is None)
+                    for b in range(2):
+                        so, io, uo = ho.floating_region_score(logit[b:b + 1], emb[b:b + 1], unc, pur, norm, gt[b], size=3,
+                                                              purity_type=pur, K=7)
+                        if a is not None:
+                            so = so.copy(); so[a[b]] = -np.inf
+                        assert bits_equal(new[0][b].cpu().numpy(), so) and bits_equal(new[1][b].cpu().numpy(), io) and \
+                            bits_equal(new[2][b].cpu().numpy(), uo), (H, W, dt, unc, pur, norm, b)
+
+
 def test_region_selection_full_size_real_geometry_vs_oracle(dev):
     """The real pipeline's geometry at full label size: logits 640x1280 and a C=64 float64 embedding at
     160x320 resized to 1024x2048 inside the scorer (never materialised on the device), 2331 regions --
