@@ -70,9 +70,10 @@ def parse():
     ap.add_argument("--source", choices=["fullres", "lowres"], default="fullres",
                     help="fullres = SURVEY 8(d) unit of work (default, the BASELINE metric); lowres = the "
                          "RegionSelection boundary: x4 low-res head outputs, upsampling fused into the scorer (N1)")
-    ap.add_argument("--lr-mode", choices=["exact", "gram"], default="exact",
-                    help="--source lowres only: 'gram' evaluates the embedding's radius through per-cell Gram terms (SURVEY 8f N1; "
-                         "not bit-identical to upsample-then-score)")
+    ap.add_argument("--lr-mode", choices=["gram", "exact"], default="gram",
+                    help="--source lowres only: 'gram' (the product's default for float64 embeddings) evaluates the embedding's radius "
+                         "through per-cell Gram terms (SURVEY 8f N1); 'exact' interpolates every channel (bit-identical to "
+                         "upsample-then-score)")
     ap.add_argument("--cpu-images", type=int, default=8, help="timed images in the CPU-baseline sample, after one "
                                                               "untimed warm-up image (0 = skip)")
     ap.add_argument("--resets", choices=["undo", "kernel", "fills", "side"], default="undo",
@@ -136,7 +137,7 @@ class Pipeline:
     collect in one wire block that is exchanged ONCE, behind the last step."""
 
     def __init__(self, dev, feat, logit, gt, B, n_regions, rows, depth, lowres=False, branch="halo",
-                 resets="undo", sel_priority=-1, lr_mode="exact"):
+                 resets="undo", sel_priority=-1, lr_mode="gram"):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
@@ -165,6 +166,7 @@ class Pipeline:
         self.scored = [torch.cuda.Event() for _ in range(D)]
         self.selected_done = [torch.cuda.Event() for _ in range(D)]
         self.ev = []                       # (start, stop) HIP events around k_feat_reduce
+        self.ev_lr = []                    # low-res source: (logit start, logit stop, embedding start, embedding stop, images)
         self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]
         self.counts = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(D)]
         # this rank's block of the round's wire format (halo_amd/pool.py), padded to ceil(N / world) rows
@@ -217,9 +219,13 @@ class Pipeline:
                 self.s_score.wait_event(self.reset_done[k])
             # all three output maps of FloatingRegionScore.forward are written (floating_region.py:217)
             if self.lowres:
+                lev = None
+                if timed:
+                    lev = tuple(self.lib.halo_event_create() for _ in range(4))
+                    self.ev_lr.append(lev + (b,))
                 sc, self.imp, self.unc_map = score_maps_lowres(lb, fb, self.size, self.unc, self.pur, self.norm, gb, ksize=3,
                                                                K=self.K, c=1.0, active=self.active[k][:b], want_maps=True,
-                                                               mode=self.lr_mode)
+                                                               mode=self.lr_mode, events=lev)
                 self.score[k][:b].copy_(sc)
             else:
                 _, self.imp, self.unc_map = score_maps(lb, fb, self.unc, self.pur, self.norm, gb, size=3, K=self.K, c=1.0,
@@ -292,6 +298,20 @@ class Pipeline:
                     self.ref_tables[lo] = self.tables[k].clone()
             elif not torch.equal(self.ref_tables[lo][:b], self.tables[k][:b]):
                 self.tables_consistent = False
+
+    def lowres_pass_ms(self):
+        """(logit pass ms, embedding pass ms) per full-batch timed step of the low-res source"""
+        import ctypes
+        lo, fe = [], []
+        for e0, e1, e2, e3, nimg in self.ev_lr:
+            a, b = ctypes.c_float(0), ctypes.c_float(0)
+            ok = self.lib.halo_event_elapsed_ms(e0, e1, ctypes.byref(a)) == 0 and self.lib.halo_event_elapsed_ms(e2, e3, ctypes.byref(b)) == 0
+            if ok and nimg == self.B:
+                lo.append(a.value); fe.append(b.value)
+            for e in (e0, e1, e2, e3):
+                self.lib.halo_event_destroy(e)
+        self.ev_lr = []
+        return lo, fe
 
     def feat_kernel_ms(self):
         import ctypes
@@ -498,6 +518,7 @@ def main():
         assert torch.equal(tables[known], ref), "rows gathered from other ranks differ from this rank's results for the same images"
 
     feat_ms = pipe.feat_kernel_ms()
+    lr_logit_ms, lr_feat_ms = pipe.lowres_pass_ms()
     assert pipe.min_picked == n_regions, "selection stopped early"
     assert pipe.tables_consistent, "pick tables of the same images differ between steps (race in the pipeline)"
 
@@ -548,9 +569,33 @@ def main():
             out["roofline"] = None
             if lowres:
                 out["path_algorithmic_GBps"] = None
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        if lowres and lr_feat_ms and uses_feat:
+            # the embedding pass of the low-res boundary: what bounds it depends on the mode
+            h4, w4 = Hh // 4, Ww // 4
+            t_feat, t_logit = float(np.mean(lr_feat_ms)), float(np.mean(lr_logit_ms))
+            if a.lr_mode == "gram" and fdtype == torch.float64:
+                # k_gram_lr + k_radius_gram: the low-res tensor read once, the radius map written (the five Gram maps are
+                # intermediates, 5/C of the tensor, not counted)
+                nbytes = B * (C * h4 * w4 * 8 + Hh * Ww * 8)
+                ach = nbytes / (t_feat * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": "k_gram_lr + k_radius_gram", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": nbytes,
+                                   "avg_launch_ms": round(t_feat, 4), "launches_timed": len(lr_feat_ms)}
+            else:
+                # k_feat_reduce_lr: per output pixel and channel one 4-tap interpolation (1 mul + 3 fma) and one fma into the sum
+                # of squares = 9 flops in 5 VALU slots, in the embedding's dtype; peak = the FP64 / FP32 vector rate (an all-fma
+                # stream; this mix can reach 9/10 of it)
+                flops = 9.0 * B * Hh * Ww * C
+                peak = 78.6 if fdtype == torch.float64 else 157.3
+                ach = flops / (t_feat * 1e-3) / 1e12
+                out["roofline"] = {"bound": "valu", "kernel": "k_feat_reduce_lr", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "traffic": None, "flops_per_launch": flops,
+                                   "avg_launch_ms": round(t_feat, 4), "launches_timed": len(lr_feat_ms),
+                                   "valu_slot_frac": round(ach / peak * 10.0 / 9.0, 4)}
+            out["lowres_passes_ms"] = {"logit_pass(k_logit_maps_lr, f32 VALU-bound)": round(t_logit, 4), "embedding_pass": round(t_feat, 4)}
+        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
-            if out["roofline"] is None or not os.path.exists(pmc):
+            if out["roofline"] is None or lowres or not os.path.exists(pmc):
                 continue
             try:
                 rec = json.load(open(pmc))

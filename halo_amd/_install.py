@@ -72,12 +72,18 @@ class _Alias(importlib.abc.Loader):
 
     def __init__(self, real):
         self.real = real
+        self._spec = None
 
     def create_module(self, spec):
-        return importlib.import_module(self.real)
+        mod = importlib.import_module(self.real)
+        self._spec = getattr(mod, "__spec__", None)
+        return mod
 
     def exec_module(self, module):
-        pass
+        # importlib's module_from_spec has just overwritten the module's __spec__ with the alias' spec: put the real one
+        # back, so that __spec__.parent == __package__ (relative imports executed later inside the module, importlib.reload)
+        if self._spec is not None:
+            module.__spec__ = self._spec
 
 
 class _Wrap(importlib.abc.Loader):

@@ -43,6 +43,8 @@ SIGNATURES = {
     "halo_score_lr_gram_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _i64]),
     "halo_score_maps_lr_gram": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "halo_score_maps_lr_timed": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _int, _vp, _vp, _vp, _vp]),
     "halo_region_uncertainty": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "halo_region_impurity": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp]),
     "halo_quantize_radius": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _sz, _vp]),
@@ -124,7 +126,7 @@ def lib():
                 raise HaloHipError("%s does not export %s" % (path, name))
             fn.restype = res
             fn.argtypes = args
-            setattr(ns, name, _on_stream_device(fn) if res is _int and args and args[-1] is _vp else fn)
+            setattr(ns, name, _on_stream_device(fn) if res is _int and args and _vp in args else fn)
         got = h.halo_version()
         if got != ABI_VERSION:
             raise HaloHipError("%s has ABI version %d, this package binds version %d: rebuild it "

@@ -172,6 +172,24 @@ class _Slot:
 
 
 _SIDE = {}
+_QUEUE_WARNED = False
+
+
+def _check_hw_queues(n_streams):
+    """Warn once when fewer hardware queues than concurrently used streams are configured (see halo_amd/__init__.py)."""
+    global _QUEUE_WARNED
+    if _QUEUE_WARNED:
+        return
+    try:
+        have = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))      # ROCm's default when unset
+    except ValueError:
+        return
+    if have < n_streams + 1:
+        _QUEUE_WARNED = True
+        import warnings
+        warnings.warn("halo_amd RegionSelection drives %d side streams beside the caller's, but GPU_MAX_HW_QUEUES=%d hardware "
+                      "queues are configured: streams sharing a queue serialise.  Export GPU_MAX_HW_QUEUES=8 (or import halo_amd) "
+                      "before the first HIP call (INTEGRATION.md section 3)." % (n_streams, have), RuntimeWarning, stacklevel=3)
 
 
 def _side_streams(dev, n):
@@ -290,9 +308,10 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     for the GPU: a pool of writer threads waits for each image's event, encodes the PNG and writes the
     indicator.  At most `in_flight` images are between "launched" and "copied back to the host" (bounds device
     and pinned memory; each slot owns its pinned staging buffers); `in_flight=0` runs strictly one image at a
-    time like the reference.  `lowres_mode`: 'exact' (default; environment HALO_LOWRES) scores bit-identically to the
-    reference's upsample-then-score, 'gram' evaluates the radius of a float64 embedding through per-cell Gram terms
-    (floating_region.score_maps_lowres) -- same files on every test vector, not bit-identical maps."""
+    time like the reference.  `lowres_mode`: 'gram' (default; environment HALO_LOWRES) evaluates the radius of a float64
+    embedding through per-cell Gram terms (floating_region.score_maps_lowres: bit-identical to its oracle twin, maps within
+    1e-12 of upsample-then-score, the reference's files on every test vector); 'exact' interpolates every channel and is
+    bit-identical to upsample-then-score (the only route for float32 embeddings)."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -300,6 +319,7 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     dev = torch.device("cuda", torch.cuda.current_device())
     depth = max(1, in_flight)
     side = _side_streams(dev, max(1, min(streams, depth)))
+    _check_hw_queues(len(side))
     backlog = threading.Semaphore(depth + 4 * max(1, writer_threads))   # images whose files are not on disk yet (host copies)
     slots = queue.Queue()
     for k in range(depth):

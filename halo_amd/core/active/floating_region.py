@@ -110,23 +110,24 @@ LOWRES_MODES = ("exact", "gram")
 
 
 def lowres_mode(mode=None):
-    """'exact' (default) or 'gram'; None reads HALO_LOWRES from the environment"""
-    mode = os.environ.get("HALO_LOWRES", "exact") if mode is None else mode
+    """'gram' (default) or 'exact'; None reads HALO_LOWRES from the environment"""
+    mode = os.environ.get("HALO_LOWRES", "gram") if mode is None else mode
     if mode not in LOWRES_MODES:
         raise ValueError("low-res mode must be one of %s, got %r" % (LOWRES_MODES, mode))
     return mode
 
 
 def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
-                      ksize=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, mode=None):
+                      ksize=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, mode=None, events=None):
     """FloatingRegionScore.forward on the bilinear (align_corners=True) upsampling of LOW-RES sources to
     `size`, without materialising the upsampled tensors -- core/active/build.py:122-144 in one call.
     logit_lr (B,O,hl,wl) float32, decoder_lr (B,C,hf,wf) float64|float32.
 
-    mode 'exact' (default): bit-identical to bilinear_align_corners(...) followed by score_maps(...).
-    mode 'gram' (float64 embeddings; float32 ones silently take 'exact'): the embedding's radius / norm through the 10
-    inner products of each low-res cell's corner vectors -- the same number rounded differently (the
-    radius map differs by ~1e-15), 3x faster at C = 256; everything else unchanged."""
+    mode 'gram' (default for float64 embeddings; float32 ones take 'exact'): the embedding's radius / norm through the 10
+    inner products of each low-res cell's corner vectors -- bit-identical to the CPU oracle's statement of
+    that form (oracle.halo_oracle.gram_radius), within ~1e-15 of upsample-then-reduce, 3x faster at C = 256.
+    mode 'exact': bit-identical to bilinear_align_corners(...) followed by score_maps(...).  Everything else is the same
+    in both modes.  `events`: four optional handles from halo_event_create recorded around the logit and embedding passes."""
     if pur_type not in _lib.PUR:
         raise NotImplementedError("Error: purity type '{}' not implemented".format(pur_type))
     mode = lowres_mode(mode)
@@ -162,11 +163,16 @@ def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, 
     ws = _workspace(dev, nws, "score")
     psize = ksize if purity_size is None else purity_size
     fn, name = (L.halo_score_maps_lr_gram, "halo_score_maps_lr_gram") if gram else (L.halo_score_maps_lr, "halo_score_maps_lr")
-    rc = fn(_lib.ptr(logit_lr), logit_lr.stride(0), hl, wl, _lib.ptr(feat), fdt, fbs, hf, wf,
+    args = (_lib.ptr(logit_lr), logit_lr.stride(0), hl, wl, _lib.ptr(feat), fdt, fbs, hf, wf,
             _lib.ptr(gt), _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
             _lib.PUR[pur_type], 1 if normalize else 0, int(ksize), int(psize), int(K), float(c),
             _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
             _lib.stream_ptr(dev))
+    if events is not None:      # (logit start, logit stop, embedding start, embedding stop) from halo_event_create, or None each
+        name = "halo_score_maps_lr_timed"
+        rc = L.halo_score_maps_lr_timed(*(args + (1 if gram else 0,) + tuple(events)))
+    else:
+        rc = fn(*args)
     _lib.check(rc, name)
     return score, imp, unc
 
@@ -181,7 +187,12 @@ class FloatingRegionScore(nn.Module):
         self.in_channels = in_channels
         assert size % 2 == 1, "error size"
         if padding_mode != "zeros":
-            raise NotImplementedError("halo_amd FloatingRegionScore implements padding_mode='zeros' only")
+            # the reference forwards padding_mode to its two nn.Conv2d box filters (floating_region.py:49,63), but no caller in
+            # its tree ever passes one (build.py:83-88 and visualize.py:22-34 construct the scorer with the default): the
+            # window kernels here implement the zero padding those callers get
+            raise NotImplementedError("halo_amd FloatingRegionScore implements padding_mode='zeros' only (got %r); the reference "
+                                      "forwards the argument to nn.Conv2d (core/active/floating_region.py:49,63) but none of its "
+                                      "callers passes anything else (core/active/build.py:83-88)" % (padding_mode,))
         if purity_type is None:
             purity_type = cfg.ACTIVE.PURITY
         self.size = size

@@ -261,6 +261,38 @@ class HyperMLR(nn.Module):
         return self._hyper_logits(x)
 
 
+class HyperMetrics(object):
+    """Compute metrics for embeddings in euclidean and hyperbolic space (hyperbolic.py:191-228; no caller in the
+    reference tree -- kept so that `from core.utils.hyperbolic import HyperMetrics` keeps working after install()).
+
+    Args:
+        c (float, optional): Hyperbolic curvature. Defaults to 1.0
+
+    The exponential maps and the Poincare distance run on the HIP kernels behind HyperMapper; the remaining
+    element-wise glue (mse, norms, acos) is device-side torch arithmetic on the (N, d) inputs."""
+
+    def __init__(self, c=1.) -> None:
+        self.c = c
+        self.mapper = HyperMapper(c=self.c)
+
+    def compute(self, x, y):
+        _lib.require_device(x, y)
+        metrics = {}
+        metrics['mse'] = torch.nn.functional.mse_loss(x, y)
+        metrics['cosine_dist'] = self.mapper.cosine_distance(x, y)
+        x_h = self.mapper.expmap(x)
+        y_h = self.mapper.expmap(y)
+        radius_x = torch.linalg.norm(x_h, dim=-1)
+        radius_y = torch.linalg.norm(y_h, dim=-1)
+        metrics['radius_x'] = radius_x
+        metrics['radius_y'] = radius_y
+        x_norm_e = x_h / radius_x.reshape(-1, 1)
+        y_norm_e = y_h / radius_y.reshape(-1, 1)
+        metrics['ang_e'] = torch.acos((x_norm_e * y_norm_e).sum(dim=-1)) * 180 / math.pi
+        metrics['poincare_dist'] = self.mapper.poincare_distance(x_h, y_h)
+        return metrics
+
+
 def bilinear_align_corners(x, size):
     """F.interpolate(x, size, mode='bilinear', align_corners=True) for float32/float64 NCHW
     (core/active/build.py:123-125,133-135; classifier.py:375-377,556-557)."""

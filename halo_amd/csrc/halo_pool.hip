@@ -55,28 +55,32 @@ __global__ void __launch_bounds__(256) k_reset_state_bytes(unsigned char *__rest
     if (i < n) { active[i] = 0; selected[i] = 0; amask[i] = 255; }
 }
 
-// one wave per pick: the windows select_pixels_to_label wrote (build.py:52-62) go back to the round-1 state
+// a wave per pick (a few fat workgroups per image, their waves striding over the picks: small workgroups wait to be
+// placed beside the streaming kernel): the windows select_pixels_to_label wrote (build.py:52-62) go back to the round-1 state
+constexpr int UNDO_WGS = 32;
 __global__ void __launch_bounds__(256) k_undo_picks(const double *__restrict__ picks, const int *__restrict__ n_picked, int n, int H, int W,
                                                     int arad, int mrad, unsigned char *__restrict__ active,
                                                     unsigned char *__restrict__ selected, long long *__restrict__ amask)
 {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= n || i >= n_picked[b]) return;
-    const double *p = picks + ((size_t)b * n + i) * 3;
-    const int h = (int)p[0], w = (int)p[1];
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int np = n_picked[b] < n ? n_picked[b] : n;
     const size_t base = (size_t)b * H * W;
-    const int my0 = h - mrad < 0 ? 0 : h - mrad, my1 = h + mrad >= H ? H - 1 : h + mrad;
-    const int mx0 = w - mrad < 0 ? 0 : w - mrad, mx1 = w + mrad >= W ? W - 1 : w + mrad;
-    const int mw = mx1 - mx0 + 1, mn = mw * (my1 - my0 + 1);
-    for (int e = lane; e < mn; e += 64) active[base + (size_t)(my0 + e / mw) * W + mx0 + e % mw] = 0;
-    const int ay0 = h - arad < 0 ? 0 : h - arad, ay1 = h + arad >= H ? H - 1 : h + arad;
-    const int ax0 = w - arad < 0 ? 0 : w - arad, ax1 = w + arad >= W ? W - 1 : w + arad;
-    const int aw = ax1 - ax0 + 1, an = aw * (ay1 - ay0 + 1);
-    for (int e = lane; e < an; e += 64) {
-        const size_t o = base + (size_t)(ay0 + e / aw) * W + ax0 + e % aw;
-        selected[o] = 0;
-        amask[o] = 255;
+    const int nwaves = gridDim.x * 4;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < np; i += nwaves) {
+        const double *p = picks + ((size_t)b * n + i) * 3;
+        const int h = (int)p[0], w = (int)p[1];
+        const int my0 = h - mrad < 0 ? 0 : h - mrad, my1 = h + mrad >= H ? H - 1 : h + mrad;
+        const int mx0 = w - mrad < 0 ? 0 : w - mrad, mx1 = w + mrad >= W ? W - 1 : w + mrad;
+        const int mw = mx1 - mx0 + 1, mn = mw * (my1 - my0 + 1);
+        for (int e = lane; e < mn; e += 64) active[base + (size_t)(my0 + e / mw) * W + mx0 + e % mw] = 0;
+        const int ay0 = h - arad < 0 ? 0 : h - arad, ay1 = h + arad >= H ? H - 1 : h + arad;
+        const int ax0 = w - arad < 0 ? 0 : w - arad, ax1 = w + arad >= W ? W - 1 : w + arad;
+        const int aw = ax1 - ax0 + 1, an = aw * (ay1 - ay0 + 1);
+        for (int e = lane; e < an; e += 64) {
+            const size_t o = base + (size_t)(ay0 + e / aw) * W + ax0 + e % aw;
+            selected[o] = 0;
+            amask[o] = 255;
+        }
     }
 }
 
@@ -117,7 +121,7 @@ extern "C" int halo_undo_picks(const double *picks, const int32_t *n_picked, int
     if (!picks || !n_picked || !active || !selected || !active_mask || B < 0 || B > 65535 || H <= 0 || W <= 0 || n_regions < 0 ||
         active_radius < 0 || mask_radius < 0)
         return fail(HALO_E_ARG, "halo_undo_picks: bad argument");
-    hipLaunchKernelGGL(k_undo_picks, dim3((unsigned)cdiv(n_regions, 4), (unsigned)B), dim3(256), 0, (hipStream_t)stream, picks,
+    hipLaunchKernelGGL(k_undo_picks, dim3((unsigned)(cdiv(n_regions, 4) < UNDO_WGS ? cdiv(n_regions, 4) : UNDO_WGS), (unsigned)B), dim3(256), 0, (hipStream_t)stream, picks,
                        (const int *)n_picked, (int)n_regions, (int)H, (int)W, (int)active_radius, (int)mask_radius, active, selected,
                        (long long *)active_mask);
     return check_launch("halo_undo_picks");

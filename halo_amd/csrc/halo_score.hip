@@ -1439,7 +1439,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
                       int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
                       int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                       void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
-                      void *ev_feat_stop, const LrDims *lr)
+                      void *ev_feat_stop, const LrDims *lr, void *ev_logit_start = nullptr, void *ev_logit_stop = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
@@ -1491,6 +1491,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     const FusedLogit *flp = fuse ? &fl : nullptr;
     const bool need_logit_pass = !fuse && ( unc_type != HALO_UNC_ZEROS || pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU);
     short *pred_from_logits = (pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU) ? pred : nullptr;
+    if (ev_logit_start) (void)hipEventRecord((hipEvent_t)ev_logit_start, st);
     if (need_logit_pass && lr) {
         const float shl = H > 1 ? (float)(lr->hl - 1) / (float)(H - 1) : 0.0f, swl = W > 1 ? (float)(lr->wl - 1) / (float)(W - 1) : 0.0f;
         dim3 grid((unsigned)nblk1, (unsigned)B);
@@ -1517,6 +1518,8 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     } else if (!fuse) {
         hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(B * hw, TPB)), block, 0, st, ent, (long long)(B * hw), 0.0f);
     }
+
+    if (ev_logit_stop) (void)hipEventRecord((hipEvent_t)ev_logit_stop, st);
 
     // ---- features -> radius / norm  (+ min/max partials)
     int nblk_imp = nblk1;
@@ -1716,4 +1719,25 @@ extern "C" int halo_score_maps_lr_gram(const float *logit_lr, int64_t logit_bstr
     return score_impl(logit_lr, logit_bstride, feat_lr, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
                       normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream, nullptr,
                       nullptr, &lr);
+}
+
+// halo_score_maps_lr (gram = 0) / halo_score_maps_lr_gram (gram = 1) with optional hipEvent_t pairs (halo_event_create) recorded on
+// `stream` around the logit pass (k_logit_maps_lr) and around the embedding pass (k_feat_reduce_lr, or k_gram_lr + k_radius_gram)
+// -- bench.py's live kernel times for the low-resolution boundary.
+extern "C" int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bstride, int64_t hl, int64_t wl, const void *feat_lr,
+                                        int feat_dtype, int64_t feat_bstride, int64_t hf, int64_t wf, const int64_t *gt,
+                                        const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
+                                        int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
+                                        void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream,
+                                        int gram, void *ev_logit_start, void *ev_logit_stop, void *ev_feat_start, void *ev_feat_stop)
+{
+    if (hl <= 0 || wl <= 0) return fail(HALO_E_ARG, "halo_score_maps_lr_timed: bad low-res logit size");
+    const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
+    if (need_feat && (hf <= 0 || wf <= 0)) return fail(HALO_E_ARG, "halo_score_maps_lr_timed: bad low-res embedding size");
+    if (gram && need_feat && workspace_bytes < halo_score_lr_gram_workspace_bytes(B, O, H, W, hf, wf))
+        return fail(HALO_E_WORKSPACE, "halo_score_maps_lr_timed: workspace too small");
+    LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf, gram != 0};
+    return score_impl(logit_lr, logit_bstride, feat_lr, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
+                      normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream, ev_feat_start,
+                      ev_feat_stop, &lr, ev_logit_start, ev_logit_stop);
 }

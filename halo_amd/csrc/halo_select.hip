@@ -345,11 +345,14 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
 
     // ---- serial tile-table kernel: the whole job, or only the images the sweep handed over
     const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * (SEL_TPB_MAIN / 64) * 12 + 64;
-    // behind the sweep: two workgroups walk the images (see the kernel); HALO_SEL_RESUME_WGS overrides (tuning aid)
+    // behind the sweep: a few workgroups walk the images (see the kernel), skipping the finished ones; HALO_SEL_RESUME_WGS
+    // overrides (tuning aid).  Eight: the 256-thread, 96-VGPR resume kernel fits beside the streaming kernel on any CU, so
+    // they are placed at once, and a degenerate round in which the sweep hands over EVERY image (NaN / +inf / constant maps,
+    // plateaus of ties) is continued eight images at a time instead of two.
     unsigned nwg = (unsigned)B;
     if (resume) {
         static const int wgs_env = [] { const char *e = getenv("HALO_SEL_RESUME_WGS"); return e ? atoi(e) : 0; }();
-        const unsigned want = wgs_env > 0 ? (unsigned)wgs_env : 2u;
+        const unsigned want = wgs_env > 0 ? (unsigned)wgs_env : 8u;
         nwg = want < (unsigned)B ? want : (unsigned)B;
     }
     dim3 grid(nwg);

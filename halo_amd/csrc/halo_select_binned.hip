@@ -643,48 +643,56 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
 // ------------------------------------------------------------------ windows of the picks
 // build.py:45-62 for every pick at once: all four writes store constants (or ground_truth of the
 // same pixel), so the order between picks does not matter.
+// A few fat workgroups per image whose waves stride over the picks, not one small workgroup per four picks: beside the
+// streaming feature kernel every workgroup waits to be PLACED (9 328 of them took 0.70 ms for 6 us of work in the
+// round-3 bench trace); APPLY_WGS x 4 waves per image keep the same stores in flight with 18 picks per wave.
+constexpr int APPLY_WGS = 32;
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_sel_apply(T *__restrict__ score, unsigned char *__restrict__ active,
                                                    unsigned char *__restrict__ selected, long long *__restrict__ active_mask,
                                                    const long long *__restrict__ gt, double *__restrict__ picks, BinWs ws, BinGeom g)
 {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= ws.hdr[b].np) return;
-    const unsigned pos = ws.plist[(size_t)b * g.n_regions + p];
-    const int w = (int)(pos >> 16), h = (int)(pos & 0xffffu);
+    const int np = ws.hdr[b].np;
     const size_t hw = (size_t)g.H * g.W;
     T *sc = score + (size_t)b * hw;
-    // (h, w, value) row of the pick table.  The value is read BEFORE this wave writes its window: no other pick's window
-    // covers this pixel (picks are more than mask_radius apart), so it still holds the original score
-    if (picks) {
-        const double v = key_value(order_key((double)sc[(size_t)h * g.W + w]));      // -0 -> +0, as the serial kernel reports it
-        if (lane == 0) {
-            double *pk = picks + ((size_t)b * g.n_regions + p) * 3;
-            pk[0] = (double)h;
-            pk[1] = (double)w;
-            pk[2] = v;
-        }
-    }
     unsigned char *act = active + (size_t)b * hw, *sel = selected + (size_t)b * hw;
     long long *am = active_mask + (size_t)b * hw;
     const long long *gtb = gt + (size_t)b * hw;
     const T neg_inf = sizeof(T) == 8 ? (T)__longlong_as_double(0xfff0000000000000ll) : (T)__uint_as_float(0xff800000u);
-    const int my0 = h - g.mrad < 0 ? 0 : h - g.mrad, my1 = h + g.mrad >= g.H ? g.H - 1 : h + g.mrad;
-    const int mx0 = w - g.mrad < 0 ? 0 : w - g.mrad, mx1 = w + g.mrad >= g.W ? g.W - 1 : w + g.mrad;
-    const int ay0 = h - g.arad < 0 ? 0 : h - g.arad, ay1 = h + g.arad >= g.H ? g.H - 1 : h + g.arad;
-    const int ax0 = w - g.arad < 0 ? 0 : w - g.arad, ax1 = w + g.arad >= g.W ? g.W - 1 : w + g.arad;
-    const int aw = ax1 - ax0 + 1, an = aw * (ay1 - ay0 + 1);
-    const int mw = mx1 - mx0 + 1, mn = mw * (my1 - my0 + 1);
-    for (int e = lane; e < an; e += 64) {                       // selected[...] = True; active_mask[...] = ground_truth[...]
-        const size_t o = (size_t)(ay0 + e / aw) * g.W + (ax0 + e % aw);
-        sel[o] = 1;
-        am[o] = gtb[o];
-    }
-    for (int e = lane; e < mn; e += 64) {                       // score[...] = -inf; active[...] = True
-        const size_t o = (size_t)(my0 + e / mw) * g.W + (mx0 + e % mw);
-        sc[o] = neg_inf;
-        act[o] = 1;
+    const unsigned *plist = ws.plist + (size_t)b * g.n_regions;
+    const int nwaves = gridDim.x * 4;
+    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < np; p += nwaves) {
+        const unsigned pos = plist[p];
+        const int w = (int)(pos >> 16), h = (int)(pos & 0xffffu);
+        // (h, w, value) row of the pick table.  The value is read BEFORE this wave writes its window: no other pick's window
+        // covers this pixel (picks are more than mask_radius apart), so it still holds the original score
+        if (picks) {
+            const double v = key_value(order_key((double)sc[(size_t)h * g.W + w]));      // -0 -> +0, as the serial kernel reports it
+            if (lane == 0) {
+                double *pk = picks + ((size_t)b * g.n_regions + p) * 3;
+                pk[0] = (double)h;
+                pk[1] = (double)w;
+                pk[2] = v;
+            }
+        }
+        const int my0 = h - g.mrad < 0 ? 0 : h - g.mrad, my1 = h + g.mrad >= g.H ? g.H - 1 : h + g.mrad;
+        const int mx0 = w - g.mrad < 0 ? 0 : w - g.mrad, mx1 = w + g.mrad >= g.W ? g.W - 1 : w + g.mrad;
+        const int ay0 = h - g.arad < 0 ? 0 : h - g.arad, ay1 = h + g.arad >= g.H ? g.H - 1 : h + g.arad;
+        const int ax0 = w - g.arad < 0 ? 0 : w - g.arad, ax1 = w + g.arad >= g.W ? g.W - 1 : w + g.arad;
+        const int aw = ax1 - ax0 + 1, an = aw * (ay1 - ay0 + 1);
+        const int mw = mx1 - mx0 + 1, mn = mw * (my1 - my0 + 1);
+        for (int e = lane; e < an; e += 64) {                       // selected[...] = True; active_mask[...] = ground_truth[...]
+            const size_t o = (size_t)(ay0 + e / aw) * g.W + (ax0 + e % aw);
+            sel[o] = 1;
+            am[o] = gtb[o];
+        }
+        for (int e = lane; e < mn; e += 64) {                       // score[...] = -inf; active[...] = True
+            const size_t o = (size_t)(my0 + e / mw) * g.W + (mx0 + e % mw);
+            sc[o] = neg_inf;
+            act[o] = 1;
+        }
     }
 }
 
@@ -788,7 +796,7 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     if (!raise_lds_limit(seen, (const void *)k_sel_sweep, 160 * 1024))
         return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(k_sel_sweep, dim3((unsigned)B), dim3(SW_TPB), p.lds_bytes, st, ws, g, n_picked);
-    const dim3 ga((unsigned)cdiv(g.n_regions, 4), (unsigned)B);
+    const dim3 ga((unsigned)(cdiv(g.n_regions, 4) < APPLY_WGS ? cdiv(g.n_regions, 4) : APPLY_WGS), (unsigned)B);
     if (dtype == HALO_F64)
         hipLaunchKernelGGL(k_sel_apply<double>, ga, blk, 0, st, (double *)score, active, selected, (long long *)active_mask, (const long long *)gt, picks, ws, g);
     else

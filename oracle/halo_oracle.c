@@ -300,6 +300,75 @@ void halo_o_bilinear_f32(const float *src, float *dst, i64 planes, i64 h, i64 w,
 }
 
 /* ------------------------------------------------------------------------- *
+ * Gram form of the radius / norm of a bilinearly upsampled float64 embedding (the
+ * reference computes it by upsampling, core/active/build.py:133-135, then reducing,
+ * core/utils/hyperbolic.py:74-83).  NOT the reference's evaluation order: the upsampled vector of an
+ * output pixel is sum_i w_i v_i over the four corner vectors of its low-res cell, hence
+ *     ||.||^2 = sum_{i<=j} (2 - [i==j]) w_i w_j <v_i, v_j> .
+ * This function restates, operation for operation, what the HIP pair k_gram_lr + k_radius_gram
+ * (halo_amd/csrc/halo_score.hip) computes, so that the product's 'gram' mode has a bit-exact CPU
+ * twin like the 'exact' mode has: five maps over the low-res grid
+ *     S = <v,v>  Hh = <v(y,x), v(y,n(x))>  Vv = <v(y,x), v(n(y),x)>  D1 = <v(y,x), v(n(y),n(x))>
+ *     D2 = <v(y,n(x)), v(n(y),x)>          (n(.) = neighbour clamped to the grid = the tap i1)
+ * as sequential fma chains over the channels from +0, then per output pixel the 10-term fma chain over
+ * the corner pairs (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3) with coefficient w_a*w_b, doubled
+ * by one addition when a != b; a negative rounding residue is clamped to zero.
+ * feat (C,h,w) f64 -> out (H,W) f64; mode 0: dist0 (radius), 1: sqrt (norm).
+ * ------------------------------------------------------------------------- */
+void halo_o_gram_radius(const double *feat, i64 C, i64 h, i64 w, i64 H, i64 W, int mode, double c, double *out)
+{
+    const i64 hwl = h * w;
+    double *gram = (double *)malloc(sizeof(double) * 5 * (size_t)hwl);
+    double *S = gram, *Hh = S + hwl, *Vv = Hh + hwl, *D1 = Vv + hwl, *D2 = D1 + hwl;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 y = 0; y < h; ++y)
+        for (i64 x = 0; x < w; ++x) {
+            const i64 ny = y + 1 < h - 1 ? y + 1 : h - 1, nx = x + 1 < w - 1 ? x + 1 : w - 1;
+            double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0, g4 = 0.0;
+            for (i64 ch = 0; ch < C; ++ch) {
+                const double *pl = feat + ch * hwl;
+                const double v0 = pl[y * w + x], r0 = pl[y * w + nx], v1 = pl[ny * w + x], r1 = pl[ny * w + nx];
+                g0 = fma(v0, v0, g0);
+                g1 = fma(v0, r0, g1);
+                g2 = fma(v0, v1, g2);
+                g3 = fma(v0, r1, g3);
+                g4 = fma(r0, v1, g4);
+            }
+            S[y * w + x] = g0; Hh[y * w + x] = g1; Vv[y * w + x] = g2; D1[y * w + x] = g3; D2[y * w + x] = g4;
+        }
+    const double ks = k_sqrt(c), rks = 1.0 / ks;
+    const double sh = H > 1 ? (double)(h - 1) / (double)(H - 1) : 0.0;
+    const double sw = W > 1 ? (double)(w - 1) / (double)(W - 1) : 0.0;
+#pragma omp parallel for schedule(static)
+    for (i64 y = 0; y < H; ++y) {
+        const double fy = sh * (double)y;
+        i64 y0 = (i64)fy; if (y0 > h - 1) y0 = h - 1;
+        const i64 y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const double ly1 = fy - (double)y0, ly0 = 1.0 - ly1;
+        for (i64 x = 0; x < W; ++x) {
+            const double fx = sw * (double)x;
+            i64 x0 = (i64)fx; if (x0 > w - 1) x0 = w - 1;
+            const i64 x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const double lx1 = fx - (double)x0, lx0 = 1.0 - lx1;
+            const double wt[4] = {ly0 * lx0, ly0 * lx1, ly1 * lx0, ly1 * lx1};
+            const i64 c00 = y0 * w + x0, c01 = y0 * w + x1, c10 = y1 * w + x0, c11 = y1 * w + x1;
+            const double G[10] = {S[c00], Hh[c00], Vv[c00], D1[c00], S[c01], D2[c00], Vv[c01], S[c10], Hh[c10], S[c11]};
+            double s = 0.0;
+            int k = 0;
+            for (int a = 0; a < 4; ++a)
+                for (int b = a; b < 4; ++b, ++k) {
+                    double coef = wt[a] * wt[b];
+                    if (b != a) coef = coef + coef;
+                    s = fma(coef, G[k], s);
+                }
+            s = s < 0.0 ? 0.0 : s;                      /* NaN stays NaN */
+            out[y * W + x] = mode == 0 ? dist0_from_ssq_f64(s, ks, rks) : sqrt(s);
+        }
+    }
+    free(gram);
+}
+
+/* ------------------------------------------------------------------------- *
  * FloatingRegionScore.forward (core/active/floating_region.py:129-217)
  * ------------------------------------------------------------------------- */
 
@@ -420,7 +489,9 @@ static void quantize_f32(float *r, i64 n, i64 K, i64 *pred)
     }
 }
 
-/* The whole forward.  Outputs: score / impurity in f64 when (pur is RADIUS|EUC_NORM and
+/* The whole forward.  C == 0 with feat != NULL: `feat` is the (H,W) float64 map of per-pixel radii (pur RADIUS / HYPER) or
+ * norms (EUC_NORM) itself, e.g. from halo_o_gram_radius, instead of the embedding it would be reduced from.
+ * Outputs: score / impurity in f64 when (pur is RADIUS|EUC_NORM and
  * feat is f64), else f32 -- the caller passes buffers of the right width and reads
  * *score_dtype.  unc_out is always f32.  ksize = entropy conv size; pksize = purity conv
  * size (3 when the module was built for 'hyper', floating_region.py:54-55).
@@ -470,7 +541,7 @@ int halo_o_floating_region_score(const float *logit, const void *feat, int feat_
         if (feat_dtype == HALO_F64) {
             double *r = (double *)malloc(sizeof(double) * hw);
 #pragma omp parallel for schedule(static)
-            for (i64 i = 0; i < hw; ++i) r[i] = dist0_from_ssq_f64(ssq_f64((const double *)feat + i, C, hw), ks, rks);
+            for (i64 i = 0; i < hw; ++i) r[i] = C == 0 ? ((const double *)feat)[i] : dist0_from_ssq_f64(ssq_f64((const double *)feat + i, C, hw), ks, rks);
             quantize_f64(r, hw, K, pred);
             free(r);
         } else {
@@ -486,6 +557,7 @@ int halo_o_floating_region_score(const float *logit, const void *feat, int feat_
         for (i64 i = 0; i < hw; ++i) {
             cnt[i] = 1.0f;
             if (pur_type == HALO_PUR_NONE) imp32[i] = 0.0f;
+            else if (feat_dtype == HALO_F64 && C == 0) imp64[i] = ((const double *)feat)[i];
             else if (feat_dtype == HALO_F64) {
                 double s = ssq_f64((const double *)feat + i, C, hw);
                 imp64[i] = pur_type == HALO_PUR_RADIUS ? dist0_from_ssq_f64(s, ks, rks) : sqrt(s);

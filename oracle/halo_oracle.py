@@ -155,9 +155,24 @@ def bilinear(x, size):
     return out
 
 
+def gram_radius(feat_lr, size, mode="radius", c=1.0):
+    """Per-pixel radius ('radius') or norm ('euc_norm') of the bilinear upsampling of a float64 low-res embedding
+    (C,h,w) to `size`, evaluated through the Gram form -- the CPU twin of the product's 'gram' low-res mode
+    (halo_o_gram_radius)."""
+    f = np.ascontiguousarray(feat_lr, dtype=np.float64)
+    if f.ndim == 4:
+        f = f[0]
+    Cc, h, w = f.shape
+    H, W = int(size[0]), int(size[1])
+    out = np.empty((H, W), np.float64)
+    lib().halo_o_gram_radius(_p(f), _i64(Cc), _i64(h), _i64(w), _i64(H), _i64(W), _int(0 if mode == "radius" else 1), _dbl(c), _p(out))
+    return out
+
+
 def floating_region_score(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=False,
-                          ground_truth=None, size=3, purity_type=None, K=100, c=1.0):
-    """FloatingRegionScore(in_channels=O, size=size, purity_type=purity_type, K=K)(logit, ...)."""
+                          ground_truth=None, size=3, purity_type=None, K=100, c=1.0, impurity_raw=None):
+    """FloatingRegionScore(in_channels=O, size=size, purity_type=purity_type, K=K)(logit, ...).
+    impurity_raw: (H,W) float64 map of per-pixel radii / norms to use INSTEAD of reducing decoder_out (gram_radius)."""
     logit = np.ascontiguousarray(logit, dtype=np.float32)
     if logit.ndim == 4:
         logit = logit[0]
@@ -167,7 +182,11 @@ def floating_region_score(logit, decoder_out=None, unc_type=None, pur_type=None,
     feat = None
     Cc = 0
     fdt = F64
-    if pur_type in ("hyper", "radius", "euc_norm"):
+    if pur_type in ("hyper", "radius", "euc_norm") and impurity_raw is not None:
+        feat = np.ascontiguousarray(impurity_raw, dtype=np.float64)
+        assert feat.shape == (H, W)
+        Cc, fdt = 0, F64
+    elif pur_type in ("hyper", "radius", "euc_norm"):
         feat = np.ascontiguousarray(decoder_out)
         if feat.ndim == 4:
             feat = feat[0]
@@ -246,11 +265,12 @@ def select_pixels_to_label(score, active_regions, active_radius, mask_radius, ac
     return score, active, selected, active_mask
 
 
-def region_selection(cfg, images, c=None):
+def region_selection(cfg, images, c=None, lowres_mode="exact"):
     """RegionSelection's per-image body (build.py:113-166) on pre-computed low-res head
     outputs.  `images`: list of dicts with logit_lr (1,O,h,w) f32, embed_lr (1,C,h,w) f64,
     origin_mask, origin_label (H,W) i64, active, selected (H,W) bool.  Returns a list of
-    (active_mask uint8, active, selected, picks)."""
+    (active_mask uint8, active, selected, picks).  lowres_mode 'gram': the radius / norm of a float64
+    embedding through gram_radius (the product's 'gram' mode) instead of upsample-then-reduce."""
     per_region = (2 * cfg.ACTIVE.RADIUS_K + 1) ** 2
     budget = cfg.ACTIVE.BUDGET / len(cfg.ACTIVE.SELECT_ITER)
     unc, pur = cfg.ACTIVE.UNCERTAINTY, cfg.ACTIVE.PURITY
@@ -260,13 +280,16 @@ def region_selection(cfg, images, c=None):
         H, W = im["origin_label"].shape
         logit = bilinear(im["logit_lr"], (H, W))
         dec = im["embed_lr"]
-        if unc in ("certainty", "hyperbolic") or pur in ("hyper", "radius", "euc_norm") or \
+        raw = None
+        if lowres_mode == "gram" and pur in ("hyper", "radius", "euc_norm") and np.asarray(dec).dtype == np.float64:
+            raw = gram_radius(dec, (H, W), "euc_norm" if pur == "euc_norm" else "radius", c)
+        elif unc in ("certainty", "hyperbolic") or pur in ("hyper", "radius", "euc_norm") or \
                 (unc == "none" and cfg.MODEL.HYPER):
             dec = bilinear(dec, (H, W))
         score, _, _ = floating_region_score(
             logit, decoder_out=dec, unc_type=unc, pur_type=pur, normalize=cfg.ACTIVE.NORMALIZE,
             ground_truth=im["origin_label"], size=2 * cfg.ACTIVE.RADIUS_K + 1, purity_type=pur,
-            K=cfg.ACTIVE.K, c=c)
+            K=cfg.ACTIVE.K, c=c, impurity_raw=raw)
         active = im["active"].copy()
         selected = im["selected"].copy()
         amask = im["origin_mask"].copy()

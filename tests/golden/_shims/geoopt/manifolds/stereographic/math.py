@@ -23,6 +23,12 @@ geoopt layer of the fixtures is "parity unpinned" (see DESIGN.md); the
 closed-form known-answer tests in tests/test_oracle_kat.py pin that layer
 independently with mpmath.
 
+Open doubt: ``artanh`` below evaluates its two logarithms in float64 and casts back -- the
+form of geoopt's older ``poincare/math.py`` ``Artanh`` function; ``stereographic/math.py`` may compute
+``0.5 * (log1p(z) - log1p(-z))`` in the INPUT dtype.  For float64 inputs (the reference's HYPER=True path) the two are
+one; for float32 inputs they differ by at most ~3 float32 ulp.  tests/test_oracle_kat.py evaluates dist0 both
+ways in torch and holds the oracle / HIP result within 2e-6 relative of BOTH, so the 1e-4 bar holds whichever it is.
+
 Only the k < 0 (Poincare ball) branch is needed: HyperMapper always passes
 ``k = tensor(-c)`` with c > 0 (hyperbolic.py:26).
 """

@@ -32,6 +32,7 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("HALO_REFERENCE", "/root/reference")
+OUT_DIR = os.environ.get("HALO_FIXTURE_OUT", HERE)      # tests/test_fixtures_reproduce.py regenerates into a temp dir
 
 
 def import_reference():
@@ -190,7 +191,7 @@ def gen_case(cfg, hyp, fr, ab, name, H, W, C, O, seed, n_regions, combos, f32_em
         out[f"{tag}__min_rel_gap"] = np.array([gaps[tag]], dtype=np.float64)
         print(f"  {name}/{tag}: score {score.dtype} picks r1={len(picks1)} r2={len(picks2)} "
               f"min_rel_gap={gaps[tag]:.3e}")
-    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, f"{name}.npz"), **out)
 
 
 def gen_hypermapper(hyp):
@@ -213,7 +214,17 @@ def gen_hypermapper(hyp):
         out[f"{tag}__dist"] = m.poincare_distance(xh, yh).numpy()
         out[f"{tag}__expmap2"] = m.expmap2(x.double()).numpy()
         out[f"{tag}__cosine"] = m.cosine_distance(x[6:], yh[6:].float()).numpy()
-    np.savez_compressed(os.path.join(HERE, "hypermapper.npz"), **out)
+    # HyperMetrics.compute (hyperbolic.py:191-228; no caller in-tree) -- its own generator, so the arrays above keep their bits
+    g2 = torch.Generator().manual_seed(100)
+    for c in (1.0, 0.5):
+        hm = hyp.HyperMetrics(c=c)
+        a = torch.randn(23, 10, generator=g2, dtype=torch.float32) * 0.5
+        b = torch.randn(23, 10, generator=g2, dtype=torch.float32) * 0.5
+        met = hm.compute(a, b)
+        out[f"hm_c{c}__x"], out[f"hm_c{c}__y"] = a.numpy(), b.numpy()
+        for key, val in met.items():
+            out[f"hm_c{c}__{key}"] = val.numpy()
+    np.savez_compressed(os.path.join(OUT_DIR, "hypermapper.npz"), **out)
 
 
 def gen_helpers(cfg, hyp, fr):
@@ -242,7 +253,7 @@ def gen_helpers(cfg, hyp, fr):
         am = torch.argmax(p, dim=0)
         imp, cnt = f_rip.compute_region_impurity(am, O)
         out["argmax"] = am.numpy(); out["imp_ripu_k5"] = imp.numpy(); out["cnt_ripu_k5"] = cnt.numpy()
-    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "helpers.npz"), **out)
 
 
 def gen_grads(hyp):
@@ -275,7 +286,7 @@ def gen_grads(hyp):
                     f"{tag}__g_z": z.grad.numpy(), f"{tag}__g_embed": embed.grad.numpy(),
                     f"{tag}__g_P": mlr.P_MLR.grad.numpy(), f"{tag}__g_A": mlr.A_MLR.grad.numpy()})
         print(f"  grads {tag}: |g_z| max {float(z.grad.abs().max()):.3e}, nan {bool(torch.isnan(z.grad).any())}")
-    np.savez_compressed(os.path.join(HERE, "grads.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "grads.npz"), **out)
 
 
 def gen_losses():
@@ -313,7 +324,7 @@ def gen_losses():
     (g0,) = torch.autograd.grad(l0, x0, allow_unused=True)
     out["empty__x"] = x0.detach().numpy(); out["empty__loss_isnan"] = np.array([bool(torch.isnan(l0))])
     out["empty__gx"] = (g0 if g0 is not None else torch.zeros_like(x0)).numpy()
-    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "losses.npz"), **out)
 
 
 class _FakeExtractor(torch.nn.Module):
@@ -392,7 +403,7 @@ def gen_region_selection(cfg, hyp, fr, ab):
                 Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8)
         print(f"  region_selection round {rnd}: selected px img0 = "
               f"{int(out[f'r{rnd}_img0__selected'].sum())}")
-    np.savez_compressed(os.path.join(HERE, "region_selection.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "region_selection.npz"), **out)
 
 
 def main():

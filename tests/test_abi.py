@@ -86,6 +86,9 @@ def test_reference_error_behaviour():
     with pytest.raises(NotImplementedError, match="purity type 'bogus' not implemented"):   # :199-202
         frs(torch.zeros(1, 19, 4, 4), unc_type="entropy", pur_type="bogus")
     assert FloatingRegionScore(size=5, purity_type="hyper", K=7).purity_size == 3           # :54-55
+    # a padding mode no caller of the reference passes: refused with the reason, not silently zero-padded
+    with pytest.raises(NotImplementedError, match=r"padding_mode='zeros' only.*floating_region.py:49,63.*build.py:83-88"):
+        FloatingRegionScore(size=3, padding_mode="reflect")
 
 
 def test_hypermlr_parameters_match_reference_names_and_dtypes():
@@ -128,3 +131,29 @@ def test_direct_png_writer_decodes_to_the_same_mode_L_image(tmp_path):
     _persist(a if a.shape == (64, 96) else np.full((64, 96), 255, np.uint8), act, act.clone(), str(tmp_path / "m.png"), str(tmp_path / "i.pth"))
     ind = torch.load(str(tmp_path / "i.pth"))
     assert set(ind) == {"active", "selected"} and ind["active"].dtype == torch.bool and torch.equal(ind["active"], act)
+
+
+def test_hw_queue_default_and_warning(monkeypatch):
+    """the product must not rely on an environment knob only the bench sets.  `import halo_amd` chooses
+    GPU_MAX_HW_QUEUES=8 unless the user did (it is read when the HIP runtime starts); RegionSelection warns once when fewer
+    queues than the streams it drives are configured."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    code = "import sys, os; sys.path.insert(0, %r); import halo_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "3"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "3"
+    from halo_amd.core.active import build
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    monkeypatch.setattr(build, "_QUEUE_WARNED", False)
+    with pytest.warns(RuntimeWarning, match="GPU_MAX_HW_QUEUES=2"):
+        build._check_hw_queues(4)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        build._check_hw_queues(4)                         # once
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+        monkeypatch.setattr(build, "_QUEUE_WARNED", False)
+        build._check_hw_queues(4)                         # enough queues: silent

@@ -49,6 +49,13 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
+def _lr_mode():
+    """the low-res mode RegionSelection / score_maps_lowres run in by default ('gram' unless HALO_LOWRES says otherwise):
+    the oracle driver is asked for the same evaluation order, so the comparisons stay bit-exact"""
+    from halo_amd.core.active.floating_region import lowres_mode
+    return lowres_mode(None)
+
+
 def bits_equal(a, b):
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
@@ -103,6 +110,21 @@ def test_hypermapper_lastdim_api(golden, dev):
         assert max_abs_diff(m.expmap2(t(d[k + "__x"], dev).double()).cpu().numpy(), d[k + "__expmap2"]) < 1e-12
         assert max_abs_diff(m.cosine_distance(t(d[k + "__x"][6:], dev), t(d[k + "__y_h"][6:], dev).float()).cpu().numpy(),
                             d[k + "__cosine"]) < 1e-5
+
+
+def test_hypermetrics_vs_reference(golden, dev):
+    """HyperMetrics.compute (hyperbolic.py:191-228; dead in the reference tree, kept for API completeness) against the
+    reference's own outputs: exponential maps and the Poincare distance through the HIP kernels."""
+    from halo_amd.core.utils.hyperbolic import HyperMetrics
+    d = golden("hypermapper")
+    for c in (1.0, 0.5):
+        k = f"hm_c{c}__"
+        met = HyperMetrics(c=c).compute(t(d[k + "x"], dev), t(d[k + "y"], dev))
+        assert set(met) == {"mse", "cosine_dist", "radius_x", "radius_y", "ang_e", "poincare_dist"}
+        for key, tol in (("mse", 1e-7), ("cosine_dist", 1e-5), ("radius_x", 1e-12), ("radius_y", 1e-12), ("ang_e", 1e-9), ("poincare_dist", 1e-8)):
+            got = met[key].cpu().numpy()
+            assert got.dtype == d[k + key].dtype and got.shape == d[k + key].shape, key
+            assert max_abs_diff(got, d[k + key]) < tol, (key, c)
 
 
 # ------------------------------------------------------------------ score + selection on the golden vectors
@@ -581,7 +603,7 @@ def test_lowres_sources_equal_upsample_then_score(dev, geom, unc, pur):
     gt = rng.integers(0, O, (B, H, W)).astype(np.int64)
     act = rng.random((B, H, W)) < 0.03
     lg, em = t(logit_lr, dev), t(emb_lr, dev)
-    a = score_maps_lowres(lg, em, (H, W), unc, pur, True, t(gt, dev), ksize=3, K=50, active=t(act, dev))
+    a = score_maps_lowres(lg, em, (H, W), unc, pur, True, t(gt, dev), ksize=3, K=50, active=t(act, dev), mode="exact")
     b = score_maps(bilinear_align_corners(lg, (H, W)), bilinear_align_corners(em, (H, W)), unc, pur, True, t(gt, dev),
                    size=3, K=50, active=t(act, dev))
     for x, y in zip(a, b):
@@ -628,6 +650,96 @@ def test_lowres_gram_mode_tracks_the_exact_mode(dev, geom, pur):
         picks, npk = greedy_select(sc, n, 1, 3, act, sel, am, gt)
         res.append((picks[:, :, :2].cpu().numpy().copy(), npk.cpu().numpy().copy(), act.cpu().numpy().copy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("geom", [((16, 32), (16, 32), (64, 128)), ((40, 80), (10, 20), (64, 128)), ((23, 37), (9, 14), (50, 77)),
+                                  ((64, 128), (64, 128), (64, 128)), ((5, 7), (3, 4), (96, 130)), ((21, 33), (21, 33), (64, 100)),
+                                  ((8, 8), (3, 63), (12, 250)), ((8, 8), (2, 64), (9, 257)), ((4, 4), (1, 1), (9, 11)), ((4, 4), (7, 1), (30, 6)),
+                                  ((12, 20), (30, 44), (24, 40))])       # the last one DOWN-samples the embedding
+@pytest.mark.parametrize("unc,pur,norm", [("entropy", "radius", True), ("pixel_entropy", "euc_norm", True), ("entropy", "hyper", True),
+                                           ("entropy", "radius", False)])
+def test_lowres_gram_mode_equals_its_oracle_twin_bitwise(dev, geom, unc, pur, norm):
+    """Round 3: the 'gram' low-res mode (k_gram_lr + k_radius_gram) has a CPU twin (oracle.halo_oracle.gram_radius: the same
+    operations in the same order), so the mode is pinned bit for bit like the exact one -- all three maps, every geometry
+    (wave-width edge cases of the 63-column strips, single rows / columns, down-sampling), projected and zero vectors."""
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from oracle import halo_oracle as ho
+    (hl, wl), (hf, wf), (H, W) = geom
+    rng = np.random.default_rng(hl * 131 + hf * 7 + wf)
+    B, C, O = 2, 20, 19
+    logit_lr = rng.standard_normal((B, O, hl, wl)).astype(np.float32)
+    z = (rng.standard_normal((B, C, hf, wf)) * 0.3).astype(np.float32)
+    z[0, :, 0, 0] = 0.0
+    z[1, :, hf // 2:, wf // 2:] *= 200.0                      # projected onto the ball's boundary
+    emb_lr = ho.expmap(z, 1.0, dim=1)
+    gt = rng.integers(0, O, (B, H, W)).astype(np.int64)
+    act = rng.random((B, H, W)) < 0.03
+    g = score_maps_lowres(t(logit_lr, dev), t(emb_lr, dev), (H, W), unc, pur, norm, t(gt, dev), ksize=3, K=50, active=t(act, dev),
+                          mode="gram")
+    for b in range(B):
+        raw = ho.gram_radius(emb_lr[b], (H, W), "euc_norm" if pur == "euc_norm" else "radius", 1.0)
+        so, io, uo = ho.floating_region_score(ho.bilinear(logit_lr[b:b + 1], (H, W)), None, unc, pur, norm, gt[b], size=3,
+                                              purity_type=pur, K=50, impurity_raw=raw)
+        so = so.copy(); so[act[b]] = -np.inf
+        assert bits_equal(g[0][b].cpu().numpy(), so) and bits_equal(g[1][b].cpu().numpy(), io) and bits_equal(g[2][b].cpu().numpy(), uo), b
+
+
+def test_gram_mode_full_size_vs_oracle(dev):
+    """the real boundary at full size -- C = 256 float64 embedding 160x320 and logits 640x1280 -> 1024x2048 --
+    on SMOOTH embeddings (a 40x80 latent upsampled x4 before the exponential map, like real feature maps) that include a
+    region projected onto the ball's boundary.  Per image: HIP 'gram' == its oracle twin bit for bit (three maps, 2331 picks,
+    masks); against the oracle's upsample-then-score ('exact' order, the reference's) the normalised maps agree to 1e-12
+    (tolerance stated here; observed 3e-13) and the picks / masks are identical.  The two orders differ by a few 1e-16 in the
+    squared norm; artanh amplifies that by 1 / (1 - norm^2), so the invariant is stated on the norm: |tanh(r/2) - tanh(r'/2)|
+    <= 1e-14 (observed 2.6e-15; raw radii near 9 differ by up to 2e-12, a vector AT the projection limit would by 2.5e-10).
+    HALO_GRAM_IMAGES (default 2) images; tools/r03_gram_fullsize.sh ran 32 (profiles/r03_gram_fullsize.txt)."""
+    from halo_amd.core.active.build import acquire_batch_lowres
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from oracle import halo_oracle as ho
+    H, W, C, O, n = 1024, 2048, 256, 19, 2331
+    n_images = int(os.environ.get("HALO_GRAM_IMAGES", "2"))
+    bound = 1.0 / math.sqrt(C)
+    worst = 0.0
+    for i in range(n_images):
+        rng = np.random.default_rng(9000 + i)
+        lat = (rng.standard_normal((1, C, 40, 80)) * 0.12).astype(np.float32)
+        z = ho.bilinear(lat, (160, 320))
+        y0, x0 = int(rng.integers(0, 120)), int(rng.integers(0, 260))
+        z[0, :, y0:y0 + 30, x0:x0 + 50] *= np.float32(40.0)             # saturates tanh: projected (boundary) vectors
+        emb_lr = ho.expmap(z, 1.0, dim=1)
+        logit160 = ho.hypermlr(emb_lr, rng.uniform(-bound, bound, (O, C)), rng.uniform(-bound, bound, (O, C)), 1.0).astype(np.float32)
+        logit_lr = ho.bilinear(logit160, (640, 1280))
+        gt = rng.integers(0, O, (H, W)).astype(np.int64)
+        lg, em = t(logit_lr, dev), t(emb_lr, dev)
+        g = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, ksize=3, mode="gram")
+        # the twin
+        logit_up = ho.bilinear(logit_lr, (H, W))
+        sg, ig, ug = ho.floating_region_score(logit_up, None, "entropy", "radius", True, None, size=3, purity_type="radius",
+                                              impurity_raw=ho.gram_radius(emb_lr, (H, W)))
+        assert bits_equal(g[0][0].cpu().numpy(), sg) and bits_equal(g[1][0].cpu().numpy(), ig) and bits_equal(g[2][0].cpu().numpy(), ug), i
+        # the reference's order
+        se, ie, ue = ho.floating_region_score(logit_up, ho.bilinear(emb_lr, (H, W)), "entropy", "radius", True, None, size=3,
+                                              purity_type="radius")
+        worst = max(worst, float(np.abs(sg - se).max()), float(np.abs(ig - ie).max()))
+        assert np.abs(sg - se).max() <= 1e-12 and np.abs(ig - ie).max() <= 1e-12 and np.array_equal(ug, ue), (i, worst)
+        r_g = score_maps_lowres(lg, em, (H, W), "none", "radius", False, None, ksize=3, mode="gram")[1][0].cpu().numpy()
+        r_e = score_maps_lowres(lg, em, (H, W), "none", "radius", False, None, ksize=3, mode="exact")[1][0].cpu().numpy()
+        assert np.abs(np.tanh(r_g / 2) - np.tanh(r_e / 2)).max() <= 1e-14, i
+        res = []
+        for sc in (sg, se):
+            a, s_, m = np.zeros((H, W), bool), np.zeros((H, W), bool), np.full((H, W), 255, np.int64)
+            _, _, _, _, pk = ho.select_pixels_to_label(sc.copy(), n, 1, 5, a, s_, m, gt, True)
+            res.append((pk, a, s_, m))
+        assert len(res[0][0]) == n and np.array_equal(res[0][0][:, :2], res[1][0][:, :2]), i     # the same pixels in the same order
+        for x, y in zip(res[0][1:], res[1][1:]):
+            assert np.array_equal(x, y), i
+        act = torch.zeros((1, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+        pk, nk = acquire_batch_lowres(lg, em, (H, W), t(gt, dev)[None], act, sel, am, unc_type="entropy", pur_type="radius", normalize=True,
+                                      n_regions=n, active_radius=1, mask_radius=5, lowres_mode="gram")
+        assert int(nk[0]) == n and bits_equal(pk[0].cpu().numpy(), res[0][0]), i
+        assert np.array_equal(act[0].cpu().numpy(), res[0][1]) and np.array_equal(am[0].cpu().numpy(), res[0][3]), i
+    print("gram vs upsample-then-score, %d full-size images: max |map difference| %.3g" % (n_images, worst))
 
 
 def test_lowres_gram_mode_on_degenerate_grids(dev):
@@ -681,7 +793,7 @@ def test_lowres_downsampling_falls_back_to_explicit_upsample(dev):
     lg = t(rng.standard_normal((1, 19, 24, 40)).astype(np.float32), dev)
     em = t(rng.standard_normal((1, 4, 700, 1100)) * 0.05, dev)
     with pytest.raises(HaloUnsupported):
-        score_maps_lowres(lg, em, (24, 40), "entropy", "radius", True, None)
+        score_maps_lowres(lg, em, (24, 40), "entropy", "radius", True, None, mode="exact")
     gt = t(rng.integers(0, 19, (1, 24, 40)).astype(np.int64), dev)
 
     def fresh():
@@ -689,7 +801,7 @@ def test_lowres_downsampling_falls_back_to_explicit_upsample(dev):
         return a, torch.zeros_like(a), torch.full((1, 24, 40), 255, dtype=torch.int64, device=dev)
     a1, s1, m1 = fresh()
     p1, n1 = acquire_batch_lowres(lg, em, (24, 40), gt, a1, s1, m1, unc_type="entropy", pur_type="radius", normalize=True,
-                                  n_regions=5, active_radius=1, mask_radius=5)
+                                  n_regions=5, active_radius=1, mask_radius=5, lowres_mode="exact")
     a2, s2, m2 = fresh()
     p2, n2 = acquire_batch(lg, bilinear_align_corners(em, (24, 40)), gt, a2, s2, m2, unc_type="entropy", pur_type="radius",
                            normalize=True, n_regions=5, active_radius=1, mask_radius=5)
@@ -799,7 +911,7 @@ def test_region_selection_pipelined_pool_vs_oracle(dev):
         oracle_in.append(dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act,
                               selected=np.zeros((H, W), bool), origin_mask=np.full((H, W), 255, np.int64)))
     RegionSelection(cfg, _Fake(), _Fake(outs), items, 1, in_flight=2, writer_threads=3)
-    want = ho.region_selection(cfg, oracle_in)
+    want = ho.region_selection(cfg, oracle_in, lowres_mode=_lr_mode())
     for i, (mask, act, sel, _) in enumerate(want):
         png = np.array(Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8)
         ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
@@ -963,7 +1075,8 @@ def test_region_selection_full_size_real_geometry_vs_oracle(dev):
             "path_to_indicator": [os.path.join(tmp, "i.pth")], "name": ["img"]}
     RegionSelection(cfg, _Fake(), _Fake([(t(logit_lr, dev), t(emb_lr, dev))]), [item], 1)
     (mask, a_o, s_o, picks), = ho.region_selection(cfg, [dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act,
-                                                            selected=np.zeros((H, W), bool), origin_mask=np.full((H, W), 255, np.int64))])
+                                                            selected=np.zeros((H, W), bool), origin_mask=np.full((H, W), 255, np.int64))],
+                                                   lowres_mode=_lr_mode())
     assert len(picks) == 2331
     ind = torch.load(os.path.join(tmp, "i.pth"))
     assert np.array_equal(np.array(Image.open(os.path.join(tmp, "m.png")), dtype=np.uint8), mask)
@@ -1227,7 +1340,8 @@ def test_region_selection_deeplab_v2_geometry_full_size(dev):
             "path_to_indicator": [os.path.join(tmp, "i.pth")], "name": ["img"]}
     RegionSelection(cfg, _Fake(), _Fake([(t(logit_lr, dev), t(emb_lr, dev))]), [item], 1)
     (mask, a_o, s_o, picks), = ho.region_selection(cfg, [dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act,
-                                                            selected=np.zeros((H, W), bool), origin_mask=np.full((H, W), 255, np.int64))])
+                                                            selected=np.zeros((H, W), bool), origin_mask=np.full((H, W), 255, np.int64))],
+                                                   lowres_mode=_lr_mode())
     assert len(picks) == 2331
     ind = torch.load(os.path.join(tmp, "i.pth"))
     assert np.array_equal(np.array(Image.open(os.path.join(tmp, "m.png")), dtype=np.uint8), mask)
@@ -1242,10 +1356,13 @@ def test_narrow_maps_through_the_lowres_scorer(dev):
     for (H, W) in ((4096, 4), (3000, 1), (2, 5000)):
         lg = t(rng.standard_normal((1, 19, max(1, H // 4), max(1, W // 2))).astype(np.float32), dev)
         em = t((rng.standard_normal((1, 6, max(1, H // 8), max(1, W // 2))) * 0.2), dev)
-        a = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, ksize=3)
+        a = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, ksize=3, mode="exact")
         b = score_maps(bilinear_align_corners(lg, (H, W)), bilinear_align_corners(em, (H, W)), "entropy", "radius", True, None, size=3)
         for x, y in zip(a, b):
             assert bits_equal(x.cpu().numpy(), y.cpu().numpy()), (H, W)
+        g = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, ksize=3, mode="gram")
+        for x, y in zip(a, g):
+            assert max_abs_diff(x.cpu().numpy(), y.cpu().numpy()) < 1e-12, (H, W)
 
 
 def test_region_selection_reads_the_curvature_of_the_cfg_it_is_given(dev):
@@ -1272,8 +1389,8 @@ def test_region_selection_reads_the_curvature_of_the_cfg_it_is_given(dev):
     tables = RegionSelection(cfg, _Fake(), _Fake([(t(logit_lr, dev), t(emb_lr, dev))]), [item], 1, return_tables=True)
     im = dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=np.zeros((H, W), bool), selected=np.zeros((H, W), bool),
               origin_mask=np.full((H, W), 255, np.int64))
-    (mask, a_o, s_o, picks), = ho.region_selection(cfg, [im])
-    (mask1, _, _, picks1), = ho.region_selection(cfg, [im], c=1.0)
+    (mask, a_o, s_o, picks), = ho.region_selection(cfg, [im], lowres_mode=_lr_mode())
+    (mask1, _, _, picks1), = ho.region_selection(cfg, [im], c=1.0, lowres_mode=_lr_mode())
     assert not np.array_equal(picks, picks1), "the test inputs must tell the two curvatures apart"
     assert np.array_equal(np.array(Image.open(os.path.join(tmp, "m.png")), dtype=np.uint8), mask)
     assert len(tables) == 1 and tables[0][1] == len(picks) and bits_equal(tables[0][0][:len(picks)].cpu().numpy(), picks)
@@ -1455,6 +1572,7 @@ import numpy as np, torch, torch.distributed as dist
 from PIL import Image
 torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
 dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+from halo_amd.core.active.floating_region import lowres_mode
 from halo_amd.pool import region_selection_sharded
 from oracle import halo_oracle as ho
 from test_pool_gloo import _Pool, _cfg
@@ -1496,7 +1614,8 @@ res = region_selection_sharded(_cfg(), Tap(), head, DS(), 1, loader_kwargs=dict(
 cfg = _cfg()
 want = ho.region_selection(cfg, [dict(logit_lr=it["logit_lr"][None].numpy(), embed_lr=it["embed_lr"][None].numpy(),
                                       origin_label=it["origin_label"].numpy(), origin_mask=it["origin_mask"].numpy(),
-                                      active=it["active"].numpy(), selected=it["selected"].numpy()) for it in pool.items])
+                                      active=it["active"].numpy(), selected=it["selected"].numpy()) for it in pool.items],
+                           lowres_mode=lowres_mode(None))       # the evaluation order RegionSelection runs by default
 assert res["range"] == (0, 5) and res["tables"].is_cuda and res["tables"].shape[0] == 5
 for i, (mask, act, sel, picks) in enumerate(want):
     assert np.array_equal(np.array(Image.open(os.path.join(root, "m%d.png" % i))), mask), i

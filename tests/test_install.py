@@ -74,6 +74,12 @@ assert tl.FloatingRegionScore is hf.FloatingRegionScore
 assert tl.LocalConsistentLoss is hl.LocalConsistentLoss and tl.NegativeLearningLoss is hl.NegativeLearningLoss
 import core.utils.hyperbolic, core.active.floating_region
 assert core.utils.hyperbolic is hh and core.active.floating_region is hf
+from core.utils.hyperbolic import HyperMapper, HyperMLR, HyperMetrics          # every public name of the reference module
+assert HyperMetrics(c=0.5).mapper.c == 0.5
+# ADVICE r2: an aliased module keeps ITS OWN spec (relative imports inside it, importlib.reload)
+import importlib
+assert hb.__spec__.name == 'halo_amd.core.active.build' and hb.__package__ == 'halo_amd.core.active'
+assert importlib.reload(hb) is hb and sys.modules['core.active.build'] is hb
 # ONE cfg object: the reference's (curvature 0.7 reaches the scorer and the heads)
 import core.configs, halo_amd.core.configs as hc
 assert hc.cfg is core.configs.cfg and hf.cfg is core.configs.cfg and hb.cfg is core.configs.cfg

@@ -106,9 +106,12 @@ def test_hypermapper_lastdim(golden):
         assert max_abs_diff(ho.dist(d[t + "__expmap"], d[t + "__y_h"], c), d[t + "__dist"]) < 1e-8
 
 
-def test_region_selection_driver(golden):
+@pytest.mark.parametrize("lowres_mode", ["exact", "gram"])
+def test_region_selection_driver(golden, lowres_mode):
     """RegionSelection (build.py:71-186), two rounds over a 3-image pool, including the
-    budget formula, the prior-pick masking and the uint8 mask the reference saved as PNG."""
+    budget formula, the prior-pick masking and the uint8 mask the reference saved as PNG.
+    'gram': the radius through the Gram form (the product's default low-res mode for float64 embeddings) must
+    reproduce the reference's files as well."""
     d = golden("region_selection")
     H, W, C, O = (int(v) for v in d["meta_HWCO"])
     cfg = types.SimpleNamespace(
@@ -120,7 +123,7 @@ def test_region_selection_driver(golden):
     for rnd in (1, 2):
         imgs = [dict(logit_lr=d[f"img{i}__logit_lr"], embed_lr=d[f"img{i}__embed_lr"],
                      origin_label=d[f"img{i}__gt"], **state[i]) for i in range(3)]
-        res = ho.region_selection(cfg, imgs)
+        res = ho.region_selection(cfg, imgs, lowres_mode=lowres_mode)
         for i, (mask, act, sel, picks) in enumerate(res):
             assert np.array_equal(mask, d[f"r{rnd}_img{i}__mask_png"])
             assert np.array_equal(act, d[f"r{rnd}_img{i}__active"])
@@ -143,3 +146,35 @@ def test_helper_methods(golden):
     assert max_abs_diff(i, d["imp_hyper"]) < 1e-6 and np.array_equal(c, d["cnt_hyper"])
     i, c = ho.region_impurity(d["argmax"], 19, 5)
     assert max_abs_diff(i, d["imp_ripu_k5"]) < 1e-6 and np.array_equal(c, d["cnt_ripu_k5"])
+
+
+def test_gram_radius_tracks_upsample_then_reduce():
+    """The Gram form of the low-res radius (oracle twin of k_gram_lr + k_radius_gram) against the reference order
+    (bilinear upsample, then dist0 / norm over the channels): the same number rounded differently.  Smooth embeddings,
+    projected (boundary) vectors, zero vectors, clamped edge taps, non-integer magnifications."""
+    rng = np.random.default_rng(11)
+    for (C, h, w, H, W) in ((8, 8, 16, 32, 64), (24, 9, 7, 40, 45), (64, 12, 20, 77, 128), (5, 1, 6, 4, 24), (3, 4, 4, 4, 4)):
+        z = (rng.standard_normal((1, C, h, w)) * 0.1).astype(np.float32)
+        z[0, :, 0, 0] = 0.0
+        if h > 2 and w > 3:
+            z[0, :, 1:3, 1:4] *= 300.0                   # tanh clamp + projection: vectors on the ball's boundary
+        emb = ho.expmap(z, 1.0, dim=1)
+        up = ho.bilinear(emb, (H, W))
+        for mode, ref in (("radius", ho.dist0(up, 1.0, dim=1)[0]), ("euc_norm", np.sqrt((up[0] ** 2).sum(0)))):
+            g = ho.gram_radius(emb, (H, W), mode, 1.0)
+            assert g.shape == (H, W)
+            tol = 1e-12 if mode == "radius" else 1e-13
+            assert np.nanmax(np.abs(g - ref) / np.maximum(1.0, np.abs(ref))) < tol, (C, h, w, H, W, mode)
+    # as the impurity of the scorer: same maps to ~1e-15, same picks
+    logit = rng.standard_normal((1, 19, 16, 32)).astype(np.float32)
+    emb = ho.expmap((rng.standard_normal((1, 16, 16, 32)) * 0.1).astype(np.float32), 1.0, dim=1)
+    up, lg = ho.bilinear(emb, (64, 128)), ho.bilinear(logit, (64, 128))
+    a = ho.floating_region_score(lg, up, "entropy", "radius", True, None, size=3, purity_type="radius")
+    b = ho.floating_region_score(lg, None, "entropy", "radius", True, None, size=3, purity_type="radius",
+                                 impurity_raw=ho.gram_radius(emb, (64, 128)))
+    assert a[0].dtype == b[0].dtype == np.float64 and np.abs(a[0] - b[0]).max() < 1e-13 and np.array_equal(a[2], b[2])
+    for pur in ("hyper",):
+        a = ho.floating_region_score(lg, up, "entropy", pur, True, None, size=3, purity_type=pur, K=20)
+        b = ho.floating_region_score(lg, None, "entropy", pur, True, None, size=3, purity_type=pur, K=20,
+                                     impurity_raw=ho.gram_radius(emb, (64, 128)))
+        assert np.mean(a[1] != b[1]) < 0.01            # a radius on a bin edge may land in the neighbouring bin
