@@ -167,10 +167,15 @@ class Pipeline:
         self.selected_done = [torch.cuda.Event() for _ in range(D)]
         self.ev = []                       # (start, stop) HIP events around k_feat_reduce
         self.ev_lr = []                    # low-res source: (logit start, logit stop, embedding start, embedding stop, images)
-        self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]
+        self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]      # warm-up steps
         self.counts = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(D)]
-        # this rank's block of the round's wire format (halo_amd/pool.py), padded to ceil(N / world) rows
+        # the round's tables of this rank: the selector writes each timed step's rows in place; packed into the wire block
+        # (halo_amd/pool.py, padded to ceil(N / world) rows) ONCE, right before the round's one collective
+        self.round_tables = torch.zeros((rows, n_regions, 3), dtype=torch.float64, device=dev)
+        self.round_counts = torch.zeros((rows,), dtype=torch.int32, device=dev)
         self.wire = torch.zeros((rows, 3 * n_regions + 1), dtype=torch.int32, device=dev)
+        self.rows_done = 0
+        self.slot_out = [None] * D
         self.step_no = 0
         self.slot_lo = [None] * D          # which ring slice each slot last processed
         self.ref_tables = {}               # ring offset -> pick table seen first (the ring repeats: tables must too)
@@ -192,7 +197,7 @@ class Pipeline:
         slot's stream; `row` (timed steps): where the batch's tables go in the round's wire block."""
         from halo_amd.core.active.build import greedy_select
         from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
-        from halo_amd.pool import pack_tables_into, undo_picks
+        from halo_amd.pool import undo_picks
         B, R = self.B, self.R
         b = B if b is None else b
         k = self.step_no % self.D
@@ -234,12 +239,12 @@ class Pipeline:
             self.scored[k].record(self.s_score)
         with torch.cuda.stream(self.s_sel[k]):
             self.s_sel[k].wait_event(self.scored[k])
+            dst = (self.tables[k][:b], self.counts[k][:b]) if row is None else (self.round_tables[row:row + b], self.round_counts[row:row + b])
             picks, npk = greedy_select(self.score[k][:b], self.n, 1, self.mrad, self.active[k][:b], self.selected[k][:b],
-                                       self.amask[k][:b], gb)
-            self.tables[k][:b].copy_(picks)
-            self.counts[k][:b].copy_(npk)
-            if row is not None:        # the round's exchange format, one launch per step; the collective itself runs once
-                pack_tables_into(self.wire[row:row + b], picks, npk)
+                                       self.amask[k][:b], gb, out=dst)
+            self.slot_out[k] = dst
+            if row is not None:
+                self.rows_done = max(self.rows_done, row + b)
             if self.resets == "undo":
                 undo_picks(picks, npk, 1, self.mrad, self.active[k][:b], self.selected[k][:b], self.amask[k][:b])
             self.selected_done[k].record(self.s_sel[k])
@@ -254,10 +259,12 @@ class Pipeline:
     def finish_round(self, n_images, host_backend=False):
         """The path's one exchange step: behind the last selection of the round, ONE all-gather of the
         rank's wire block on the communication stream.  Returns (tables, counts) of the whole pool in pool order."""
-        from halo_amd.pool import gather_wire
+        from halo_amd.pool import gather_wire, pack_tables_into
         with torch.cuda.stream(self.s_comm):
             for e in self.selected_done:
                 self.s_comm.wait_event(e)
+            n = self.rows_done           # the round's exchange format: one launch for the whole block
+            pack_tables_into(self.wire[:n], self.round_tables[:n], self.round_counts[:n])
             if host_backend:
                 self.s_comm.synchronize()
                 t0 = time.perf_counter()
@@ -292,11 +299,12 @@ class Pipeline:
             if ent is None:
                 continue
             lo, b = ent
-            self.min_picked = min(self.min_picked, int(self.counts[k][:b].min()))
+            tab, cnt = self.slot_out[k]
+            self.min_picked = min(self.min_picked, int(cnt.min()))
             if lo not in self.ref_tables:
                 if b == self.B:
-                    self.ref_tables[lo] = self.tables[k].clone()
-            elif not torch.equal(self.ref_tables[lo][:b], self.tables[k][:b]):
+                    self.ref_tables[lo] = tab.clone()
+            elif not torch.equal(self.ref_tables[lo][:b], tab):
                 self.tables_consistent = False
 
     def lowres_pass_ms(self):
@@ -502,11 +510,9 @@ def main():
     # ---- what the exchange delivered (outside the timed region): this rank's rows are its local tables, and -- pool
     # mode -- every other rank's rows equal this rank's own results for the same content
     assert tables.shape[0] == n_pool and counts.shape[0] == n_pool
-    k_last = (pipe.step_no - 1) % pipe.D
-    if sched:
-        b_last = sched[-1]
-        assert torch.equal(tables[hi_r - b_last:hi_r], pipe.tables[k_last][:b_last]), "gathered table differs from the local one"
-        assert torch.equal(counts[hi_r - b_last:hi_r], pipe.counts[k_last][:b_last])
+    if sched:      # what came back for this rank's block is what its selector wrote
+        assert torch.equal(tables[lo_r:hi_r], pipe.round_tables[:n_local]), "gathered tables differ from the local ones"
+        assert torch.equal(counts[lo_r:hi_r], pipe.round_counts[:n_local])
     assert int(counts.min()) == n_regions, "a gathered image has fewer picks than regions"
     exchange_checked = 0
     if pool_mode and n_local > 0:
@@ -588,7 +594,7 @@ def main():
                 flops = 9.0 * B * Hh * Ww * C
                 peak = 78.6 if fdtype == torch.float64 else 157.3
                 ach = flops / (t_feat * 1e-3) / 1e12
-                out["roofline"] = {"bound": "valu", "kernel": "k_feat_reduce_lr", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                out["roofline"] = {"bound": "valu", "kernel": "k_feat_reduce_lr_dmaf" if fdtype == torch.float64 else "k_feat_reduce_lr", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": None, "flops_per_launch": flops,
                                    "avg_launch_ms": round(t_feat, 4), "launches_timed": len(lr_feat_ms),
                                    "valu_slot_frac": round(ach / peak * 10.0 / 9.0, 4)}

@@ -22,12 +22,14 @@ from .floating_region import FloatingRegionScore, score_maps, score_maps_lowres,
 
 
 def greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth,
-                  return_picks=True, method=None):
+                  return_picks=True, method=None, out=None):
     """Batched device-side selection.  score (B,H,W) f32|f64, active/selected (B,H,W) bool,
     active_mask/ground_truth (B,H,W) int64 -- all on one ROCm device, all mutated in place.
     Returns (picks (B,n,3) float64 rows (h, w, value), n_picked (B,) int32) or None.
     method: "auto" (default; environment HALO_SELECT overrides) = value-binned sweep with the serial kernel
-    behind it, "serial" = the tile-table kernel only, "binned" = the sweep or HaloUnsupported.  Same results."""
+    behind it, "serial" = the tile-table kernel only, "binned" = the sweep or HaloUnsupported.  Same results.
+    out: optional (picks (B,n,3) float64, n_picked (B,) int32) contiguous device tensors to write the tables into
+    (pipelined callers collect a whole round's tables in one buffer); rows past an image's count are left as they are."""
     dev = _lib.require_device(score, active, selected, active_mask, ground_truth)
     B, H, W = score.shape
     for t in (score, active, selected, active_mask, ground_truth):
@@ -36,7 +38,12 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     assert active_mask.dtype == torch.int64 and ground_truth.dtype == torch.int64
     n = int(max(0, min(int(n_regions), H * W)))
     picks = n_picked = None
-    if return_picks:
+    if out is not None:
+        picks, n_picked = out
+        assert picks.shape == (B, max(n, 1), 3) and picks.dtype == torch.float64 and picks.is_contiguous() and picks.device == dev
+        assert n_picked.shape == (B,) and n_picked.dtype == torch.int32 and n_picked.is_contiguous() and n_picked.device == dev
+        return_picks = True
+    elif return_picks:
         picks = torch.zeros((B, max(n, 1), 3), dtype=torch.float64, device=dev)
         n_picked = torch.zeros((B,), dtype=torch.int32, device=dev)
     if n == 0 or B == 0:

@@ -1148,6 +1148,381 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
     block_minmax<TPB>(mn, mx, partials + (size_t)tile_id * 2);
 }
 
+// ---- k_feat_reduce_lr with the window staged by LDS-DMA into a double buffer (float64, even source width).
+// The kernel above is bound by its staging, not by its arithmetic (round 2: 2.4 ms without the arithmetic, 1.9 ms without the
+// staging, 3.05 ms complete, per 16 images): every 16-channel chunk is one dependent global round trip between two barriers,
+// through registers and ds_write_b64.  Here the window of chunk n + 1 travels global -> LDS by global_load_lds_dwordx4 (16 bytes
+// per lane, no registers, no LDS write instructions) WHILE chunk n is being interpolated: two LDS images of DMA_UNITS 16-byte
+// units, DMA_PER_WAVE instructions per wave and chunk, a counted s_waitcnt vmcnt(DMA_PER_WAVE) + raw s_barrier so that the
+// prefetch stays in flight across the barriers.
+//   * LDS image of a chunk: [channel][row][pair] dense, lane-linear in the order the DMA writes it (the destination of an
+//     LDS-DMA is wave-uniform base + lane x 16); the window starts at an EVEN source column so that every pair is a 16-byte
+//     aligned load (w even);
+//   * lanes past the end of a chunk re-read a valid address into the image's padding (no exec masking: every wave issues
+//     exactly DMA_PER_WAVE instructions per chunk, which is what the counted wait counts);
+//   * a pair that would start past the row's last column (only the clamped extra column of a right-edge tile) is loaded from
+//     (w - 2, w - 1) and its first half overwritten with the second after the data has landed: both halves then hold the
+//     clamped tap v[w - 1] the arithmetic expects there.
+// Same lerp4 / fma chains per pixel, so the same bits as k_feat_reduce_lr and as upsample-then-reduce.
+constexpr int DMA_PER_WAVE = 4, DMA_UNITS = DMA_PER_WAVE * TPB;      // 1024 units = 16 KiB per image
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dma(const double *__restrict__ feat, long long bstride, int C, int h, int w,
+                                                            int H, int W, double sh, double sw, int CC, double ks, double rks,
+                                                            double *__restrict__ out, double *__restrict__ partials)
+{
+    typedef double T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+    T *img = reinterpret_cast<T *>(lr_smem);                     // two images of DMA_UNITS * 2 doubles
+    typedef __attribute__((address_space(3))) unsigned char *lds_bytes;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_bytes)lr_smem;
+    // tile <-> block: XCD-contiguous eighths of the row-major tile list (see k_feat_reduce_lr)
+    const unsigned ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty * gridDim.z;
+    const unsigned lin = blockIdx.x + ntx * (blockIdx.y + nty * blockIdx.z);
+    const unsigned xq = ntiles / 8, xr = ntiles % 8, xk = lin % 8;
+    const unsigned tile_id = (xk < xr ? xk * (xq + 1) : xr * (xq + 1) + (xk - xr) * xq) + lin / 8;
+    const int bx = (int)(tile_id % ntx), by = (int)((tile_id / ntx) % nty);
+    const int b = (int)(tile_id / (ntx * nty));
+    const int X0 = bx * LR_TW, Y0 = by * LR_TH;
+    const int lx = threadIdx.x & (LR_TW - 1), ly = threadIdx.x / LR_TW;      // ly = wave in 0..3
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = X0 + lx;
+    const int ylast = (Y0 + LR_TH - 1 < H ? Y0 + LR_TH - 1 : H - 1), xlast = (X0 + LR_TW - 1 < W ? X0 + LR_TW - 1 : W - 1);
+    const int ty_lo = make_taps<T>(Y0, sh, h).i0, ty_hi = make_taps<T>(ylast, sh, h).i1;
+    const int tx_lo = make_taps<T>(X0, sw, w).i0 & ~1, tx_hi = make_taps<T>(xlast, sw, w).i1;       // even start column
+    const int rows = ty_hi - ty_lo + 2;                          // with the clamped extra row
+    const int U = (tx_hi - tx_lo + 2 + 1) >> 1;                  // pairs per row, covering the clamped extra column
+    const int per = rows * U, stride = 2 * U, plane = 2 * per;   // units per channel; row / channel strides in doubles
+    const bool xin = x < W;
+    const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
+    T acc[LR_PPT], w00[LR_PPT], w01[LR_PPT], w10[LR_PPT], w11[LR_PPT];
+    int o00[LR_PPT], o10[LR_PPT];
+    bool live[LR_PPT];
+    int a0 = 0, pat = 0;
+    bool regular = true;
+#pragma unroll
+    for (int j = 0; j < LR_PPT; ++j) {
+        const int y = Y0 + ly * LR_PPT + j;
+        live[j] = xin && y < H;
+        const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
+        w00[j] = ty.l0 * tx.l0; w01[j] = ty.l0 * tx.l1; w10[j] = ty.l1 * tx.l0; w11[j] = ty.l1 * tx.l1;
+        o00[j] = (ty.i0 - ty_lo) * stride + (tx.i0 - tx_lo);
+        o10[j] = (ty.i1 - ty_lo) * stride + (tx.i0 - tx_lo);
+        acc[j] = (T)0;
+        if (j == 0) a0 = ty.i0;
+        const int d = ty.i0 - a0;
+        regular = regular && (d == 0 || d == 1);
+        if (j > 0) pat |= (d & 1) << (j - 1);
+    }
+    const int dx1 = tx.i1 - tx.i0;
+    const int upat = __builtin_amdgcn_readfirstlane(regular ? pat : -1);
+    // this lane's DMA_PER_WAVE units of a chunk: source offset (doubles, from the chunk's first plane) and channel inside the chunk
+    const long long hwl = (long long)h * w;
+    unsigned soff[DMA_PER_WAVE], sch[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int u = (i * (TPB / 64) + wv) * 64 + lane;
+        const int ch = u / per, rem = u - ch * per, r = rem / U, pp = rem - r * U;
+        const int sr = ty_lo + r < h - 1 ? ty_lo + r : h - 1;
+        int q0 = tx_lo + 2 * pp;
+        q0 = q0 + 1 > w - 1 ? w - 2 : q0;                        // a pair past the last column: (w - 2, w - 1), patched after it lands
+        sch[i] = (unsigned)ch;
+        soff[i] = (unsigned)(sr * w + q0);
+    }
+    const T *fb = feat + (size_t)b * bstride;
+    auto issue = [&](int c0, int buf) {
+        const int cc = C - c0 < CC ? C - c0 : CC;
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const unsigned ch = sch[i] < (unsigned)cc ? sch[i] : (unsigned)(cc - 1);       // past the chunk: any valid plane (padding)
+            const T *src = fb + (size_t)(c0 + ch) * hwl + soff[i];
+            const unsigned dst = lds0 + (unsigned)buf * (DMA_UNITS * 16) + (unsigned)((i * (TPB / 64) + wv) * 64) * 16u;
+            glds16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+        }
+    };
+    const bool patch = tx_lo + 2 * U > w;                        // block-uniform: the image holds a pair past the last source column
+    const int nchunks = (C + CC - 1) / CC;
+    issue(0, 0);
+    for (int n = 0; n < nchunks; ++n) {
+        const int c0 = n * CC, cc = C - c0 < CC ? C - c0 : CC;
+        if (n + 1 < nchunks) {
+            issue(c0 + CC, (n + 1) & 1);                          // its image was last read two iterations ago, behind a barrier
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");      // all but the newest chunk of THIS wave have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                             // ... and every other wave's part of chunk n too
+        T *tile = img + (size_t)(n & 1) * (DMA_UNITS * 2);
+        if (patch) {
+            const int pu = (w - tx_lo) >> 1;                      // the pair that starts at column w
+            for (int e = threadIdx.x; e < cc * rows; e += TPB) {
+                T *q = tile + (size_t)(e / rows) * plane + (size_t)(e % rows) * stride + 2 * pu;
+                q[0] = q[1];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const T *t0 = tile + o00[0];
+        if (upat == 0) lr_rows_chunk<T, 0>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
+        else if (upat == 4) lr_rows_chunk<T, 4>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
+        else if (upat == 6) lr_rows_chunk<T, 6>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
+        else if (upat == 7) lr_rows_chunk<T, 7>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
+        else {
+#pragma unroll 1
+            for (int ch = 0; ch < cc; ++ch) {
+                const T *tp = tile + (size_t)ch * plane;
+#pragma unroll
+                for (int j = 0; j < LR_PPT; ++j) {
+                    const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
+                    acc[j] = fma_t(v, v, acc[j]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of the image are retired ...
+        __builtin_amdgcn_s_barrier();                             // ... and everybody's, before the next iteration restages it
+    }
+    double mn = 0.0, mx = 0.0;
+    bool have = false;
+#pragma unroll
+    for (int j = 0; j < LR_PPT; ++j) {
+        if (!live[j]) continue;
+        const int y = Y0 + ly * LR_PPT + j;
+        T r;
+        if constexpr (MODE == 0) r = dist0_from_ssq(acc[j], ks, rks);
+        else r = __builtin_sqrt(acc[j]);
+        out[(size_t)b * H * W + (size_t)y * W + x] = r;
+        if (!have) { mn = mx = (double)r; have = true; }
+        else { mn = nan_min(mn, (double)r); mx = nan_max(mx, (double)r); }
+    }
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }         // thread 0 (pixel X0,Y0) is always live
+    __syncthreads();
+    if (!have) { mn = seed[0]; mx = seed[1]; }
+    block_minmax<TPB>(mn, mx, partials + (size_t)tile_id * 2);
+}
+
+// ---- k_feat_reduce_lr_dma with a COMPILE-TIME image geometry: ROWS x UU pairs per channel, CCF = DMA_UNITS / (ROWS * UU)
+// channels per image.  Every LDS address of the interpolation loop is then one base register plus an immediate offset
+// (channel * plane + row * stride + {0, 8}): no address arithmetic in the loop (3 of 26 instructions per channel before), the
+// loop is fully unrolled over the chunk, and the six row words of channel c + 1 are requested BEFORE channel c is interpolated
+// (two register sets, counted lgkmcnt) -- a wave no longer parks on its own LDS latency once per channel.
+template <int PAT, int OFF, int STRIDE_B> struct LrRowsImm {
+    double v[3][2];
+    // request the row words of the channel whose plane starts OFF bytes behind `base` (no wait)
+    __device__ __forceinline__ void issue(unsigned base)
+    {
+        if constexpr (PAT != 0) {
+            asm volatile("ds_read_b64 %0, %6 offset:%7\n\tds_read_b64 %1, %6 offset:%8\n\tds_read_b64 %2, %6 offset:%9\n\t"
+                         "ds_read_b64 %3, %6 offset:%10\n\tds_read_b64 %4, %6 offset:%11\n\tds_read_b64 %5, %6 offset:%12"
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]), "=&v"(v[2][1])
+                         : "v"(base), "n"(OFF), "n"(OFF + 8), "n"(OFF + STRIDE_B), "n"(OFF + STRIDE_B + 8), "n"(OFF + 2 * STRIDE_B),
+                           "n"(OFF + 2 * STRIDE_B + 8)
+                         : "memory");
+        } else {
+            asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\tds_read_b64 %2, %4 offset:%7\n\t"
+                         "ds_read_b64 %3, %4 offset:%8"
+                         : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1])
+                         : "v"(base), "n"(OFF), "n"(OFF + 8), "n"(OFF + STRIDE_B), "n"(OFF + STRIDE_B + 8)
+                         : "memory");
+        }
+    }
+    // the values become readable: N = LDS reads issued AFTER this set's (they may stay in flight)
+    template <int N> __device__ __forceinline__ void wait()
+    {
+        if constexpr (PAT != 0)
+            asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[2][0]), "+v"(v[2][1]) : "n"(N) : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]) : "n"(N) : "memory");
+    }
+    __device__ __forceinline__ void accumulate(const double (&w00)[LR_PPT], const double (&w01)[LR_PPT], const double (&w10)[LR_PPT],
+                                               const double (&w11)[LR_PPT], double (&acc)[LR_PPT]) const
+    {
+#pragma unroll
+        for (int j = 0; j < LR_PPT; ++j) {
+            const int a = j == 0 ? 0 : (PAT >> (j - 1)) & 1;
+            const double x = lerp4<double>(v[a][0], v[a][1], v[a + 1][0], v[a + 1][1], w00[j], w01[j], w10[j], w11[j]);
+            acc[j] = fma_t(x, x, acc[j]);
+        }
+    }
+};
+
+template <int PAT, int ROWS, int UU, int CH, int CCF>
+__device__ __forceinline__ void lr_imm_steps(unsigned base, int cc, LrRowsImm<PAT, (CH % CCF) * ROWS * UU * 16, UU * 16> &cur,
+                                             const double (&w00)[LR_PPT], const double (&w01)[LR_PPT], const double (&w10)[LR_PPT],
+                                             const double (&w11)[LR_PPT], double (&acc)[LR_PPT])
+{
+    constexpr int NREAD = PAT != 0 ? 6 : 4;
+    if constexpr (CH + 1 < CCF) {
+        LrRowsImm<PAT, ((CH + 1) % CCF) * ROWS * UU * 16, UU * 16> nxt;
+        nxt.issue(base);                                   // channel CH + 1 on its way ...
+        cur.template wait<NREAD>();                        // ... channel CH has landed
+        if (CH < cc) cur.accumulate(w00, w01, w10, w11, acc);
+        lr_imm_steps<PAT, ROWS, UU, CH + 1, CCF>(base, cc, nxt, w00, w01, w10, w11, acc);
+    } else {
+        cur.template wait<0>();
+        if (CH < cc) cur.accumulate(w00, w01, w10, w11, acc);
+    }
+}
+
+template <int PAT, int ROWS, int UU, int CCF>
+__device__ __forceinline__ void lr_imm_chunk(unsigned base, int cc, const double (&w00)[LR_PPT], const double (&w01)[LR_PPT],
+                                             const double (&w10)[LR_PPT], const double (&w11)[LR_PPT], double (&acc)[LR_PPT])
+{
+    LrRowsImm<PAT, 0, UU * 16> first;
+    first.issue(base);
+    lr_imm_steps<PAT, ROWS, UU, 0, CCF>(base, cc, first, w00, w01, w10, w11, acc);
+}
+
+template <int MODE, int ROWS, int UU>
+__global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__restrict__ feat, long long bstride, int C, int h, int w,
+                                                             int H, int W, double sh, double sw, double ks, double rks,
+                                                             double *__restrict__ out, double *__restrict__ partials)
+{
+    typedef double T;
+    constexpr int PER = ROWS * UU, CCF = DMA_UNITS / PER, STRIDE = 2 * UU, PLANE = 2 * PER;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+    T *img = reinterpret_cast<T *>(lr_smem);
+    typedef __attribute__((address_space(3))) unsigned char *lds_bytes;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_bytes)lr_smem;
+    const unsigned ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty * gridDim.z;
+    const unsigned lin = blockIdx.x + ntx * (blockIdx.y + nty * blockIdx.z);
+    const unsigned xq = ntiles / 8, xr = ntiles % 8, xk = lin % 8;
+    const unsigned tile_id = (xk < xr ? xk * (xq + 1) : xr * (xq + 1) + (xk - xr) * xq) + lin / 8;
+    const int bx = (int)(tile_id % ntx), by = (int)((tile_id / ntx) % nty);
+    const int b = (int)(tile_id / (ntx * nty));
+    const int X0 = bx * LR_TW, Y0 = by * LR_TH;
+    const int lx = threadIdx.x & (LR_TW - 1), ly = threadIdx.x / LR_TW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = X0 + lx;
+    const int xlast = (X0 + LR_TW - 1 < W ? X0 + LR_TW - 1 : W - 1);
+    const int ty_lo = make_taps<T>(Y0, sh, h).i0;
+    const int tx_lo = make_taps<T>(X0, sw, w).i0 & ~1, tx_hi = make_taps<T>(xlast, sw, w).i1;
+    const bool xin = x < W;
+    const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
+    T acc[LR_PPT], w00[LR_PPT], w01[LR_PPT], w10[LR_PPT], w11[LR_PPT];
+    int o00[LR_PPT], o10[LR_PPT];
+    bool live[LR_PPT];
+    int a0 = 0, pat = 0;
+    bool regular = true;
+#pragma unroll
+    for (int j = 0; j < LR_PPT; ++j) {
+        const int y = Y0 + ly * LR_PPT + j;
+        live[j] = xin && y < H;
+        const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
+        w00[j] = ty.l0 * tx.l0; w01[j] = ty.l0 * tx.l1; w10[j] = ty.l1 * tx.l0; w11[j] = ty.l1 * tx.l1;
+        o00[j] = (ty.i0 - ty_lo) * STRIDE + (tx.i0 - tx_lo);
+        o10[j] = (ty.i1 - ty_lo) * STRIDE + (tx.i0 - tx_lo);
+        acc[j] = (T)0;
+        if (j == 0) a0 = ty.i0;
+        const int d = ty.i0 - a0;
+        regular = regular && (d == 0 || d == 1);
+        if (j > 0) pat |= (d & 1) << (j - 1);
+    }
+    const int dx1 = tx.i1 - tx.i0;
+    const int upat = __builtin_amdgcn_readfirstlane(regular ? pat : -1);
+    const long long hwl = (long long)h * w;
+    unsigned soff[DMA_PER_WAVE], sch[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int u = (i * (TPB / 64) + wv) * 64 + lane;
+        const int ch = u / PER, rem = u - ch * PER, r = rem / UU, pp = rem - r * UU;      // compile-time divisors
+        const int sr = ty_lo + r < h - 1 ? ty_lo + r : h - 1;
+        int q0 = tx_lo + 2 * pp;
+        q0 = q0 + 1 > w - 1 ? w - 2 : q0;                        // pairs past the last column (one of them is read: patched below)
+        sch[i] = (unsigned)ch;
+        soff[i] = (unsigned)(sr * w + q0);
+    }
+    const T *fb = feat + (size_t)b * bstride;
+    // per-lane source pointers of the chunk to be issued next, advanced by CCF planes per chunk (two VALU instructions per
+    // pointer and chunk instead of re-deriving channel * plane + offset); the last, partial chunk clamps its channel
+    const T *sp[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) sp[i] = fb + (size_t)sch[i] * hwl + soff[i];
+    const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(wv * 64) * 16u));
+    auto issue = [&](int c0, int buf) {
+        const int cc = C - c0 < CCF ? C - c0 : CCF;
+        if (cc == CCF) {
+#pragma unroll
+            for (int i = 0; i < DMA_PER_WAVE; ++i) {
+                glds16(sp[i], dst0 + (unsigned)buf * (DMA_UNITS * 16) + (unsigned)(i * (TPB / 64) * 64) * 16u);
+                sp[i] += (size_t)CCF * hwl;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < DMA_PER_WAVE; ++i) {
+                const unsigned ch = sch[i] < (unsigned)cc ? sch[i] : (unsigned)(cc - 1);
+                glds16(fb + (size_t)(c0 + ch) * hwl + soff[i], dst0 + (unsigned)buf * (DMA_UNITS * 16) + (unsigned)(i * (TPB / 64) * 64) * 16u);
+            }
+        }
+    };
+    const int pu = (w - tx_lo) >> 1;                              // the pair that starts at column w, if the image holds it
+    const bool patch = tx_hi + 1 >= w && pu < UU;                 // block-uniform: the clamped extra column lies past the row
+    const int nchunks = (C + CCF - 1) / CCF;
+    issue(0, 0);
+    for (int n = 0; n < nchunks; ++n) {
+        const int c0 = n * CCF, cc = C - c0 < CCF ? C - c0 : CCF;
+        if (n + 1 < nchunks) {
+            issue(c0 + CCF, (n + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        T *tile = img + (size_t)(n & 1) * (DMA_UNITS * 2);
+        if (patch) {
+            for (int e = threadIdx.x; e < cc * ROWS; e += TPB) {
+                T *q = tile + (size_t)(e / ROWS) * PLANE + (size_t)(e % ROWS) * STRIDE + 2 * pu;
+                q[0] = q[1];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const unsigned base = lds0 + (unsigned)(n & 1) * (DMA_UNITS * 16) + (unsigned)o00[0] * 8u;
+        if (upat == 0) lr_imm_chunk<0, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
+        else if (upat == 4) lr_imm_chunk<4, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
+        else if (upat == 6) lr_imm_chunk<6, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
+        else if (upat == 7) lr_imm_chunk<7, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
+        else {
+#pragma unroll 1
+            for (int ch = 0; ch < cc; ++ch) {
+                const T *tp = tile + (size_t)ch * PLANE;
+#pragma unroll
+                for (int j = 0; j < LR_PPT; ++j) {
+                    const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
+                    acc[j] = fma_t(v, v, acc[j]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    double mn = 0.0, mx = 0.0;
+    bool have = false;
+#pragma unroll
+    for (int j = 0; j < LR_PPT; ++j) {
+        if (!live[j]) continue;
+        const int y = Y0 + ly * LR_PPT + j;
+        T r;
+        if constexpr (MODE == 0) r = dist0_from_ssq(acc[j], ks, rks);
+        else r = __builtin_sqrt(acc[j]);
+        out[(size_t)b * H * W + (size_t)y * W + x] = r;
+        if (!have) { mn = mx = (double)r; have = true; }
+        else { mn = nan_min(mn, (double)r); mx = nan_max(mx, (double)r); }
+    }
+    __shared__ double seed[2];
+    if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
+    __syncthreads();
+    if (!have) { mn = seed[0]; mx = seed[1]; }
+    block_minmax<TPB>(mn, mx, partials + (size_t)tile_id * 2);
+}
+
 // ---- Gram form of the low-resolution radius ("precompute the 4-neighbour Gram terms per low-res cell,
 // then each output pixel costs O(10) not O(C)").  The interpolated embedding of an output pixel is sum_i w_i v_i over the
 // four corner vectors of its low-res cell, so  ||.||^2 = sum_{i<=j} (2 - [i==j]) w_i w_j <v_i, v_j>.  The 10 inner products
@@ -1419,15 +1794,42 @@ static int launch_feat_lr(const T *feat, long long bstride, int C, const LrDims 
     lr_window<T>(H, lr.hf, LR_TH, max_rows);
     lr_window<T>(W, lr.wf, LR_TW, max_cols);
     ++max_rows; ++max_cols;       // the staged window carries one clamped extra row and column (k_feat_reduce_lr)
+    const T sh = H > 1 ? (T)(lr.hf - 1) / (T)(H - 1) : (T)0, sw = W > 1 ? (T)(lr.wf - 1) / (T)(W - 1) : (T)0;
+    dim3 grid((unsigned)cdiv(W, LR_TW), (unsigned)cdiv(H, LR_TH), (unsigned)B), block(TPB);
+    nblk = (int)(grid.x * grid.y);
+    if constexpr (sizeof(T) == 8) {
+        // LDS-DMA double buffer (k_feat_reduce_lr_dma): float64, even source width (16-byte aligned pairs), at least 4 channels
+        // of the largest window per 16 KiB image; HALO_LR_NODMA=1 keeps the register-staged kernel (A/B switch, same bits)
+        const int units_per_ch = max_rows * ((max_cols + 2) / 2 + 1);        // even start column: up to one more pair per row
+        int CCd = DMA_UNITS / units_per_ch;
+        CCd = CCd > C ? C : CCd;
+        const bool dma_ok = lr.wf >= 2 && lr.wf % 2 == 0 && bstride % 2 == 0 && aligned16(feat) && CCd >= 4 && getenv("HALO_LR_NODMA") == nullptr;
+        if (dma_ok) {
+            const size_t lds = 2 * (size_t)DMA_UNITS * 16;
+            // compile-time image geometries (k_feat_reduce_lr_dmaf): rows x pairs that cover the launch's largest window
+            const int need_rows = max_rows, need_u = (max_cols + 2) / 2;
+            const bool nofixed = getenv("HALO_LR_NOFIXED") != nullptr;                 // A/B switch: runtime strides
+#define HALO_LR_FIXED(R_, U_)                                                                                                              \
+            if (!nofixed && need_rows <= R_ && need_u <= U_) {                                                                             \
+                if (mode == 0) hipLaunchKernelGGL((k_feat_reduce_lr_dmaf<0, R_, U_>), grid, block, lds, st, (const double *)feat, bstride, C, lr.hf, lr.wf, H, W, (double)sh, (double)sw, ks, rks, (double *)out, partials); \
+                else hipLaunchKernelGGL((k_feat_reduce_lr_dmaf<1, R_, U_>), grid, block, lds, st, (const double *)feat, bstride, C, lr.hf, lr.wf, H, W, (double)sh, (double)sw, ks, rks, (double *)out, partials);           \
+                return HALO_OK;                                                                                                            \
+            }
+            HALO_LR_FIXED(6, 8)        // x6.4 (160x320 -> 1024x2048): 21 channels per image
+            HALO_LR_FIXED(7, 10)       // x4: 14 channels per image
+            HALO_LR_FIXED(8, 12)
+#undef HALO_LR_FIXED
+            if (mode == 0) hipLaunchKernelGGL((k_feat_reduce_lr_dma<0>), grid, block, lds, st, (const double *)feat, bstride, C, lr.hf, lr.wf, H, W, (double)sh, (double)sw, CCd, ks, rks, (double *)out, partials);
+            else hipLaunchKernelGGL((k_feat_reduce_lr_dma<1>), grid, block, lds, st, (const double *)feat, bstride, C, lr.hf, lr.wf, H, W, (double)sh, (double)sw, CCd, ks, rks, (double *)out, partials);
+            return HALO_OK;
+        }
+    }
     const size_t plane_bytes = (size_t)max_rows * max_cols * sizeof(T);
     if (plane_bytes > 48 * 1024) return fail(HALO_E_UNSUPPORTED, "halo_score_maps_lr: source window too large for LDS (downsampling?)");
     // channels per chunk: what the block's four waves prefetch in one group each (k_feat_reduce_lr), LDS permitting
     int CC = (int)((48 * 1024) / plane_bytes);
     CC = CC > (TPB / 64) * LR_STAGE_G ? (TPB / 64) * LR_STAGE_G : CC;
     CC = CC > C ? C : CC;
-    const T sh = H > 1 ? (T)(lr.hf - 1) / (T)(H - 1) : (T)0, sw = W > 1 ? (T)(lr.wf - 1) / (T)(W - 1) : (T)0;
-    dim3 grid((unsigned)cdiv(W, LR_TW), (unsigned)cdiv(H, LR_TH), (unsigned)B), block(TPB);
-    nblk = (int)(grid.x * grid.y);
     const size_t lds = (size_t)CC * plane_bytes;
     if (mode == 0) hipLaunchKernelGGL((k_feat_reduce_lr<T, 0>), grid, block, lds, st, feat, bstride, C, lr.hf, lr.wf, H, W, sh, sw, max_rows, max_cols, CC, ks, rks, out, partials);
     else hipLaunchKernelGGL((k_feat_reduce_lr<T, 1>), grid, block, lds, st, feat, bstride, C, lr.hf, lr.wf, H, W, sh, sw, max_rows, max_cols, CC, ks, rks, out, partials);

@@ -1,0 +1,43 @@
+"""A/B of the exact low-res embedding pass: LDS-DMA double buffer with compile-time image geometry (k_feat_reduce_lr_dmaf, default),
+the same with runtime strides (HALO_LR_NOFIXED=1), register staging
+(HALO_LR_NODMA=1): bit equality of the maps and ms per 16 images (HIP events around the embedding pass), several geometries."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from halo_amd import _lib
+from halo_amd.core.active.floating_region import score_maps_lowres
+from halo_amd.core.utils.hyperbolic import HyperMapper
+
+dev = torch.device("cuda:0")
+L = _lib.lib()
+O, H, W = 19, 1024, 2048
+for (B, C, hl, wl, hf, wf, tag) in ((16, 256, 256, 512, 256, 512, "bench ring x4, C=256"), (8, 64, 640, 1280, 160, 320, "v3+ head: emb 160x320 C=64"),
+                                     (4, 64, 640, 1280, 640, 1280, "v2 head: emb 640x1280 C=64"), (16, 512, 256, 512, 256, 512, "x4, C=512")):
+    g = torch.Generator(device=dev).manual_seed(1)
+    lg = torch.randn((B, O, hl, wl), generator=g, device=dev)
+    em = HyperMapper(1.0).expmap(torch.randn((B, C, hf, wf), generator=g, device=dev) * 0.1, dim=1)
+    res = {}
+    for name, env in (("dma", None), ("dma_rt", "HALO_LR_NOFIXED"), ("regs", "HALO_LR_NODMA")):
+        os.environ.pop("HALO_LR_NODMA", None); os.environ.pop("HALO_LR_NOFIXED", None)
+        if env:
+            os.environ[env] = "1"
+        ms = []
+        for it in range(6):
+            ev = tuple(L.halo_event_create() for _ in range(4))
+            out = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, mode="exact", events=ev)
+            torch.cuda.synchronize()
+            v = ctypes.c_float(0)
+            L.halo_event_elapsed_ms(ev[2], ev[3], ctypes.byref(v))
+            if it:
+                ms.append(v.value)
+            for e in ev:
+                L.halo_event_destroy(e)
+        res[name] = (min(ms), out)
+    os.environ.pop("HALO_LR_NODMA", None); os.environ.pop("HALO_LR_NOFIXED", None)
+    same_rt = all(torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a.view(torch.int32),
+                              b.view(torch.int64) if b.dtype == torch.float64 else b.view(torch.int32)) for a, b in zip(res["dma_rt"][1], res["regs"][1]))
+    same = same_rt and all(torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a.view(torch.int32),
+                           b.view(torch.int64) if b.dtype == torch.float64 else b.view(torch.int32)) for a, b in zip(res["dma"][1], res["regs"][1]))
+    flops = 9.0 * B * H * W * C
+    print(f"{tag}: dma {res['dma'][0]:.3f} ms ({flops / res['dma'][0] / 1e9:.1f} TFLOP/s = {flops / res['dma'][0] / 1e9 / 78.6:.2f} of FP64 vector peak), "
+          f"runtime-stride DMA {res['dma_rt'][0]:.3f} ms, register staging {res['regs'][0]:.3f} ms, bit-identical {same}", flush=True)
