@@ -1,8 +1,10 @@
-"""Turn gpurun_out/r02/ (tools/collect_profiles.sh on an MI355X box) into the tracked summaries under profiles/."""
+"""Turn gpurun_out/<round>/ (tools/collect_profiles.sh on an MI355X box) into the tracked summaries under profiles/.
+    python tools/distill_profiles.py [r03]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", RND + "_profiles")
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -61,29 +63,50 @@ def short(name):
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    d = copy_json("bench_default.json", "r02_bench_default.json")
-    copy_json("bench_under_rocprof.json", "r02_bench_under_rocprof.json")
-    for v in ("f32", "lowres", "lowres_gram", "c512", "ripu", "hyper", "pool2975"):
-        copy_json("bench_%s.json" % v, "r02_bench_%s.json" % v)
-    stats_csv("trace/*/*_kernel_stats.csv", "r02_kernel_stats.csv")
-    stats_csv("trace_ripu/*/*_kernel_stats.csv", "r02_kernel_stats_ripu.csv", 25)
-    stats_csv("trace_hyper/*/*_kernel_stats.csv", "r02_kernel_stats_hyper.csv", 25)
-    stats_csv("trace_select/*/*_kernel_stats.csv", "r02_kernel_stats_select_tool.csv", 25)
-    stats_csv("trace_feat_alone/*/*_kernel_stats.csv", "r02_kernel_stats_feat_alone.csv", 12)
-    stats_csv("trace_lowres/*/*_kernel_stats.csv", "r02_kernel_stats_lowres.csv", 25)
-    stats_csv("trace_f32/*/*_kernel_stats.csv", "r02_kernel_stats_f32.csv", 25)
-    stats_csv("trace_lowres_gram/*/*_kernel_stats.csv", "r02_kernel_stats_lowres_gram.csv", 25)
+    d = copy_json("bench_default.json", RND + "_bench_default.json")
+    copy_json("bench_under_rocprof.json", RND + "_bench_under_rocprof.json")
+    for v in ("f32", "lowres", "lowres_exact", "lowres_gram", "c512", "ripu", "hyper", "pool2975", "resets_kernel", "resets_fills"):
+        copy_json("bench_%s.json" % v, RND + "_bench_%s.json" % v)
+    stats_csv("trace/*/*_kernel_stats.csv", RND + "_kernel_stats.csv")
+    stats_csv("trace_ripu/*/*_kernel_stats.csv", RND + "_kernel_stats_ripu.csv", 25)
+    stats_csv("trace_hyper/*/*_kernel_stats.csv", RND + "_kernel_stats_hyper.csv", 25)
+    stats_csv("trace_select/*/*_kernel_stats.csv", RND + "_kernel_stats_select_tool.csv", 25)
+    stats_csv("trace_feat_alone/*/*_kernel_stats.csv", RND + "_kernel_stats_feat_alone.csv", 12)
+    stats_csv("trace_lowres/*/*_kernel_stats.csv", RND + "_kernel_stats_lowres.csv", 25)
+    stats_csv("trace_f32/*/*_kernel_stats.csv", RND + "_kernel_stats_f32.csv", 25)
+    stats_csv("trace_lowres_gram/*/*_kernel_stats.csv", RND + "_kernel_stats_lowres_gram.csv", 25)
     lr = counters("pmc_lowres/*/*counter_collection.csv")
     if lr:
-        json.dump({"round": 2, "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_lowres.py",
-                   "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs",
-                   "per_kernel_avg_per_launch": {short(k): {n: sum(v) / len(v) for n, v in c.items()} for k, c in lr.items() if "_lr" in k}},
-                  open(os.path.join(DST, "r02_pmc_lowres.json"), "w"), indent=1)
-    for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt"):
+        clk = counters("pmc_lowres_clk/*/*counter_collection.csv")
+        ins = counters("pmc_lowres_insts/*/*counter_collection.csv")
+        per = {}
+        for k, c in lr.items():
+            if "_lr" not in k and "gram" not in k:
+                continue
+            rec = {n: sum(v) / len(v) for n, v in c.items()}
+            if k in ins:
+                rec.update({n: sum(v) / len(v) for n, v in ins[k].items()})
+            if k in clk:
+                gui = sum(clk[k]["GRBM_GUI_ACTIVE"]) / len(clk[k]["GRBM_GUI_ACTIVE"]) / 8          # summed over the 8 XCDs
+                d_ms = durations("pmc_lowres_clk/*/*kernel_trace.csv", short(k))
+                if d_ms:
+                    ms = sorted(d_ms)[len(d_ms) // 2]
+                    rec["duration_ms_clock_pass"] = ms
+                    rec["effective_clock_GHz"] = gui / (ms * 1e-3) / 1e9
+                    # one wave's VALU instruction keeps it "active" for 4 cycles; a float64 instruction also occupies the SIMD's
+                    # FP64 pipe for 4 cycles (16 lanes per cycle), so this ratio is the pipe's busy fraction for float64 kernels
+                    # (float32 kernels: two waves overlap, the ratio tops out at 2)
+                    rec["valu_active_cycles_per_SIMD_cycle"] = rec["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * gui)
+            per[short(k)] = rec
+        json.dump({"round": int(RND[1:]), "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_lowres.py (three passes: SQ activity, "
+                                                      "GRBM_GUI_ACTIVE for the clock, instruction counts)",
+                   "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all waves; GRBM_GUI_ACTIVE / 8 = shader cycles",
+                   "per_kernel_avg_per_launch": per}, open(os.path.join(DST, RND + "_pmc_lowres.json"), "w"), indent=1)
+    for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt", "tail_timeline.txt", "ab_lowres_dma.txt"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]
-            open(os.path.join(DST, "r02_" + t), "w").writelines(keep)
+            open(os.path.join(DST, RND + "_" + t), "w").writelines(keep)
     # ---- HBM traffic of the roofline kernel (two separate --pmc passes; gfx950: FETCH_SIZE doubled)
     fetch, write = counters("pmc_fetch/*/*counter_collection.csv"), counters("pmc_write/*/*counter_collection.csv")
     per = {}
@@ -101,13 +124,13 @@ def main():
         B, H, W, C, O = 16, 1024, 2048, 256, 19
         alg = B * H * W * (C * 8 + 8 + O * 4 + 4)
         hbm = int(2 * f_kb * 1024 + w_kb * 1024)
-        json.dump({"round": 2, "kernel": short(feat), "batch": B, "dtype": "f64", "shape_HWCO": [H, W, C, O],
+        json.dump({"round": int(RND[1:]), "kernel": short(feat), "batch": B, "dtype": "f64", "shape_HWCO": [H, W, C, O],
                    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
                               "--cpu-images 0 --ring 16 (two separate passes)",
                    "FETCH_SIZE_KB_avg_per_launch": f_kb, "WRITE_SIZE_KB_min_per_launch": w_kb,
                    "correction": "gfx950: FETCH_SIZE reports 1/2 of a 16-B/lane coalesced streaming read (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
                    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
-                   "per_kernel_KB": per}, open(os.path.join(DST, "r02_pmc_summary.json"), "w"), indent=1)
+                   "per_kernel_KB": per}, open(os.path.join(DST, RND + "_pmc_summary.json"), "w"), indent=1)
     # ---- HyperMLR on the matrix cores
     mlr = counters("pmc_mlr/*/*counter_collection.csv")
     clk = counters("pmc_mlr_clk/*/*counter_collection.csv")
@@ -119,15 +142,15 @@ def main():
             dur_clk = durations("pmc_mlr_clk/*/*kernel_trace.csv", "hypermlr")
             cycles = gui[0] / 8 if gui else None          # summed over the 8 XCDs
             util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cycles if cycles else None
-            json.dump({"round": 2, "kernel": short(k), "shape": "x (1,256,1024,2048) f64, 19 classes, float32 logits",
+            json.dump({"round": int(RND[1:]), "kernel": short(k), "shape": "x (1,256,1024,2048) f64, 19 classes, float32 logits",
                        "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_mlr.py ; second pass --pmc GRBM_GUI_ACTIVE",
                        "counters_avg_per_launch": c, "duration_ms": dur, "duration_ms_clock_pass": dur_clk,
                        "shader_cycles_per_launch": cycles, "effective_clock_GHz": (cycles / (sum(dur_clk) / len(dur_clk) * 1e-3) / 1e9) if cycles and dur_clk else None,
                        "mfma_busy_cycles_per_SIMD": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024,
                        "mfma_utilisation": util, "note": "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (64 per v_mfma_f64_16x16x4_f64) summed over 1024 SIMDs; "
                                                          "f64 MFMA and f64 VALU share the FP64 units, so the epilogue's VALU time adds to, not overlaps with, the MFMA time"},
-                      open(os.path.join(DST, "r02_mfma_head.json"), "w"), indent=1)
-    print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith("r02_")))
+                      open(os.path.join(DST, RND + "_mfma_head.json"), "w"), indent=1)
+    print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith(RND + "_")))
     if d:
         print("default bench:", d["value"], d["unit"], "roofline", d["roofline"])
 
