@@ -160,6 +160,9 @@ class Pipeline:
         self.active = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
         self.selected = [torch.zeros((B, Hh, Ww), dtype=torch.bool, device=dev) for _ in range(D)]
         self.amask = [torch.full((B, Hh, Ww), 255, dtype=torch.int64, device=dev) for _ in range(D)]
+        from halo_amd.core.active.floating_region import new_score_range
+        # normalised maps: the scorer bounds their value range for free and the selector skips its range pass
+        self.rng = [new_score_range(B, dev) if self.norm else None for _ in range(D)]
         self.resets = resets
         self.s_house = torch.cuda.Stream(dev)
         self.reset_done = [torch.cuda.Event() for _ in range(D)]
@@ -230,18 +233,19 @@ class Pipeline:
                     self.ev_lr.append(lev + (b,))
                 sc, self.imp, self.unc_map = score_maps_lowres(lb, fb, self.size, self.unc, self.pur, self.norm, gb, ksize=3,
                                                                K=self.K, c=1.0, active=self.active[k][:b], want_maps=True,
-                                                               mode=self.lr_mode, events=lev)
+                                                               mode=self.lr_mode, events=lev,
+                                                               score_range=None if self.rng[k] is None else self.rng[k][:b])
                 self.score[k][:b].copy_(sc)
             else:
                 _, self.imp, self.unc_map = score_maps(lb, fb, self.unc, self.pur, self.norm, gb, size=3, K=self.K, c=1.0,
                                                        active=self.active[k][:b], want_maps=True, out=self.score[k][:b],
-                                                       events=evs)
+                                                       events=evs, score_range=None if self.rng[k] is None else self.rng[k][:b])
             self.scored[k].record(self.s_score)
         with torch.cuda.stream(self.s_sel[k]):
             self.s_sel[k].wait_event(self.scored[k])
             dst = (self.tables[k][:b], self.counts[k][:b]) if row is None else (self.round_tables[row:row + b], self.round_counts[row:row + b])
             picks, npk = greedy_select(self.score[k][:b], self.n, 1, self.mrad, self.active[k][:b], self.selected[k][:b],
-                                       self.amask[k][:b], gb, out=dst)
+                                       self.amask[k][:b], gb, out=dst, score_range=None if self.rng[k] is None else self.rng[k][:b])
             self.slot_out[k] = dst
             if row is not None:
                 self.rows_done = max(self.rows_done, row + b)

@@ -36,7 +36,7 @@ SIGNATURES = {
     "halo_score_maps": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
                                _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_score_maps_timed": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
-                                     _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+                                     _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "halo_score_lr_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "halo_score_maps_lr": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                   _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -44,7 +44,7 @@ SIGNATURES = {
     "halo_score_maps_lr_gram": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_score_maps_lr_timed": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
-                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _int, _vp, _vp, _vp, _vp]),
+                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "halo_region_uncertainty": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "halo_region_impurity": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp]),
     "halo_quantize_radius": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _sz, _vp]),
@@ -62,6 +62,10 @@ SIGNATURES = {
     "halo_undo_picks": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "halo_device_identity": (_int, [_int, C.c_char_p, _sz]),
     "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "halo_score_range_bytes": (_sz, [_i64]),
+    "halo_score_range": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp]),
+    "halo_greedy_select_ranged": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _sz, _int, _vp, _vp]),
     "halo_greedy_select": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _sz, _int, _vp]),
 }

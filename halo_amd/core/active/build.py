@@ -18,18 +18,20 @@ from PIL import Image
 from ... import _lib
 from ..configs import cfg
 from ..utils.hyperbolic import HyperMapper, bilinear_align_corners
-from .floating_region import FloatingRegionScore, score_maps, score_maps_lowres, _workspace
+from .floating_region import FloatingRegionScore, new_score_range, score_maps, score_maps_lowres, _workspace
 
 
 def greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth,
-                  return_picks=True, method=None, out=None):
+                  return_picks=True, method=None, out=None, score_range=None):
     """Batched device-side selection.  score (B,H,W) f32|f64, active/selected (B,H,W) bool,
     active_mask/ground_truth (B,H,W) int64 -- all on one ROCm device, all mutated in place.
     Returns (picks (B,n,3) float64 rows (h, w, value), n_picked (B,) int32) or None.
     method: "auto" (default; environment HALO_SELECT overrides) = value-binned sweep with the serial kernel
     behind it, "serial" = the tile-table kernel only, "binned" = the sweep or HaloUnsupported.  Same results.
     out: optional (picks (B,n,3) float64, n_picked (B,) int32) contiguous device tensors to write the tables into
-    (pipelined callers collect a whole round's tables in one buffer); rows past an image's count are left as they are."""
+    (pipelined callers collect a whole round's tables in one buffer); rows past an image's count are left as they are.
+    score_range: the records score_maps / score_maps_lowres filled for these maps (new_score_range): the sweep then skips its
+    pass over the map for the value range (the records only have to bound the values: the picks do not depend on them)."""
     dev = _lib.require_device(score, active, selected, active_mask, ground_truth)
     B, H, W = score.shape
     for t in (score, active, selected, active_mask, ground_truth):
@@ -55,10 +57,12 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     method = _lib.SELECT[name]
     nws = L.halo_select_workspace_bytes(B, H, W, n, int(mask_radius)) if method != _lib.SELECT["serial"] else 256
     ws = _workspace(dev, nws, "select")
-    rc = L.halo_greedy_select(_lib.ptr(score), _lib.dtype_code(score), B, H, W, n, int(active_radius),
-                              int(mask_radius), _lib.ptr(active), _lib.ptr(selected), _lib.ptr(active_mask),
-                              _lib.ptr(ground_truth), _lib.ptr(picks), _lib.ptr(n_picked), _lib.ptr(ws), ws.numel(),
-                              method, _lib.stream_ptr(dev))
+    if score_range is not None:
+        assert score_range.is_contiguous() and score_range.device == dev and score_range.numel() >= L.halo_score_range_bytes(B)
+    rc = L.halo_greedy_select_ranged(_lib.ptr(score), _lib.dtype_code(score), B, H, W, n, int(active_radius),
+                                     int(mask_radius), _lib.ptr(active), _lib.ptr(selected), _lib.ptr(active_mask),
+                                     _lib.ptr(ground_truth), _lib.ptr(picks), _lib.ptr(n_picked), _lib.ptr(ws), ws.numel(),
+                                     method, _lib.ptr(score_range), _lib.stream_ptr(dev))
     _lib.check(rc, "halo_greedy_select")
     return (picks, n_picked) if return_picks else None
 
@@ -100,9 +104,11 @@ def acquire_batch(logit, decoder_out, ground_truth, active, selected, active_mas
     (build.py:137-160 for B images at once).  Mutates active/selected/active_mask; returns
     (picks (B,n,3), n_picked (B,))."""
     size = 2 * active_radius + 1 if size is None else size
+    # normalised maps are bounded by [0, 1]: the scorer hands the selector their range for free
+    rng = new_score_range(logit.shape[0], logit.device) if normalize and logit.shape[0] else None
     score, _, _ = score_maps(logit, decoder_out, unc_type, pur_type, normalize, ground_truth, size=size,
-                             purity_size=purity_size, K=K, c=c, active=active, want_maps=False)
-    return greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth)
+                             purity_size=purity_size, K=K, c=c, active=active, want_maps=False, score_range=rng)
+    return greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth, score_range=rng)
 
 
 def acquire_batch_lowres(logit_lr, decoder_lr, size, ground_truth, active, selected, active_mask, *, unc_type, pur_type,
@@ -112,16 +118,17 @@ def acquire_batch_lowres(logit_lr, decoder_lr, size, ground_truth, active, selec
     embedding is never materialised), then mask + greedy selection.  Falls back to explicit HIP
     upsampling when the fused kernel declines the geometry (strong downsampling)."""
     ksize = 2 * active_radius + 1 if ksize is None else ksize
+    rng = new_score_range(logit_lr.shape[0], logit_lr.device) if normalize and logit_lr.shape[0] else None
     try:
         score, _, _ = score_maps_lowres(logit_lr, decoder_lr, size, unc_type, pur_type, normalize, ground_truth,
                                         ksize=ksize, purity_size=purity_size, K=K, c=c, active=active, want_maps=False,
-                                        mode=lowres_mode)
+                                        mode=lowres_mode, score_range=rng)
     except _lib.HaloUnsupported:
         logit = bilinear_align_corners(logit_lr.float(), size)
         dec = bilinear_align_corners(decoder_lr, size) if pur_type in ("hyper", "radius", "euc_norm") else decoder_lr
         score, _, _ = score_maps(logit, dec, unc_type, pur_type, normalize, ground_truth, size=ksize,
-                                 purity_size=purity_size, K=K, c=c, active=active, want_maps=False)
-    return greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth)
+                                 purity_size=purity_size, K=K, c=c, active=active, want_maps=False, score_range=rng)
+    return greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth, score_range=rng)
 
 
 class AcquisitionParams:

@@ -37,15 +37,23 @@ def score_dtype(pur_type, decoder_out):
     return torch.float32
 
 
+def new_score_range(B, dev):
+    """Storage for the value-range records of B score maps (opaque, 64 bytes each): filled by score_maps /
+    score_maps_lowres (`score_range=`), consumed by greedy_select (`score_range=`), which then skips its own pass over the
+    map to find the range."""
+    n = _lib.lib().halo_score_range_bytes(1)
+    return torch.empty((int(B), int(n)), dtype=torch.uint8, device=dev)
+
+
 def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
-               size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, out=None, events=None):
+               size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, out=None, events=None, score_range=None):
     """Batched FloatingRegionScore.forward.
 
     logit (B,O,H,W) float32; decoder_out (B,C,H,W) float64|float32; ground_truth (B,H,W) int64;
     active (B,H,W) bool, optional: fuses `score[active] = -inf` (core/active/build.py:146).
     out: optional pre-allocated (B,H,W) score tensor to write into (pipelined callers own their
     buffers); events: optional (start, stop) handles from halo_event_create, recorded around the
-    feature-reduction kernel.
+    feature-reduction kernel; score_range: optional new_score_range(B, dev) to receive the maps' value ranges.
     Returns (score, impurity, uncertainty), each (B,H,W); the last two are None if not want_maps.
     """
     if pur_type not in _lib.PUR:
@@ -97,11 +105,13 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
     ws = _workspace(dev, nws, "score")
     psize = size if purity_size is None else purity_size
     ev0, ev1 = events if events is not None else (None, None)
+    if score_range is not None:
+        assert score_range.is_contiguous() and score_range.device == dev and score_range.numel() >= L.halo_score_range_bytes(B)
     rc = L.halo_score_maps_timed(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt),
                                  _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
                                  _lib.PUR[pur_type], 1 if normalize else 0, int(size), int(psize), int(K), float(c),
                                  _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
-                                 _lib.stream_ptr(dev), ev0, ev1)
+                                 _lib.stream_ptr(dev), ev0, ev1, _lib.ptr(score_range))
     _lib.check(rc, "halo_score_maps")
     return score, imp, unc
 
@@ -118,7 +128,8 @@ def lowres_mode(mode=None):
 
 
 def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
-                      ksize=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, mode=None, events=None):
+                      ksize=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, mode=None, events=None,
+                      score_range=None):
     """FloatingRegionScore.forward on the bilinear (align_corners=True) upsampling of LOW-RES sources to
     `size`, without materialising the upsampled tensors -- core/active/build.py:122-144 in one call.
     logit_lr (B,O,hl,wl) float32, decoder_lr (B,C,hf,wf) float64|float32.
@@ -168,9 +179,12 @@ def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, 
             _lib.PUR[pur_type], 1 if normalize else 0, int(ksize), int(psize), int(K), float(c),
             _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
             _lib.stream_ptr(dev))
-    if events is not None:      # (logit start, logit stop, embedding start, embedding stop) from halo_event_create, or None each
+    if events is not None or score_range is not None:
+        # events: (logit start, logit stop, embedding start, embedding stop) from halo_event_create, or None each
+        if score_range is not None:
+            assert score_range.is_contiguous() and score_range.device == dev and score_range.numel() >= L.halo_score_range_bytes(B)
         name = "halo_score_maps_lr_timed"
-        rc = L.halo_score_maps_lr_timed(*(args + (1 if gram else 0,) + tuple(events)))
+        rc = L.halo_score_maps_lr_timed(*(args + (1 if gram else 0,) + tuple(events or (None,) * 4) + (_lib.ptr(score_range),)))
     else:
         rc = fn(*args)
     _lib.check(rc, name)

@@ -16,6 +16,7 @@
 // what ATen's CPU norm(dim=1) computes.  Algorithmic traffic: C*sizeof(T) bytes per pixel.
 #include "halo_common.hpp"
 #include "halo_devmath.hpp"
+#include "halo_select_plan.hpp"      // SelHdr / order_key: the score-range record handed to the selector
 #include <stdlib.h>
 
 namespace halo {
@@ -62,10 +63,20 @@ __global__ void __launch_bounds__(TPB) k_minmax_finalize(const double *__restric
 // both maps of normalize_map in one launch: blockIdx.y = slot (0: impurity partials, 1: uncertainty partials).  1024
 // threads: the kernel is a dependent chain of loads on 2 B blocks, i.e. pure latency -- fewer trips per thread.
 constexpr int FIN_TPB = 1024;
+// rng (optional): the image's score-range record for the selector.  A normalised score is a product of two values in [0, 1]
+// (or NaN where a map is constant), so [0, 1] bounds it without a pass over the map; the combine kernel adds the "some pixel
+// is pickable" / "NaN present" facts.
 __global__ void __launch_bounds__(FIN_TPB) k_minmax_finalize2(const double *__restrict__ part0, int nblk0, const double *__restrict__ part1,
-                                                               int nblk1, double *__restrict__ stats)
+                                                               int nblk1, double *__restrict__ stats, SelHdr *__restrict__ rng)
 {
     const int b = blockIdx.x, slot = blockIdx.y;
+    if (rng && slot == 0 && threadIdx.x == 0) {
+        SelHdr h;
+        memset(&h, 0, sizeof(h));
+        h.kmin_inv = ~order_key(0.0);
+        h.kmax = order_key(1.0);
+        rng[b] = h;
+    }
     const int nblk = slot ? nblk1 : nblk0;
     const double2 *p = reinterpret_cast<const double2 *>((slot ? part1 : part0) + (size_t)b * nblk * 2);
     const double2 p0 = p[0];
@@ -856,11 +867,22 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
 // k_combine with the 3 x 3 box sum of the uncertainty recomputed from the entropy map (box3_row4: the same operations
 // that produced the min / max, so the same bits) instead of read from a stored copy: one kernel and one 4-byte map
 // less in the step's tail.  4 pixels per lane, 16-byte loads and stores.
+// What the selector needs to know about a normalised score map beyond its [0, 1] bound: is any pixel pickable (finite,
+// not masked), is a NaN / +inf present.  Ballots per wave, an atomic only while the record does not say so yet.
+__device__ __forceinline__ void report_range(SelHdr *__restrict__ rec, bool any_ok, bool any_bad)
+{
+    const unsigned long long okm = __ballot(any_ok), badm = __ballot(any_bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (okm && rec->nvalid == 0u) atomicAdd(&rec->nvalid, 1u);
+        if (badm && !(rec->flags & (unsigned)SEL_F_BAD)) atomicOr(&rec->flags, (unsigned)SEL_F_BAD);
+    }
+}
+
 template <typename TI>
 __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp_raw, const float *__restrict__ ent,
                                                       const double *__restrict__ stats, const unsigned char *__restrict__ active,
                                                       int H, int W, int pk, int normalize, TI *__restrict__ score,
-                                                      TI *__restrict__ imp_out, float *__restrict__ unc_out)
+                                                      TI *__restrict__ imp_out, float *__restrict__ unc_out, SelHdr *__restrict__ rng)
 {
     const int b = blockIdx.y;
     const long long hw = (long long)H * W;
@@ -911,6 +933,17 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
         if (imp_out) *reinterpret_cast<float4 *>(imp_out + o) = make_float4(im[0], im[1], im[2], im[3]);
     }
     if (unc_out) *reinterpret_cast<float4 *>(unc_out + o) = make_float4(un[0], un[1], un[2], un[3]);
+    if (rng) {
+        bool ok = false, bad = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool fin = sc[j] >= (TI)0 && sc[j] <= (TI)1;              // a pickable value; false for NaN, +-inf
+            const bool masked = sc[j] < (TI)0 && sc[j] == sc[j] + sc[j];    // -inf (`score[active] = -inf`)
+            ok = ok || fin;
+            bad = bad || !(fin || masked);                                   // NaN, +inf, or anything the [0, 1] bound does not cover
+        }
+        report_range(rng + b, ok, bad);
+    }
 }
 
 
@@ -1753,7 +1786,7 @@ extern "C" int halo_score_maps(const float *logit, int64_t logit_bstride, const 
 {
     return halo_score_maps_timed(logit, logit_bstride, feat, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type,
                                  pur_type, normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace,
-                                 workspace_bytes, stream, nullptr, nullptr);
+                                 workspace_bytes, stream, nullptr, nullptr, nullptr);
 }
 
 extern "C" size_t halo_score_lr_workspace_bytes(int64_t B, int64_t O, int64_t H, int64_t W)
@@ -1841,7 +1874,8 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
                       int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
                       int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                       void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
-                      void *ev_feat_stop, const LrDims *lr, void *ev_logit_start = nullptr, void *ev_logit_stop = nullptr)
+                      void *ev_feat_stop, const LrDims *lr, void *ev_logit_start = nullptr, void *ev_logit_stop = nullptr,
+                      void *score_range = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
@@ -1998,15 +2032,22 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     }
 
     // ---- global min/max (normalize_map only), then normalise + product
+    // the score's value range for the selector: free when the maps are normalised and the fused combine kernel runs (the
+    // product of two values in [0, 1]); otherwise the exact reduction, here instead of in the selector
+    SelHdr *rng_free = (score_range && normalize && fuse_tail) ? (SelHdr *)score_range : nullptr;
     if (normalize)
         hipLaunchKernelGGL(k_minmax_finalize2, dim3((unsigned)B, 2u), dim3(FIN_TPB), 0, st, (const double *)part_imp, nblk_imp,
-                           (const double *)part_unc, nblk_unc, stats);
+                           (const double *)part_unc, nblk_unc, stats, rng_free);
     if (fuse_tail) {
         dim3 gridc((unsigned)nblk_c3, (unsigned)B);
-        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty);
-        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty);
+        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty, rng_free);
+        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty, rng_free);
     } else if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
+    if (score_range && !rng_free) {
+        const int rc = score_range_exact(score, f64out ? HALO_F64 : HALO_F32, B, hw, score_range, st);
+        if (rc != HALO_OK) return rc;
+    }
     return check_launch("halo_score_maps");
 }
 
@@ -2081,11 +2122,11 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
                                      int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
                                      int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                                      void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
-                                     void *ev_feat_stop)
+                                     void *ev_feat_stop, void *score_range)
 {
     return score_impl(logit, logit_bstride, feat, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
                       normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream,
-                      ev_feat_start, ev_feat_stop, nullptr);
+                      ev_feat_start, ev_feat_stop, nullptr, nullptr, nullptr, score_range);
 }
 
 // FloatingRegionScore.forward on bilinearly upsampled (align_corners=True) low-resolution sources
@@ -2131,7 +2172,8 @@ extern "C" int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bst
                                         const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
                                         int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
                                         void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream,
-                                        int gram, void *ev_logit_start, void *ev_logit_stop, void *ev_feat_start, void *ev_feat_stop)
+                                        int gram, void *ev_logit_start, void *ev_logit_stop, void *ev_feat_start, void *ev_feat_stop,
+                                        void *score_range)
 {
     if (hl <= 0 || wl <= 0) return fail(HALO_E_ARG, "halo_score_maps_lr_timed: bad low-res logit size");
     const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
@@ -2141,5 +2183,5 @@ extern "C" int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bst
     LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf, gram != 0};
     return score_impl(logit_lr, logit_bstride, feat_lr, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
                       normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream, ev_feat_start,
-                      ev_feat_stop, &lr, ev_logit_start, ev_logit_stop);
+                      ev_feat_stop, &lr, ev_logit_start, ev_logit_stop, score_range);
 }

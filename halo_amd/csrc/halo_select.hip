@@ -313,6 +313,25 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
                                   int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                                   void *workspace, size_t workspace_bytes, int method, void *stream)
 {
+    return halo_greedy_select_ranged(score, dtype, B, H, W, n_regions, active_radius, mask_radius, active, selected, active_mask, gt,
+                                     picks, n_picked, workspace, workspace_bytes, method, nullptr, stream);
+}
+
+extern "C" size_t halo_score_range_bytes(int64_t B) { return B > 0 ? (size_t)B * sizeof(SelHdr) : 0; }
+
+extern "C" int halo_score_range(const void *score, int dtype, int64_t B, int64_t H, int64_t W, void *score_range, void *stream)
+{
+    if (!score || !score_range || B <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_range: null/empty argument");
+    if (dtype != HALO_F32 && dtype != HALO_F64) return fail(HALO_E_ARG, "halo_score_range: bad dtype");
+    const int rc = score_range_exact(score, dtype, B, H * W, score_range, (hipStream_t)stream);
+    return rc != HALO_OK ? rc : check_launch("halo_score_range");
+}
+
+extern "C" int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,
+                                         int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
+                                         int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
+                                         void *workspace, size_t workspace_bytes, int method, const void *score_range, void *stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (!score || !active || !selected || !active_mask || !gt || B <= 0 || H <= 0 || W <= 0)
         return fail(HALO_E_ARG, "halo_greedy_select: null/empty argument");
@@ -335,7 +354,7 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
         if (p.ok) {
             SelHdr *hdr = nullptr;
             const int rc = binned_select(score, dtype, B, p, active, selected, active_mask, gt, picks, n_picked, workspace,
-                                         workspace_bytes, st, &hdr);
+                                         workspace_bytes, st, &hdr, score_range);
             if (rc != HALO_OK) return rc;
             resume = hdr;
         } else if (method == HALO_SELECT_BINNED)

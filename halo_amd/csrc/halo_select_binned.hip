@@ -17,9 +17,9 @@
 //   k_sel_range    min / max of the finite values, count of pickable pixels
 //   k_sel_hist1    2048 equal-width coarse bins over [min, max]                      (LDS histograms)
 //   k_sel_scan1    threshold bin t1 (top-K), every coarse bin split into count/target equal sub-bins
-//   k_sel_compact  pixels >= t1 -> staging list (key, pos, fine bin) + fine-bin histogram
-//   k_sel_scan2    fine-bin offsets
-//   k_sel_scatter  staging list -> candidates grouped by fine bin, bins in descending value order
+//   k_sel_place    pixels >= t1 -> a slot of their fine bin (one returned atomic per candidate; bins have BIN_CAP slots
+//                  and are numbered in descending value order) -- round 2 went through a staging list, a fine histogram,
+//                  a prefix scan and a scatter pass
 //   k_sel_sweep    ONE workgroup per image walks the bins: filter a bin's candidates against the
 //                  pick grid (4 waves, one candidate per lane), then wave 0 takes the survivors
 //                  in exact (value, w, h) order with a register-resident arg-max loop
@@ -29,8 +29,8 @@
 // bins are monotone in the value, so the result is the reference's sequence bit for bit.
 //
 // The sweep gives up ("bail") where its assumptions do not hold -- NaN or +inf in the map, a
-// constant map, a bin with more than 256 unsuppressed candidates (plateaus of exact ties), or
-// candidates exhausted after the threshold bin had to be dropped -- and leaves the image, in the
+// constant map, a fine bin with more candidates than slots or more than 256 unsuppressed ones (plateaus of exact ties),
+// or candidates exhausted after the threshold bin had to be dropped -- and leaves the image, in the
 // exact state the reference would have after `np` picks, to the serial kernel of halo_select.hip,
 // which is enqueued behind it and returns immediately for images that are done.
 #include <stdlib.h>
@@ -46,14 +46,16 @@ constexpr int SW_SURV = 256;     // survivor capacity of one bin (4 per lane of 
 constexpr int FWIN = 1024;       // fine-bin offsets staged in LDS at a time
 
 // per-image arrays: element [b * stride + i]
+constexpr int BIN_CAP = 256;     // slots per fine bin (expected occupancy <= target = 128: equal-width sub-bins of a 1/2048 slice of
+                                 // the value range are Poisson-filled; a fuller bin -- a plateau of ties -- hands the image over)
+
 struct BinWs {
     SelHdr *hdr;
+    const SelHdr *rng;                       // where the value range lives: hdr, or the scorer's range record (halo_score_range_t)
     unsigned *hist1, *cbase, *cm;            // NB1 each
-    unsigned *fhist, *fcur;                  // nfmax each
-    unsigned *foff;                          // nfmax + 1
-    uint4 *tmp;                              // captot: (key lo, key hi, pos, fine bin)
-    unsigned long long *ckey;                // captot
-    unsigned *cpos;                          // captot
+    unsigned *fcur;                          // nfmax: candidates placed in each fine bin
+    unsigned long long *ckey;                // nfmax * BIN_CAP: bin f owns slots [f * BIN_CAP, (f + 1) * BIN_CAP)
+    unsigned *cpos;                          // nfmax * BIN_CAP
     unsigned *plist;                         // n_regions: picks as (w << 16) | h
 };
 
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(256) k_sel_hist1(const T *__restrict__ score, 
 {
     __shared__ unsigned h[NB1];
     const int b = blockIdx.y;
-    const ValRange r = sel_range(ws.hdr[b]);
+    const ValRange r = sel_range(ws.rng[b]);
     if (!r.ok) return;
     for (int j = threadIdx.x; j < NB1; j += 256) h[j] = 0;
     __syncthreads();
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256) k_sel_scan1(BinWs ws, BinGeom g)
     __shared__ unsigned sc_c[256], sc_m[256], s_t1;
     const int b = blockIdx.x, tid = threadIdx.x;
     SelHdr *hdr = ws.hdr + b;
-    const ValRange r = sel_range(*hdr);
+    const ValRange r = sel_range(ws.rng[b]);
     const unsigned *hist = ws.hist1 + (size_t)b * NB1;
     unsigned c[8], m[8], tc = 0, tm = 0;
 #pragma unroll
@@ -229,23 +231,29 @@ __global__ void __launch_bounds__(256) k_sel_scan1(BinWs ws, BinGeom g)
     }
 }
 
-// ------------------------------------------------------------------ candidates -> staging list
+// ------------------------------------------------------------------ candidates -> their fine bins, in one pass
+// Round 3: a candidate goes straight to a slot of its fine bin -- one returned atomic on the bin's counter, two stores --
+// instead of staging list -> fine histogram -> prefix scan -> scatter (round 2: two atomics and a 16-byte round trip per
+// candidate, three launches).  Bins have BIN_CAP slots; a candidate that finds its bin full marks the image SEL_F_OVERFLOW and
+// the sweep hands it over untouched.
 template <typename T>
-__global__ void __launch_bounds__(256) k_sel_compact(const T *__restrict__ score, BinWs ws, BinGeom g)
+__global__ void __launch_bounds__(256) k_sel_place(const T *__restrict__ score, BinWs ws, BinGeom g)
 {
     __shared__ unsigned s_base[NB1], s_m[NB1];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.y, tid = threadIdx.x;
     SelHdr *hdr = ws.hdr + b;
-    const ValRange r = sel_range(*hdr);
+    const ValRange r = sel_range(ws.rng[b]);
     const unsigned t1 = hdr->t1;
     if (!r.ok || t1 >= NB1) return;
     for (int j = tid; j < NB1; j += 256) { s_base[j] = ws.cbase[(size_t)b * NB1 + j]; s_m[j] = ws.cm[(size_t)b * NB1 + j]; }
     __syncthreads();
     const T *sc = score + (size_t)b * g.H * g.W;
-    unsigned *fhist = ws.fhist + (size_t)b * g.nfmax;
-    uint4 *tmp = ws.tmp + (size_t)b * g.captot;
-    // four row segments per iteration: their loads, their histogram atomics and ONE staging-list append per wave are in
-    // flight together (beside a bandwidth-bound kernel each dependent round trip costs microseconds)
+    unsigned *fcur = ws.fcur + (size_t)b * g.nfmax;
+    unsigned long long *ckey = ws.ckey + (size_t)b * g.nfmax * BIN_CAP;
+    unsigned *cpos = ws.cpos + (size_t)b * g.nfmax * BIN_CAP;
+    bool overflow = false;
+    // four row segments per iteration: their loads and their returned atomics are in flight together (beside a
+    // bandwidth-bound kernel each dependent round trip costs microseconds)
     for (int y = blockIdx.x; y < g.H; y += gridDim.x)
         for (int x0 = 0; x0 < g.W; x0 += 4 * 256) {
             double v[4];
@@ -254,8 +262,8 @@ __global__ void __launch_bounds__(256) k_sel_compact(const T *__restrict__ score
                 const int x = x0 + u * 256 + tid;
                 v[u] = x < g.W ? (double)sc[(size_t)y * g.W + x] : __longlong_as_double(0xfff0000000000000ll);    // -inf: never a candidate
             }
-            unsigned long long k[4], mask[4];
-            unsigned f[4], total = 0;
+            unsigned long long k[4];
+            unsigned f[4], slot[4];
             bool cand[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -270,94 +278,21 @@ __global__ void __launch_bounds__(256) k_sel_compact(const T *__restrict__ score
                     unsigned sb = (unsigned)((t - (double)j) * (double)mj);      // sub-bin inside the coarse bin, monotone in v
                     sb = sb > mj - 1 ? mj - 1 : sb;
                     f[u] = s_base[j] + (mj - 1 - sb);
-                    atomicAdd(&fhist[f[u]], 1u);
-                }
-                mask[u] = __ballot(cand[u]);
-                total += (unsigned)__builtin_popcountll(mask[u]);
-            }
-            if (total) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&hdr->ncand, total);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (cand[u]) {
-                        const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
-                        const int x = x0 + u * 256 + tid;
-                        if (slot < g.captot) tmp[slot] = make_uint4((unsigned)k[u], (unsigned)(k[u] >> 32), ((unsigned)x << 16) | (unsigned)y, f[u]);
-                    }
-                    base += (unsigned)__builtin_popcountll(mask[u]);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) slot[u] = cand[u] ? atomicAdd(&fcur[f[u]], 1u) : 0u;      // four returns in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (cand[u]) {
+                    if (slot[u] < (unsigned)BIN_CAP) {
+                        const size_t sl = (size_t)f[u] * BIN_CAP + slot[u];
+                        ckey[sl] = k[u];
+                        cpos[sl] = ((unsigned)(x0 + u * 256 + tid) << 16) | (unsigned)y;
+                    } else overflow = true;
+                }
         }
-}
-
-// ------------------------------------------------------------------ fine-bin offsets
-__global__ void __launch_bounds__(256) k_sel_scan2(BinWs ws, BinGeom g)
-{
-    __shared__ unsigned part[256], carry;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const unsigned nf = ws.hdr[b].nf;
-    const unsigned *fhist = ws.fhist + (size_t)b * g.nfmax;
-    unsigned *foff = ws.foff + (size_t)b * (g.nfmax + 1);
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (unsigned base = 0; base < nf; base += 2048) {
-        unsigned v[8], tot = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const unsigned idx = base + tid * 8 + i;
-            v[i] = idx < nf ? fhist[idx] : 0u;
-            tot += v[i];
-        }
-        part[tid] = tot;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {                       // inclusive prefix scan
-            const unsigned a = tid >= d ? part[tid - d] : 0u;
-            __syncthreads();
-            part[tid] += a;
-            __syncthreads();
-        }
-        unsigned run = carry + (tid ? part[tid - 1] : 0u);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const unsigned idx = base + tid * 8 + i;
-            if (idx < nf) foff[idx] = run;
-            run += v[i];
-        }
-        __syncthreads();
-        if (tid == 255) carry = run;
-        __syncthreads();
-    }
-    if (tid == 0) foff[nf] = carry;
-}
-
-// ------------------------------------------------------------------ staging list -> bins
-__global__ void __launch_bounds__(256) k_sel_scatter(BinWs ws, BinGeom g)
-{
-    const int b = blockIdx.y;
-    const unsigned n = ws.hdr[b].ncand < g.captot ? ws.hdr[b].ncand : g.captot;
-    const uint4 *tmp = ws.tmp + (size_t)b * g.captot;
-    const unsigned *foff = ws.foff + (size_t)b * (g.nfmax + 1);
-    unsigned *fcur = ws.fcur + (size_t)b * g.nfmax;
-    unsigned long long *ckey = ws.ckey + (size_t)b * g.captot;
-    unsigned *cpos = ws.cpos + (size_t)b * g.captot;
-    const unsigned stride = gridDim.x * 256;
-    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += 4 * stride) {
-        uint4 c[4];
-        unsigned slot[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = e + u * stride < n ? tmp[e + u * stride] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) slot[u] = e + u * stride < n ? atomicAdd(&fcur[c[u].w], 1u) : 0u;     // four returns in flight
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e + u * stride < n) {
-                const unsigned sl = foff[c[u].w] + slot[u];
-                ckey[sl] = ((unsigned long long)c[u].y << 32) | c[u].x;
-                cpos[sl] = c[u].z;
-            }
-    }
+    if (__any(overflow) && (tid & 63) == 0) atomicOr(&hdr->flags, (unsigned)SEL_F_OVERFLOW);
 }
 
 // ------------------------------------------------------------------ resolve one bin (one wave)
@@ -495,10 +430,11 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     SelHdr *hdr = ws.hdr + b;
     const unsigned nf = hdr->nf;
     const bool truncated = hdr->truncated != 0;
-    const unsigned *foff = ws.foff + (size_t)b * (g.nfmax + 1);
-    const unsigned long long *ckey = ws.ckey + (size_t)b * g.captot;
-    const unsigned *cpos = ws.cpos + (size_t)b * g.captot;
+    const unsigned *fcnt = ws.fcur + (size_t)b * g.nfmax;
+    const unsigned long long *ckey = ws.ckey + (size_t)b * g.nfmax * BIN_CAP;
+    const unsigned *cpos = ws.cpos + (size_t)b * g.nfmax * BIN_CAP;
     unsigned *plist = ws.plist + (size_t)b * g.n_regions;
+    const bool overflowed = (hdr->flags & SEL_F_OVERFLOW) != 0u;       // a fine bin ran out of slots: hand the image over untouched
 
     for (unsigned i = tid * 16; i < g.grid_bytes; i += SW_TPB * 16) *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
@@ -514,7 +450,7 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     // microseconds, a chunk only ~1 us.  The three register sets rotate by unrolling the loop body three times, so the
     // compiler's counted s_waitcnt vmcnt waits for the oldest set only.
     struct Chunk { unsigned start, cnt; bool last, valid; };
-    unsigned fw0 = 0, fwn = 0;                   // fwin holds foff[fw0 .. fw0 + fwn]
+    unsigned fw0 = 0, fwn = 0;                   // fwin holds the candidate counts of bins fw0 .. fw0 + fwn - 1
     unsigned it_f = 0xffffffffu, it_c = 0, it_e = 0;         // iterator: bin, next chunk start, bin end
     auto next_chunk = [&]() {
         Chunk c;
@@ -526,11 +462,11 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
                 lds_barrier();
                 fw0 = it_f;
                 fwn = nf - it_f < (unsigned)FWIN ? nf - it_f : (unsigned)FWIN;
-                for (unsigned i = tid; i <= fwn; i += SW_TPB) fwin[i] = foff[fw0 + i];
+                for (unsigned i = tid; i < fwn; i += SW_TPB) fwin[i] = fcnt[fw0 + i];
                 __syncthreads();
             }
-            it_c = fwin[it_f - fw0];
-            it_e = fwin[it_f - fw0 + 1];
+            it_c = it_f * (unsigned)BIN_CAP;
+            it_e = it_c + (fwin[it_f - fw0] < (unsigned)BIN_CAP ? fwin[it_f - fw0] : (unsigned)BIN_CAP);
         }
         c.start = it_c;
         c.cnt = it_e - it_c < (unsigned)SW_TPB ? it_e - it_c : (unsigned)SW_TPB;
@@ -610,6 +546,7 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
         ++nb;
 #endif
     };
+    if (overflowed) fin = 2;
     Chunk c0 = next_chunk(), c1, c2;
     Regs d0, d1, d2;
     issue(c0, d0);
@@ -737,37 +674,47 @@ BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t 
     auto take = [&](size_t per_image) { const size_t at = o; o += align_up(per_image * (size_t)B, 256); return at; };
     p.off_hdr = take(sizeof(SelHdr));
     p.off_hist1 = take((size_t)NB1 * 4);
-    p.off_fhist = take((size_t)g.nfmax * 4);
     p.off_fcur = take((size_t)g.nfmax * 4);
     p.zero_bytes = o;                                       // everything above is cleared at the start of a call
     p.off_cbase = take((size_t)NB1 * 4);
     p.off_cm = take((size_t)NB1 * 4);
-    p.off_foff = take(((size_t)g.nfmax + 1) * 4);
-    p.off_tmp = take((size_t)g.captot * 16);
-    p.off_ckey = take((size_t)g.captot * 8);
-    p.off_cpos = take((size_t)g.captot * 4);
+    p.off_ckey = take((size_t)g.nfmax * BIN_CAP * 8);
+    p.off_cpos = take((size_t)g.nfmax * BIN_CAP * 4);
     p.off_plist = take((size_t)g.n_regions * 4);
     p.total_bytes = o + 256;
     p.ok = true;
     return p;
 }
 
+// The exact value range of score maps as the record halo_greedy_select_ranged accepts (also the scorer's fallback when it
+// cannot bound the range for free): zero the records, then the same reduction the selector runs on its own.
+int score_range_exact(const void *score, int dtype, int64_t B, int64_t hw, void *range_out, hipStream_t st)
+{
+    if (hipMemsetAsync(range_out, 0, (size_t)B * sizeof(SelHdr), st) != hipSuccess) return fail(HALO_E_LAUNCH, "score range: memset failed");
+    BinWs ws;
+    memset(&ws, 0, sizeof(ws));
+    ws.hdr = (SelHdr *)range_out;
+    ws.rng = ws.hdr;
+    const unsigned gx = (unsigned)(cdiv(hw, 256) < 128 ? cdiv(hw, 256) : 128);
+    if (dtype == HALO_F64) hipLaunchKernelGGL(k_sel_range<double>, dim3(gx, (unsigned)B), dim3(256), 0, st, (const double *)score, (long long)hw, ws);
+    else hipLaunchKernelGGL(k_sel_range<float>, dim3(gx, (unsigned)B), dim3(256), 0, st, (const float *)score, (long long)hw, ws);
+    return HALO_OK;
+}
+
 int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *active, uint8_t *selected, int64_t *active_mask,
                   const int64_t *gt, double *picks, int32_t *n_picked, void *workspace, size_t workspace_bytes, hipStream_t st,
-                  SelHdr **hdr_out)
+                  SelHdr **hdr_out, const void *score_range)
 {
     if (!workspace || workspace_bytes < p.total_bytes) return fail(HALO_E_WORKSPACE, "halo_greedy_select: workspace too small");
     char *base = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if ((size_t)(base - (char *)workspace) + p.total_bytes - 256 > workspace_bytes) return fail(HALO_E_WORKSPACE, "halo_greedy_select: workspace too small");
     BinWs ws;
     ws.hdr = (SelHdr *)(base + p.off_hdr);
+    ws.rng = score_range ? (const SelHdr *)score_range : ws.hdr;      // the scorer already knows the range: no pass over the map
     ws.hist1 = (unsigned *)(base + p.off_hist1);
-    ws.fhist = (unsigned *)(base + p.off_fhist);
     ws.fcur = (unsigned *)(base + p.off_fcur);
     ws.cbase = (unsigned *)(base + p.off_cbase);
     ws.cm = (unsigned *)(base + p.off_cm);
-    ws.foff = (unsigned *)(base + p.off_foff);
-    ws.tmp = (uint4 *)(base + p.off_tmp);
     ws.ckey = (unsigned long long *)(base + p.off_ckey);
     ws.cpos = (unsigned *)(base + p.off_cpos);
     ws.plist = (unsigned *)(base + p.off_plist);
@@ -780,18 +727,15 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     const unsigned gy = (unsigned)(g.H < 128 ? g.H : 128);
     dim3 blk(256);
     if (dtype == HALO_F64) {
-        hipLaunchKernelGGL(k_sel_range<double>, dim3(gx, (unsigned)B), blk, 0, st, (const double *)score, hw, ws);
+        if (!score_range) hipLaunchKernelGGL(k_sel_range<double>, dim3(gx, (unsigned)B), blk, 0, st, (const double *)score, hw, ws);
         hipLaunchKernelGGL(k_sel_hist1<double>, dim3(gx, (unsigned)B), blk, 0, st, (const double *)score, hw, ws);
     } else {
-        hipLaunchKernelGGL(k_sel_range<float>, dim3(gx, (unsigned)B), blk, 0, st, (const float *)score, hw, ws);
+        if (!score_range) hipLaunchKernelGGL(k_sel_range<float>, dim3(gx, (unsigned)B), blk, 0, st, (const float *)score, hw, ws);
         hipLaunchKernelGGL(k_sel_hist1<float>, dim3(gx, (unsigned)B), blk, 0, st, (const float *)score, hw, ws);
     }
     hipLaunchKernelGGL(k_sel_scan1, dim3((unsigned)B), blk, 0, st, ws, g);
-    if (dtype == HALO_F64) hipLaunchKernelGGL(k_sel_compact<double>, dim3(gy, (unsigned)B), blk, 0, st, (const double *)score, ws, g);
-    else hipLaunchKernelGGL(k_sel_compact<float>, dim3(gy, (unsigned)B), blk, 0, st, (const float *)score, ws, g);
-    hipLaunchKernelGGL(k_sel_scan2, dim3((unsigned)B), blk, 0, st, ws, g);
-    const unsigned gs = (unsigned)(cdiv(g.captot, 256) < 256 ? cdiv(g.captot, 256) : 256);
-    hipLaunchKernelGGL(k_sel_scatter, dim3(gs, (unsigned)B), blk, 0, st, ws, g);
+    if (dtype == HALO_F64) hipLaunchKernelGGL(k_sel_place<double>, dim3(gy, (unsigned)B), blk, 0, st, (const double *)score, ws, g);
+    else hipLaunchKernelGGL(k_sel_place<float>, dim3(gy, (unsigned)B), blk, 0, st, (const float *)score, ws, g);
     static LdsLimitSeen seen;      // the pick grid may need more than the default 64 KiB of dynamic LDS
     if (!raise_lds_limit(seen, (const void *)k_sel_sweep, 160 * 1024))
         return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");

@@ -89,6 +89,7 @@ struct SelHdr {
 };
 static_assert(sizeof(SelHdr) == 64, "SelHdr is 64 bytes");
 enum { SEL_RUN = 0, SEL_DONE = 1, SEL_BAIL = 2 };
-enum { SEL_F_BAD = 1 };            // NaN or +inf present: the value range cannot be binned
+enum { SEL_F_BAD = 1,              // NaN or +inf present: the value range cannot be binned
+       SEL_F_OVERFLOW = 2 };       // a fine bin received more candidates than it has slots (a plateau of ties)
 
 }  // namespace halo

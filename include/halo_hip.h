@@ -112,13 +112,16 @@ int halo_score_maps(const float *logit, int64_t logit_bstride, const void *feat,
 
 /* Same call with two optional hipEvent_t (as void*, from halo_event_create) recorded on `stream`
  * immediately before and after the feature-reduction kernel (k_feat_reduce, the HBM-roofline
- * kernel) -- used by bench.py to time that kernel live inside the pipelined run. */
+ * kernel) -- used by bench.py to time that kernel live inside the pipelined run -- and an optional
+ * `score_range` output (B records of halo_score_range_bytes(1) bytes, NULL = none): the value range of each
+ * score map in the form halo_greedy_select_ranged accepts, so that the selector need not read the map once more
+ * to find it.  Free when the maps are normalised (a product of two values in [0, 1]); otherwise reduced exactly. */
 int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
                           int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
                           int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
                           int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                           void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
-                          void *ev_feat_stop);
+                          void *ev_feat_stop, void *score_range);
 
 /* The same forward on LOW-RESOLUTION sources, fusing RegionSelection's two F.interpolate calls
  * (core/active/build.py:122-135) into the scorer: logit_lr (B,O,hl,wl) f32 and feat_lr (B,C,hf,wf)
@@ -155,7 +158,8 @@ int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bstride, int64
                              const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
                              int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
                              void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream,
-                             int gram, void *ev_logit_start, void *ev_logit_stop, void *ev_feat_start, void *ev_feat_stop);
+                             int gram, void *ev_logit_start, void *ev_logit_stop, void *ev_feat_start, void *ev_feat_stop,
+                             void *score_range);
 
 /* Helper methods of FloatingRegionScore that are public by convention:
  *  - compute_region_uncertainty(unc_type, logit, p, ground_truth) / compute_pixel_entropy(p)
@@ -196,6 +200,16 @@ int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, 
                        int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
                        int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                        void *workspace, size_t workspace_bytes, int method, void *stream);
+
+/* halo_greedy_select given the value range of each score map (`score_range`: B records from halo_score_maps_timed /
+ * halo_score_maps_lr_timed or halo_score_range; NULL = find it here).  The range only has to BOUND the finite values: the
+ * binning is monotone, so the picks do not depend on it.  halo_score_range computes the exact records of existing maps. */
+size_t halo_score_range_bytes(int64_t B);
+int halo_score_range(const void *score, int dtype, int64_t B, int64_t H, int64_t W, void *score_range, void *stream);
+int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,
+                              int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
+                              int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
+                              void *workspace, size_t workspace_bytes, int method, const void *score_range, void *stream);
 
 /* ---- pool side of the round: image-wise sharding, ONE all-gather of pick tables (the reference runs the
  * round on rank 0 only, core/train_learners.py:307-326) ----

@@ -1,7 +1,7 @@
 """Numpy model of the value-binned selector (halo_amd/csrc/halo_select_binned.hip) -- TEST INFRASTRUCTURE.
 
 It restates the kernels' host-visible logic step by step (range -> coarse histogram -> threshold and
-sub-bin layout -> fine bins -> sweep over the bins with a pick grid -> bail conditions) so that the
+sub-bin layout -> fine bins (BIN_CAP slots each) -> sweep over the bins with a pick grid -> bail conditions) so that the
 ALGORITHM can be checked against the CPU oracle without a GPU: same candidate bound, same bin
 arithmetic (IEEE double, truncation), same bail rules.  The product never imports this file.
 """
@@ -9,6 +9,7 @@ import numpy as np
 
 NB1 = 2048
 SW_SURV = 256
+BIN_CAP = 256     # slots per fine bin (k_sel_place): a fuller bin hands the image over untouched
 
 
 def order_key(v):
@@ -74,6 +75,9 @@ def binned_select(score, n_regions, mrad, target=128, captot=None):
     kk = key[cand]
     pos = (xs.astype(np.int64) << 16) | ys
     stats["ncand"] = int(cand.sum())
+    if len(f) and np.bincount(f).max() > BIN_CAP:
+        stats["reason"] = "overflow"
+        return "bail", [], stats
     order = np.argsort(f, kind="stable")
     f, kk, pos, ys, xs = f[order], kk[order], pos[order], ys[order], xs[order]
     # sweep

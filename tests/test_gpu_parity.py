@@ -742,6 +742,58 @@ def test_gram_mode_full_size_vs_oracle(dev):
     print("gram vs upsample-then-score, %d full-size images: max |map difference| %.3g" % (n_images, worst))
 
 
+def test_selection_with_the_scorers_range_records(dev):
+    """Round 3: the scorer hands the selector the value range of its score maps (free for normalised maps: a product of two
+    values in [0, 1]; the exact reduction otherwise), and the sweep skips its own pass over the map.  The binning is monotone
+    whatever the bounds, so picks, tables and masks must be bit-identical to the selection that finds the range itself --
+    HALO branch, the un-normalised ripu branch, prior-pick masks, a fully masked image, a constant (NaN after normalisation)
+    map, float32 and float64 scores, the low-res entry points."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import new_score_range, score_maps, score_maps_lowres
+    rng = np.random.default_rng(404)
+    H, W, C, O, B, n = 96, 160, 12, 19, 4, 60
+    for dt in (np.float64, np.float32):
+        logit = rng.standard_normal((B, O, H, W)).astype(np.float32)
+        emb = (rng.standard_normal((B, C, H, W)) * 0.05).astype(dt)
+        emb[2] = emb[2, :, :1, :1]                                        # constant radius map -> 0/0 = NaN after normalisation
+        gt = rng.integers(0, O, (B, H, W)).astype(np.int64)
+        act = rng.random((B, H, W)) < 0.05
+        act[1] = True                                                     # nothing pickable
+        for unc, pur, norm in (("entropy", "radius", True), ("entropy", "ripu", False), ("entropy", "hyper", True), ("entropy", "radius", False)):
+            res = []
+            for ranged in (False, True):
+                rec = new_score_range(B, dev) if ranged else None
+                a, sl, am = t(act, dev), torch.zeros((B, H, W), dtype=torch.bool, device=dev), torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+                sc = score_maps(t(logit, dev), t(emb, dev), unc, pur, norm, t(gt, dev), size=3, K=20, active=a, want_maps=False,
+                                score_range=rec)[0]
+                pk, nk = greedy_select(sc, n, 1, 5, a, sl, am, t(gt, dev), score_range=rec)
+                res.append((pk.cpu().numpy(), nk.cpu().numpy(), a.cpu().numpy(), sl.cpu().numpy(), am.cpu().numpy(), sc.cpu().numpy()))
+            for x, y in zip(res[0], res[1]):
+                assert bits_equal(x, y) if x.dtype.kind == "f" else np.array_equal(x, y), (dt, unc, pur, norm)
+            assert res[0][1][1] == 0                                      # the fully masked image picks nothing either way
+    # the exact records of an existing map == what the selector finds itself; low-res entry point
+    from halo_amd import _lib
+    sc = t(rng.standard_normal((2, H, W)), dev)
+    rec = new_score_range(2, dev)
+    _lib.check(_lib.lib().halo_score_range(_lib.ptr(sc), _lib.dtype_code(sc), 2, H, W, _lib.ptr(rec), _lib.stream_ptr(dev)), "halo_score_range")
+    outs = []
+    for r_ in (None, rec):
+        s2 = sc.clone()
+        a, sl, am = (torch.zeros((2, H, W), dtype=torch.bool, device=dev) for _ in range(2)) , None, None
+        a, sl = a
+        am = torch.full((2, H, W), 255, dtype=torch.int64, device=dev)
+        outs.append(greedy_select(s2, n, 1, 5, a, sl, am, t(gt[:2], dev), score_range=r_)[0].cpu().numpy())
+    assert bits_equal(outs[0], outs[1])
+    lg, em = t(rng.standard_normal((1, O, 24, 40)).astype(np.float32), dev), t(rng.standard_normal((1, C, 12, 20)) * 0.1, dev)
+    outs = []
+    for ranged in (False, True):
+        rec = new_score_range(1, dev) if ranged else None
+        sc = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, want_maps=False, score_range=rec)[0]
+        a, sl, am = torch.zeros((1, H, W), dtype=torch.bool, device=dev), torch.zeros((1, H, W), dtype=torch.bool, device=dev), torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+        outs.append(greedy_select(sc, n, 1, 5, a, sl, am, t(gt[:1], dev), score_range=rec)[0].cpu().numpy())
+    assert bits_equal(outs[0], outs[1])
+
+
 def test_lowres_gram_mode_on_degenerate_grids(dev):
     """single-row / single-column / single-pixel embeddings, odd sizes around the 63-column wave width"""
     from halo_amd.core.active.floating_region import score_maps_lowres
