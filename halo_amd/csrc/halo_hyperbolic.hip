@@ -74,7 +74,11 @@ __device__ __forceinline__ double div_by(float x, double n, double r)
 
 constexpr int EXP_LD = 8;      // 16-byte loads in flight per lane while staging
 
-__global__ void __launch_bounds__(HTPB) k_expmap0_project_tile(const float *__restrict__ x, double *__restrict__ y, long long outer,
+// A block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (one tile per block in the default launch) and requests the
+// first EXP_LD 16-byte groups per thread of its NEXT tile before it touches the current one, so that in a persistent launch
+// (HALO_EXPMAP_PERSISTENT=1) those loads are in flight during the serial part of a tile -- one lane per pixel running the
+// norm's fma chain over C channels while the other lanes of the block have nothing to do -- and during its write phase.
+__global__ void __launch_bounds__(HTPB, 4) k_expmap0_project_tile(const float *__restrict__ x, double *__restrict__ y, long long outer,
                                                                int C, long long inner, int pshift, double ks, double rks,
                                                                double maxnorm)
 {
@@ -83,62 +87,88 @@ __global__ void __launch_bounds__(HTPB) k_expmap0_project_tile(const float *__re
     float *tile = reinterpret_cast<float *>(smem_e);                         // [C][P]
     double *s_n = reinterpret_cast<double *>(smem_e + (size_t)C * P * 4);    // per pixel: n, g, projection norm (0 = none)
     double *s_g = s_n + P, *s_pr = s_g + P;
-    const long long tiles = (inner + P - 1) >> pshift;
-    const long long o = blockIdx.x / tiles, i0 = (blockIdx.x % tiles) << pshift;
-    const int np = inner - i0 < P ? (int)(inner - i0) : P;                   // pixels of this tile (a multiple of 4)
-    const float *xp = x + (size_t)o * C * inner + i0;
-    double *yp = y + (size_t)o * C * inner + i0;
-    // ---- stage: element e = (channel e >> (pshift-2), 4-pixel group e & (P/4-1))
+    const long long tiles = (inner + P - 1) >> pshift, ntiles = outer * tiles;
     const int gsh = pshift - 2, gmask = (1 << gsh) - 1, ngroups = C << gsh;
-    for (int e0 = tid; e0 < ngroups; e0 += HTPB * EXP_LD) {
-        f4_t q[EXP_LD];
+    // element e of a tile = (channel e >> (pshift-2), 4-pixel group e & (P/4-1)); the first EXP_LD * HTPB of them are prefetched
+    auto fetch = [&](long long t, f4_t (&q)[EXP_LD]) {
+        const long long o = t / tiles, i0 = (t % tiles) << pshift;
+        const int np = inner - i0 < P ? (int)(inner - i0) : P;
+        const float *xp = x + (size_t)o * C * inner + i0;
 #pragma unroll
         for (int u = 0; u < EXP_LD; ++u) {
-            const int e = e0 + u * HTPB, c = e >> gsh, px = (e & gmask) << 2;
+            const int e = tid + u * HTPB, c = e >> gsh, px = (e & gmask) << 2;
             q[u] = (f4_t){0.f, 0.f, 0.f, 0.f};
             if (e < ngroups && px < np) q[u] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(xp + (size_t)c * inner + px));
         }
+    };
+    f4_t q[EXP_LD];
+    long long t = blockIdx.x;
+    if (t < ntiles) fetch(t, q);
+    for (; t < ntiles; t += gridDim.x) {
+        const long long o = t / tiles, i0 = (t % tiles) << pshift;
+        const int np = inner - i0 < P ? (int)(inner - i0) : P;                   // pixels of this tile (a multiple of 4)
+        const float *xp = x + (size_t)o * C * inner + i0;
+        double *yp = y + (size_t)o * C * inner + i0;
+        // ---- stage: the prefetched groups, then whatever a larger tile has beyond them
 #pragma unroll
         for (int u = 0; u < EXP_LD; ++u) {
-            const int e = e0 + u * HTPB;
+            const int e = tid + u * HTPB;
             if (e < ngroups) *reinterpret_cast<f4_t *>(tile + ((size_t)(e >> gsh) << pshift) + ((e & gmask) << 2)) = q[u];
         }
-    }
-    __syncthreads();
-    // ---- one lane per pixel: ||x||, the tanh gain, and (rarely) the projection norm
-    if (tid < np) {
-        double ssq = 0.0;
-        for (int c = 0; c < C; ++c) { const double v = (double)tile[((size_t)c << pshift) + tid]; ssq = __builtin_fma(v, v, ssq); }
-        double n = __builtin_sqrt(ssq);
-        n = n < 1e-15 ? 1e-15 : n;
-        double a = n * ks;
-        a = a > 15.0 ? 15.0 : (a < -15.0 ? -15.0 : a);
-        const double g = rks * tanh(a);
-        double pr = 0.0;
-        if (g >= maxnorm * (1.0 - 1e-9)) {
-            double s2 = 0.0;
-            for (int c = 0; c < C; ++c) { const double v = g * ((double)tile[((size_t)c << pshift) + tid] / n); s2 = __builtin_fma(v, v, s2); }
-            double ny = __builtin_sqrt(s2);
-            ny = ny < 1e-15 ? 1e-15 : ny;
-            pr = ny > maxnorm ? ny : 0.0;
+        for (int e0 = tid + EXP_LD * HTPB; e0 < ngroups; e0 += HTPB * EXP_LD) {
+            f4_t r[EXP_LD];
+#pragma unroll
+            for (int u = 0; u < EXP_LD; ++u) {
+                const int e = e0 + u * HTPB, c = e >> gsh, px = (e & gmask) << 2;
+                r[u] = (f4_t){0.f, 0.f, 0.f, 0.f};
+                if (e < ngroups && px < np) r[u] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(xp + (size_t)c * inner + px));
+            }
+#pragma unroll
+            for (int u = 0; u < EXP_LD; ++u) {
+                const int e = e0 + u * HTPB;
+                if (e < ngroups) *reinterpret_cast<f4_t *>(tile + ((size_t)(e >> gsh) << pshift) + ((e & gmask) << 2)) = r[u];
+            }
         }
-        s_n[tid] = n; s_g[tid] = g; s_pr[tid] = pr;
-    }
-    __syncthreads();
-    // ---- write: a thread keeps ONE pixel pair and walks the channels (pair, n, g and the reciprocal of n hoisted).
-    // x / n is formed exactly as the hardware's own division sequence forms it for operands in the normal range
-    // (v_rcp_f64, two Newton steps, q = x r, one fma correction): same bits as `x / n`, a third of the instructions.
-    const int psh = pshift - 1, px = (tid & ((1 << psh) - 1)) << 1, cstep = HTPB >> psh;
-    if (px < np) {
-        const double n0 = s_n[px], n1 = s_n[px + 1], g0 = s_g[px], g1 = s_g[px + 1], p0 = s_pr[px], p1 = s_pr[px + 1];
-        const double r0 = exact_rcp(n0), r1 = exact_rcp(n1);
-        for (int c = tid >> psh; c < C; c += cstep) {
-            const f2_t xv = *reinterpret_cast<const f2_t *>(tile + ((size_t)c << pshift) + px);
-            double v0 = g0 * div_by(xv.x, n0, r0), v1 = g1 * div_by(xv.y, n1, r1);
-            if (p0 != 0.0) v0 = v0 / p0 * maxnorm;
-            if (p1 != 0.0) v1 = v1 / p1 * maxnorm;
-            __builtin_nontemporal_store((d2_h){v0, v1}, reinterpret_cast<d2_h *>(yp + (size_t)c * inner + px));
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x, q);                     // in flight during the rest of this tile
+        __syncthreads();
+        // ---- one lane per pixel: ||x||, the tanh gain, and (rarely) the projection norm
+        if (tid < np) {
+            double ssq = 0.0;
+#pragma unroll 4
+            for (int c = 0; c < C; ++c) { const double v = (double)tile[((size_t)c << pshift) + tid]; ssq = __builtin_fma(v, v, ssq); }
+            double n = __builtin_sqrt(ssq);
+            n = n < 1e-15 ? 1e-15 : n;
+            double a = n * ks;
+            a = a > 15.0 ? 15.0 : (a < -15.0 ? -15.0 : a);
+            const double g = rks * tanh(a);
+            double pr = 0.0;
+            if (g >= maxnorm * (1.0 - 1e-9)) {
+                double s2 = 0.0;
+#pragma unroll 1
+                for (int c = 0; c < C; ++c) { const double v = g * ((double)tile[((size_t)c << pshift) + tid] / n); s2 = __builtin_fma(v, v, s2); }
+                double ny = __builtin_sqrt(s2);
+                ny = ny < 1e-15 ? 1e-15 : ny;
+                pr = ny > maxnorm ? ny : 0.0;
+            }
+            s_n[tid] = n; s_g[tid] = g; s_pr[tid] = pr;
         }
+        __syncthreads();
+        // ---- write: a thread keeps ONE pixel pair and walks the channels (pair, n, g and the reciprocal of n hoisted).
+        // x / n is formed exactly as the hardware's own division sequence forms it for operands in the normal range
+        // (v_rcp_f64, two Newton steps, q = x r, one fma correction): same bits as `x / n`, a third of the instructions.
+        const int psh = pshift - 1, px = (tid & ((1 << psh) - 1)) << 1, cstep = HTPB >> psh;
+        if (px < np) {
+            const double n0 = s_n[px], n1 = s_n[px + 1], g0 = s_g[px], g1 = s_g[px + 1], p0 = s_pr[px], p1 = s_pr[px + 1];
+            const double r0 = exact_rcp(n0), r1 = exact_rcp(n1);
+            for (int c = tid >> psh; c < C; c += cstep) {
+                const f2_t xv = *reinterpret_cast<const f2_t *>(tile + ((size_t)c << pshift) + px);
+                double v0 = g0 * div_by(xv.x, n0, r0), v1 = g1 * div_by(xv.y, n1, r1);
+                if (p0 != 0.0) v0 = v0 / p0 * maxnorm;
+                if (p1 != 0.0) v1 = v1 / p1 * maxnorm;
+                __builtin_nontemporal_store((d2_h){v0, v1}, reinterpret_cast<d2_h *>(yp + (size_t)c * inner + px));
+            }
+        }
+        __syncthreads();                                                         // the tile may be overwritten
     }
 }
 
@@ -844,8 +874,14 @@ extern "C" int halo_expmap0_project(const void *x, int x_dtype, double *y, int64
         static LdsLimitSeen seen;
         if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_expmap0_project_tile, 96 * 1024))
             return fail(HALO_E_LAUNCH, "halo_expmap0_project: cannot raise the dynamic LDS limit");
-        const long long tiles = (inner + (1ll << pshift) - 1) >> pshift;
-        hipLaunchKernelGGL(k_expmap0_project_tile, dim3((unsigned)(outer * tiles)), dim3(HTPB), lds, st, (const float *)x, y,
+        const long long tiles = (inner + (1ll << pshift) - 1) >> pshift, ntiles = outer * tiles;
+        // One block per tile.  HALO_EXPMAP_PERSISTENT=1 launches only as many blocks as the CUs hold and lets each walk its
+        // tiles with the next tile's loads in flight (round-3 experiment: no gain at these sizes -- 0.096 vs 0.098 ms at
+        // C=256 256x512, 0.136 vs 0.122 ms at C=64 640x1280: the whole kernel is ~100 us, a block sees only 4 tiles)
+        long long resident = 256ll * (long long)((160 * 1024) / (lds + 256) > 8 ? 8 : (160 * 1024) / (lds + 256));
+        if (resident < 256) resident = 256;
+        const long long nblk = (getenv("HALO_EXPMAP_PERSISTENT") && ntiles > resident) ? resident : ntiles;
+        hipLaunchKernelGGL(k_expmap0_project_tile, dim3((unsigned)nblk), dim3(HTPB), lds, st, (const float *)x, y,
                            (long long)outer, (int)C, (long long)inner, pshift, ks, rks, maxnorm);
     }
     else if (x_dtype == HALO_F32)
@@ -1031,6 +1067,115 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
     }
 }
 
+// Round 3: BL_RO output rows per block.  Up-sampling by f reuses every source row for f output rows, so a block that owns
+// one output row (above) stages two source rows and synchronises twice for every 16 bytes it stores per lane and plane; here
+// a block owns BL_RO consecutive output rows: the <= BL_SR source rows they touch are staged once per plane chunk, and a
+// thread has BL_PC * BL_RO 16-byte stores in flight per pair of barriers instead of BL_PC.  Weights are formed from the row
+// and column fractions where they are used (w = ly * lx, the same rounded product as the precomputed ones: same bits).
+constexpr int BL_RO = 4, BL_SR = 6;
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(HTPB, 4) k_bilinear_lds_rows(const T *__restrict__ src, T *__restrict__ dst, int planes, int h, int w,
+                                                            int H, int W, T sh, T sw, int span)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    T *tile = reinterpret_cast<T *>(smem_b);                       // [BL_PC][nsr][span]
+    const int tid = threadIdx.x;
+    const int yb = blockIdx.y * BL_RO, xb0 = blockIdx.x * HTPB * VEC, xb = xb0 + tid * VEC;
+    // source rows of this block's output rows: [sy0, sy0 + nsr)
+    const int ylast = yb + BL_RO - 1 < H - 1 ? yb + BL_RO - 1 : H - 1;
+    int sy0 = (int)(sh * (T)yb), sy1 = (int)(sh * (T)ylast);
+    sy0 = sy0 > h - 1 ? h - 1 : sy0;
+    sy1 = sy1 > h - 1 ? h - 1 : sy1;
+    sy1 += sy1 < h - 1 ? 1 : 0;
+    const int nsr = sy1 - sy0 + 1;                                 // <= BL_SR (host bound)
+    int ry0[BL_RO], ry1[BL_RO];
+    T ly0[BL_RO], ly1[BL_RO];
+#pragma unroll
+    for (int r = 0; r < BL_RO; ++r) {
+        const int y = yb + r < H ? yb + r : H - 1;
+        const T fy = sh * (T)y;
+        int a = (int)fy;
+        a = a > h - 1 ? h - 1 : a;
+        ry0[r] = (a - sy0) * span;
+        ry1[r] = (a + (a < h - 1 ? 1 : 0) - sy0) * span;
+        ly1[r] = fy - (T)a;
+        ly0[r] = (T)1 - ly1[r];
+    }
+    const int xl = xb0 + HTPB * VEC - 1 < W - 1 ? xb0 + HTPB * VEC - 1 : W - 1;
+    int sx0 = (int)(sw * (T)xb0), sx1 = (int)(sw * (T)xl);
+    sx0 = sx0 > w - 1 ? w - 1 : sx0;
+    sx1 = sx1 > w - 1 ? w - 1 : sx1;
+    sx1 += sx1 < w - 1 ? 1 : 0;
+    const int ncol = sx1 - sx0 + 1;                                // <= span (host bound)
+    int x0[VEC], x1[VEC];
+    T lx0[VEC], lx1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int x = xb + j < W ? xb + j : W - 1;
+        const T fx = sw * (T)x;
+        int a = (int)fx;
+        a = a > w - 1 ? w - 1 : a;
+        x0[j] = a - sx0;
+        x1[j] = a + (a < w - 1 ? 1 : 0) - sx0;
+        lx1[j] = fx - (T)a;
+        lx0[j] = (T)1 - lx1[j];
+    }
+    const int plane_lds = nsr * span;
+    for (int p0 = blockIdx.z * BL_PC; p0 < planes; p0 += gridDim.z * BL_PC) {
+        __syncthreads();                                           // the previous chunk's taps have been read
+        // wave wv stages the (plane, source row) pairs wv, wv + 4, ...: one coalesced row segment each
+        for (int pr = tid >> 6, pl = 0, rr = tid >> 6; pr < BL_PC * nsr; pr += HTPB / 64, rr += HTPB / 64) {
+            while (rr >= nsr) { rr -= nsr; ++pl; }
+            if (p0 + pl < planes) {
+                const T *sp = src + ((size_t)(p0 + pl) * h + sy0 + rr) * w + sx0;
+                T *tq = tile + pl * plane_lds + rr * span;
+                for (int col = tid & 63; col < ncol; col += 64) tq[col] = sp[col];
+            }
+        }
+        __syncthreads();
+        if (xb < W) {
+#pragma unroll 1
+            for (int pl = 0; pl < BL_PC; ++pl) {                   // one plane's taps and outputs live at a time
+                if (p0 + pl >= planes) break;
+                const T *tp = tile + pl * plane_lds;
+#pragma unroll
+                for (int r = 0; r < BL_RO; ++r) {
+                    if (yb + r >= H) break;
+                    const T *r0 = tp + ry0[r], *r1 = tp + ry1[r];
+                    // the 4 * VEC weight products of a row are formed here, per plane: hoisted out of the plane loop they would
+                    // be BL_RO * VEC * 4 live values (64 registers) and the kernel would spill; the empty asm keeps them here
+                    T l0 = ly0[r], l1 = ly1[r];
+                    asm volatile("" : "+v"(l0), "+v"(l1));
+                    T o[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        T a = r0[x1[j]] * (l0 * lx1[j]);
+                        if constexpr (sizeof(T) == 8) {
+                            a = __builtin_fma(r0[x0[j]], l0 * lx0[j], a);
+                            a = __builtin_fma(r1[x0[j]], l1 * lx0[j], a);
+                            a = __builtin_fma(r1[x1[j]], l1 * lx1[j], a);
+                        } else {
+                            a = __builtin_fmaf(r0[x0[j]], l0 * lx0[j], a);
+                            a = __builtin_fmaf(r1[x0[j]], l1 * lx0[j], a);
+                            a = __builtin_fmaf(r1[x1[j]], l1 * lx1[j], a);
+                        }
+                        o[j] = a;
+                    }
+                    T *q = dst + ((size_t)(p0 + pl) * H + yb + r) * W + xb;
+                    if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));
+                    else if constexpr (sizeof(T) == 4 && VEC == 4) __builtin_nontemporal_store((f4_t){o[0], o[1], o[2], o[3]}, reinterpret_cast<f4_t *>(q));
+                    else {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) q[j] = o[j];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);             // one output row's taps live at a time (registers)
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int VEC>
 static void launch_bilinear_rows(const void *src, void *dst, int64_t planes, int64_t h, int64_t w, int64_t H, int64_t W, hipStream_t st)
 {
@@ -1042,6 +1187,22 @@ static void launch_bilinear_rows(const void *src, void *dst, int64_t planes, int
     if (gz > 65535) gz = 65535;
     // source columns one block can touch: its 256*VEC outputs span sw*(256*VEC-1) source units, plus the +1 taps
     const int64_t span = (int64_t)((double)sw * (double)(HTPB * VEC - 1)) + 4;
+    // BL_RO output rows per block where they touch at most BL_SR source rows (up-sampling by >= 0.8); HALO_BILINEAR_LDS1=1
+    // keeps the one-row kernel (A/B switch, same bits)
+    const int64_t srows = (int64_t)((double)sh * (double)(BL_RO - 1)) + 3;
+    const size_t lds_r = (size_t)BL_PC * srows * span * sizeof(T);
+    // (float32 with 4 pixels per lane stays on the one-row kernel: four rows of its taps and weights do not fit 128 registers)
+    if (!(sizeof(T) == 4 && VEC == 4) && srows <= BL_SR && lds_r <= 48 * 1024 && cdiv(H, BL_RO) <= 65535 && !getenv("HALO_BILINEAR_ROWS") &&
+        !getenv("HALO_BILINEAR_LDS1")) {
+        const unsigned gyr = (unsigned)cdiv(H, BL_RO);
+        int64_t gzl = cdiv(8192, (int64_t)gx * gyr);
+        const int64_t chunks = cdiv(planes, BL_PC);
+        gzl = gzl < 1 ? 1 : (gzl > chunks ? chunks : gzl);
+        if (gzl > 65535) gzl = 65535;
+        hipLaunchKernelGGL((k_bilinear_lds_rows<T, VEC>), dim3(gx, gyr, (unsigned)gzl), dim3(HTPB), lds_r, st, (const T *)src, (T *)dst,
+                           (int)planes, (int)h, (int)w, (int)H, (int)W, sh, sw, (int)span);
+        return;
+    }
     const size_t lds = (size_t)BL_PC * 2 * span * sizeof(T);
     if (lds <= 32 * 1024 && !getenv("HALO_BILINEAR_ROWS")) {      // A/B switch: taps gathered from global memory
         int64_t gzl = cdiv(8192, (int64_t)gx * H);
