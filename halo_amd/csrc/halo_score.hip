@@ -63,20 +63,10 @@ __global__ void __launch_bounds__(TPB) k_minmax_finalize(const double *__restric
 // both maps of normalize_map in one launch: blockIdx.y = slot (0: impurity partials, 1: uncertainty partials).  1024
 // threads: the kernel is a dependent chain of loads on 2 B blocks, i.e. pure latency -- fewer trips per thread.
 constexpr int FIN_TPB = 1024;
-// rng (optional): the image's score-range record for the selector.  A normalised score is a product of two values in [0, 1]
-// (or NaN where a map is constant), so [0, 1] bounds it without a pass over the map; the combine kernel adds the "some pixel
-// is pickable" / "NaN present" facts.
 __global__ void __launch_bounds__(FIN_TPB) k_minmax_finalize2(const double *__restrict__ part0, int nblk0, const double *__restrict__ part1,
-                                                               int nblk1, double *__restrict__ stats, SelHdr *__restrict__ rng)
+                                                               int nblk1, double *__restrict__ stats)
 {
     const int b = blockIdx.x, slot = blockIdx.y;
-    if (rng && slot == 0 && threadIdx.x == 0) {
-        SelHdr h;
-        memset(&h, 0, sizeof(h));
-        h.kmin_inv = ~order_key(0.0);
-        h.kmax = order_key(1.0);
-        rng[b] = h;
-    }
     const int nblk = slot ? nblk1 : nblk0;
     const double2 *p = reinterpret_cast<const double2 *>((slot ? part1 : part0) + (size_t)b * nblk * 2);
     const double2 p0 = p[0];
@@ -867,32 +857,26 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
 // k_combine with the 3 x 3 box sum of the uncertainty recomputed from the entropy map (box3_row4: the same operations
 // that produced the min / max, so the same bits) instead of read from a stored copy: one kernel and one 4-byte map
 // less in the step's tail.  4 pixels per lane, 16-byte loads and stores.
-// What the selector needs to know about a normalised score map beyond its [0, 1] bound: is any pixel pickable (finite,
-// not masked), is a NaN / +inf present.  Ballots per wave, an atomic only while the record does not say so yet.
-__device__ __forceinline__ void report_range(SelHdr *__restrict__ rec, bool any_ok, bool any_bad)
-{
-    const unsigned long long okm = __ballot(any_ok), badm = __ballot(any_bad);
-    if ((threadIdx.x & 63) == 0) {
-        if (okm && rec->nvalid == 0u) atomicAdd(&rec->nvalid, 1u);
-        if (badm && !(rec->flags & (unsigned)SEL_F_BAD)) atomicOr(&rec->flags, (unsigned)SEL_F_BAD);
-    }
-}
-
+// rng (optional, normalised maps only): the image's score-range record for the selector, written by ONE lane per image.  A
+// normalised score is the product of two values in [0, 1] -- (x - min) / (max - min) of finite maps -- or -inf where masked, so
+// [0, 1] bounds it without a pass over the map; the only other possibility is a NaN map, and that is a property of the
+// min / max themselves (a constant or NaN-carrying map makes max - min zero or NaN): no per-pixel reporting is needed.
 template <typename TI>
 __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp_raw, const float *__restrict__ ent,
                                                       const double *__restrict__ stats, const unsigned char *__restrict__ active,
                                                       int H, int W, int pk, int normalize, TI *__restrict__ score,
                                                       TI *__restrict__ imp_out, float *__restrict__ unc_out, SelHdr *__restrict__ rng)
 {
-    const int b = blockIdx.y;
+    // grid (row segments of TPB * 4 pixels, rows, images): no index division (a 64-bit i / W was a fifth of the kernel's
+    // instructions); lanes past the end of a row idle
+    const int b = blockIdx.z, y = blockIdx.y;
     const long long hw = (long long)H * W;
-    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
-    const bool live = i0 < hw;
-    const int y = live ? (int)(i0 / W) : 0, x = live ? (int)(i0 % W) : 0;
+    const int x = (blockIdx.x * TPB + threadIdx.x) * 4;
+    const bool live = x < W;
     float un[4];
-    box3_row4(ent + (size_t)b * hw, H, W, y, x, live, pk, un);
+    box3_row4(ent + (size_t)b * hw, H, W, y, live ? x : 0, live, pk, un);
     if (!live) return;
-    const size_t o = (size_t)b * hw + i0;
+    const size_t o = (size_t)b * hw + (size_t)y * W + x;
     TI im[4];
     if constexpr (sizeof(TI) == 8) {
         const double2 q0 = *reinterpret_cast<const double2 *>(imp_raw + o), q1 = *reinterpret_cast<const double2 *>(imp_raw + o + 2);
@@ -908,6 +892,18 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
         TI iden;
         if constexpr (sizeof(TI) == 8) iden = imx - imn;
         else iden = (float)((double)imx - (double)imn);
+        if (rng && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            SelHdr h;
+            memset(&h, 0, sizeof(h));
+            h.kmin_inv = ~order_key(0.0);
+            h.kmax = order_key(1.0);
+            h.nvalid = 1u;                     // "something may be pickable": a fully masked map simply yields no candidates
+            // zero, NaN or infinite range: the map holds NaN (0/0, inf/inf); a finite positive range with finite extrema
+            // leaves every quotient in [0, 1]
+            const bool fin = uden > 0.0f && uden < __builtin_inff() && iden > (TI)0 && iden < (TI)__builtin_inf();
+            h.flags = fin ? 0u : (unsigned)SEL_F_BAD;
+            rng[b] = h;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { un[j] = (un[j] - umn) / uden; im[j] = (im[j] - imn) / iden; }
     }
@@ -933,17 +929,6 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
         if (imp_out) *reinterpret_cast<float4 *>(imp_out + o) = make_float4(im[0], im[1], im[2], im[3]);
     }
     if (unc_out) *reinterpret_cast<float4 *>(unc_out + o) = make_float4(un[0], un[1], un[2], un[3]);
-    if (rng) {
-        bool ok = false, bad = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool fin = sc[j] >= (TI)0 && sc[j] <= (TI)1;              // a pickable value; false for NaN, +-inf
-            const bool masked = sc[j] < (TI)0 && sc[j] == sc[j] + sc[j];    // -inf (`score[active] = -inf`)
-            ok = ok || fin;
-            bad = bad || !(fin || masked);                                   // NaN, +inf, or anything the [0, 1] bound does not cover
-        }
-        report_range(rng + b, ok, bad);
-    }
 }
 
 
@@ -2012,7 +1997,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     const bool box3 = do_box && ksize == 3 && W % 4 == 0 && aligned16(ent) && aligned16(unc_raw);
     // 3 x 3 window + 16-byte aligned maps: the box sum is recomputed inside the combine kernel (no stored copy);
     // HALO_NO_FUSE_TAIL=1 keeps the round-2 sequence (A/B switch, identical results)
-    const bool fuse_tail = box3 && B <= 65535 && cdiv(H, BM_TH) <= 65535 && aligned16(imp_raw) && aligned16(score) && (!impurity || aligned16(impurity)) &&
+    const bool fuse_tail = box3 && B <= 65535 && H <= 65535 && aligned16(imp_raw) && aligned16(score) && (!impurity || aligned16(impurity)) &&
                            (!uncertainty || aligned16(uncertainty)) && (!active || ((uintptr_t)active & 3) == 0) &&
                            getenv("HALO_NO_FUSE_TAIL") == nullptr;
     const int nblk_c3 = (int)cdiv(hw, TPB * 4);
@@ -2037,9 +2022,9 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     SelHdr *rng_free = (score_range && normalize && fuse_tail) ? (SelHdr *)score_range : nullptr;
     if (normalize)
         hipLaunchKernelGGL(k_minmax_finalize2, dim3((unsigned)B, 2u), dim3(FIN_TPB), 0, st, (const double *)part_imp, nblk_imp,
-                           (const double *)part_unc, nblk_unc, stats, rng_free);
+                           (const double *)part_unc, nblk_unc, stats);
     if (fuse_tail) {
-        dim3 gridc((unsigned)nblk_c3, (unsigned)B);
+        dim3 gridc((unsigned)cdiv(W, TPB * 4), (unsigned)H, (unsigned)B);
         if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty, rng_free);
         else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty, rng_free);
     } else if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
