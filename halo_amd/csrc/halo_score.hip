@@ -1612,6 +1612,84 @@ __global__ void __launch_bounds__(TPB) k_gram_lr(const double *__restrict__ feat
     }
 }
 
+// k_gram_lr with 16 bytes per lane (even source width, 16-byte aligned planes): a lane owns TWO adjacent columns of two rows,
+// a wave 128 columns x 2 rows.  The right neighbour of a lane's first column is its own second column, that of its second
+// column the next lane's first (full-wave DPP shift); only lane 63 loads its right neighbour itself (8 bytes per row and
+// channel, clamped at the row's end).  Half the load instructions per byte of k_gram_lr, no idle 64th lane, and 512-column rows
+// split into four full waves.  Same fma chains, same bits.
+__global__ void __launch_bounds__(TPB) k_gram_lr2(const double *__restrict__ feat, long long bstride, int C, int h, int w,
+                                                  double *__restrict__ gram)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const unsigned per = gridDim.x / 8;                       // the host pads the grid's x extent to a multiple of 8
+    const unsigned wid = ((blockIdx.x % 8) * per + blockIdx.x / 8) * (TPB / 64) + (threadIdx.x >> 6);
+    const unsigned nwx = (unsigned)((w + 127) / 128);
+    const int y = 2 * (int)(wid / nwx);
+    if (y >= h) return;                                       // wave-uniform
+    const int xu = (int)(wid % nwx) * 128 + 2 * lane;         // this lane's first column (even)
+    const int x = xu < w - 2 ? xu : w - 2;                    // lanes past the row re-read its last pair (never stored)
+    const int xr = xu + 2 < w - 1 ? xu + 2 : w - 1;           // right neighbour of the second column, clamped (lane 63 loads it)
+    const int y1 = y + 1 < h - 1 ? y + 1 : h - 1, y2 = y + 2 < h - 1 ? y + 2 : h - 1;
+    const unsigned a0 = (unsigned)(y * w + x), a1 = (unsigned)(y1 * w + x), a2 = (unsigned)(y2 * w + x);
+    const unsigned e0 = (unsigned)(y * w + xr), e1 = (unsigned)(y1 * w + xr), e2 = (unsigned)(y2 * w + xr);
+    const int hwl = h * w;
+    const double *p = feat + (size_t)b * bstride;             // plane base: scalar, advanced by scalar adds
+    double g[2][2][GRAM_MAPS];                                // [row][column of the pair][map]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < GRAM_MAPS; ++k) g[r][q][k] = 0.0;
+    const bool last = lane == 63, edge = xu + 2 >= w;         // edge: the pair ends the row, its right neighbour is clamped to itself
+    auto accumulate = [&](const d2_t &v0, const d2_t &v1, const d2_t &v2, double x0, double x1, double x2) {
+        // right neighbours of the pair's second column: the next lane's first column, (lane 63) the value it loaded itself, or
+        // (last pair of the row) the column itself
+        const double s0 = next_lane(v0.x), s1 = next_lane(v1.x), s2 = next_lane(v2.x);
+        const double n0 = edge ? v0.y : (last ? x0 : s0), n1 = edge ? v1.y : (last ? x1 : s1), n2 = edge ? v2.y : (last ? x2 : s2);
+        const double c0[2] = {v0.x, v0.y}, c1[2] = {v1.x, v1.y}, c2[2] = {v2.x, v2.y};
+        const double r0[2] = {v0.y, n0}, r1[2] = {v1.y, n1}, r2[2] = {v2.y, n2};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            g[0][q][0] = __builtin_fma(c0[q], c0[q], g[0][q][0]); g[0][q][1] = __builtin_fma(c0[q], r0[q], g[0][q][1]);
+            g[0][q][2] = __builtin_fma(c0[q], c1[q], g[0][q][2]); g[0][q][3] = __builtin_fma(c0[q], r1[q], g[0][q][3]);
+            g[0][q][4] = __builtin_fma(r0[q], c1[q], g[0][q][4]);
+            g[1][q][0] = __builtin_fma(c1[q], c1[q], g[1][q][0]); g[1][q][1] = __builtin_fma(c1[q], r1[q], g[1][q][1]);
+            g[1][q][2] = __builtin_fma(c1[q], c2[q], g[1][q][2]); g[1][q][3] = __builtin_fma(c1[q], r2[q], g[1][q][3]);
+            g[1][q][4] = __builtin_fma(r1[q], c2[q], g[1][q][4]);
+        }
+    };
+    int c = 0;
+    for (; c + 2 <= C; c += 2) {
+        d2_t v[2][3];
+        double xe[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u, p += hwl) {
+            v[u][0] = *reinterpret_cast<const d2_t *>(p + a0); v[u][1] = *reinterpret_cast<const d2_t *>(p + a1);
+            v[u][2] = *reinterpret_cast<const d2_t *>(p + a2);
+            xe[u][0] = xe[u][1] = xe[u][2] = 0.0;
+            if (last) { xe[u][0] = p[e0]; xe[u][1] = p[e1]; xe[u][2] = p[e2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) accumulate(v[u][0], v[u][1], v[u][2], xe[u][0], xe[u][1], xe[u][2]);
+    }
+    for (; c < C; ++c, p += hwl) {
+        const d2_t v0 = *reinterpret_cast<const d2_t *>(p + a0), v1 = *reinterpret_cast<const d2_t *>(p + a1), v2 = *reinterpret_cast<const d2_t *>(p + a2);
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        if (last) { x0 = p[e0]; x1 = p[e1]; x2 = p[e2]; }
+        accumulate(v0, v1, v2, x0, x1, x2);
+    }
+    if (xu < w) {                                             // w even: both columns of the pair exist
+        double *gb = gram + (size_t)b * GRAM_MAPS * hwl;
+#pragma unroll
+        for (int k = 0; k < GRAM_MAPS; ++k) *reinterpret_cast<d2_t *>(gb + (size_t)k * hwl + a0) = (d2_t){g[0][0][k], g[0][1][k]};
+        if (y + 1 < h) {
+#pragma unroll
+            for (int k = 0; k < GRAM_MAPS; ++k) *reinterpret_cast<d2_t *>(gb + (size_t)k * hwl + a1) = (d2_t){g[1][0][k], g[1][1][k]};
+        }
+    }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ gram, int h, int w, int H, int W, double sh, double sw,
                                                      double ks, double rks, double *__restrict__ out, double *__restrict__ partials)
@@ -1948,9 +2026,17 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
         if (ev_feat_start) (void)hipEventRecord((hipEvent_t)ev_feat_start, st);
         const int mode = pur_type == HALO_PUR_EUC_NORM ? 1 : 0;
         if (gram_mode) {
-            const long long nwaves = cdiv(lr->wf, GRAM_COLS) * cdiv(lr->hf, 2);
-            hipLaunchKernelGGL(k_gram_lr, dim3((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B), block, 0, st, (const double *)feat,
-                               (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram);
+            // 16 bytes per lane where the planes allow it (even width, 16-byte aligned); HALO_GRAM_8B=1: the 8-byte kernel (A/B)
+            const bool wide = lr->wf >= 2 && lr->wf % 2 == 0 && feat_bstride % 2 == 0 && aligned16(feat) && aligned16(gram) && getenv("HALO_GRAM_8B") == nullptr;
+            if (wide) {
+                const long long nwaves = cdiv(lr->wf, 128) * cdiv(lr->hf, 2);
+                hipLaunchKernelGGL(k_gram_lr2, dim3((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B), block, 0, st, (const double *)feat,
+                                   (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram);
+            } else {
+                const long long nwaves = cdiv(lr->wf, GRAM_COLS) * cdiv(lr->hf, 2);
+                hipLaunchKernelGGL(k_gram_lr, dim3((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B), block, 0, st, (const double *)feat,
+                                   (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram);
+            }
             const double shd = H > 1 ? (double)(lr->hf - 1) / (double)(H - 1) : 0.0, swd = W > 1 ? (double)(lr->wf - 1) / (double)(W - 1) : 0.0;
             nblk_imp = nblk1;
             if (mode == 0) hipLaunchKernelGGL(k_radius_gram<0>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
