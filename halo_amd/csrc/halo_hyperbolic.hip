@@ -1072,14 +1072,14 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
 // a block owns BL_RO consecutive output rows: the <= BL_SR source rows they touch are staged once per plane chunk, and a
 // thread has BL_PC * BL_RO 16-byte stores in flight per pair of barriers instead of BL_PC.  Weights are formed from the row
 // and column fractions where they are used (w = ly * lx, the same rounded product as the precomputed ones: same bits).
-constexpr int BL_RO = 4, BL_SR = 6;
+constexpr int BL_RO = 4, BL_SR = 6, BL_PCR = 4;     // output rows per block, source rows staged at most, planes per chunk
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(HTPB, 4) k_bilinear_lds_rows(const T *__restrict__ src, T *__restrict__ dst, int planes, int h, int w,
                                                             int H, int W, T sh, T sw, int span)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    T *tile = reinterpret_cast<T *>(smem_b);                       // [BL_PC][nsr][span]
+    T *tile = reinterpret_cast<T *>(smem_b);                       // [BL_PCR][nsr][span]
     const int tid = threadIdx.x;
     const int yb = blockIdx.y * BL_RO, xb0 = blockIdx.x * HTPB * VEC, xb = xb0 + tid * VEC;
     // source rows of this block's output rows: [sy0, sy0 + nsr)
@@ -1122,10 +1122,10 @@ __global__ void __launch_bounds__(HTPB, 4) k_bilinear_lds_rows(const T *__restri
         lx0[j] = (T)1 - lx1[j];
     }
     const int plane_lds = nsr * span;
-    for (int p0 = blockIdx.z * BL_PC; p0 < planes; p0 += gridDim.z * BL_PC) {
+    for (int p0 = blockIdx.z * BL_PCR; p0 < planes; p0 += gridDim.z * BL_PCR) {
         __syncthreads();                                           // the previous chunk's taps have been read
         // wave wv stages the (plane, source row) pairs wv, wv + 4, ...: one coalesced row segment each
-        for (int pr = tid >> 6, pl = 0, rr = tid >> 6; pr < BL_PC * nsr; pr += HTPB / 64, rr += HTPB / 64) {
+        for (int pr = tid >> 6, pl = 0, rr = tid >> 6; pr < BL_PCR * nsr; pr += HTPB / 64, rr += HTPB / 64) {
             while (rr >= nsr) { rr -= nsr; ++pl; }
             if (p0 + pl < planes) {
                 const T *sp = src + ((size_t)(p0 + pl) * h + sy0 + rr) * w + sx0;
@@ -1136,7 +1136,7 @@ __global__ void __launch_bounds__(HTPB, 4) k_bilinear_lds_rows(const T *__restri
         __syncthreads();
         if (xb < W) {
 #pragma unroll 1
-            for (int pl = 0; pl < BL_PC; ++pl) {                   // one plane's taps and outputs live at a time
+            for (int pl = 0; pl < BL_PCR; ++pl) {                   // one plane's taps and outputs live at a time
                 if (p0 + pl >= planes) break;
                 const T *tp = tile + pl * plane_lds;
 #pragma unroll
@@ -1190,13 +1190,13 @@ static void launch_bilinear_rows(const void *src, void *dst, int64_t planes, int
     // BL_RO output rows per block where they touch at most BL_SR source rows (up-sampling by >= 0.8); HALO_BILINEAR_LDS1=1
     // keeps the one-row kernel (A/B switch, same bits)
     const int64_t srows = (int64_t)((double)sh * (double)(BL_RO - 1)) + 3;
-    const size_t lds_r = (size_t)BL_PC * srows * span * sizeof(T);
+    const size_t lds_r = (size_t)BL_PCR * srows * span * sizeof(T);
     // (float32 with 4 pixels per lane stays on the one-row kernel: four rows of its taps and weights do not fit 128 registers)
     if (!(sizeof(T) == 4 && VEC == 4) && srows <= BL_SR && lds_r <= 48 * 1024 && cdiv(H, BL_RO) <= 65535 && !getenv("HALO_BILINEAR_ROWS") &&
         !getenv("HALO_BILINEAR_LDS1")) {
         const unsigned gyr = (unsigned)cdiv(H, BL_RO);
         int64_t gzl = cdiv(8192, (int64_t)gx * gyr);
-        const int64_t chunks = cdiv(planes, BL_PC);
+        const int64_t chunks = cdiv(planes, BL_PCR);
         gzl = gzl < 1 ? 1 : (gzl > chunks ? chunks : gzl);
         if (gzl > 65535) gzl = 65535;
         hipLaunchKernelGGL((k_bilinear_lds_rows<T, VEC>), dim3(gx, gyr, (unsigned)gzl), dim3(HTPB), lds_r, st, (const T *)src, (T *)dst,
