@@ -37,6 +37,26 @@ python3 $R/tools/time_training_ops.py > $OUT/training_ops.txt 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_mlr -- python3 $R/tools/prof_mlr.py > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mlr_clk -- python3 $R/tools/prof_mlr.py > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_select -- python3 $R/tools/time_select.py > /dev/null 2>&1
+# the N > 1 code path at the full shape on the one GPU of the box: two ranks share it over gloo (never a measurement: both ranks
+# stream from the same HBM); the gathered pool tables must equal the one-rank run's
+python3 $R/bench.py --cpu-images 0 --ring 16 --pool-images 96 --dump-tables $OUT/pool96_one.npz > $OUT/bench_pool96_one_rank.json 2> /dev/null
+HALO_BENCH_BACKEND=gloo HALO_BENCH_SHARE_GPU=1 python3 $R/bench.py --gpus 2 --cpu-images 0 --ring 16 --pool-images 96 --dump-tables $OUT/pool96_two.npz > $OUT/bench_pool96_two_ranks_one_gpu.json 2> $OUT/bench_pool96_two.err
+python3 - <<PY > $OUT/two_ranks_one_gpu.txt 2>&1
+import json, numpy as np
+a, b = np.load("$OUT/pool96_one.npz"), np.load("$OUT/pool96_two.npz")
+same = bool(np.array_equal(a["tables"].view(np.int64), b["tables"].view(np.int64)) and np.array_equal(a["counts"], b["counts"]))
+d = json.loads([l for l in open("$OUT/bench_pool96_two_ranks_one_gpu.json") if l.startswith("{")][-1])
+print("bench.py --gpus 2 (gloo, both ranks on the one GPU), 96 full-size images, 48 per rank:")
+print("  gathered pool tables bit-identical to the one-rank run:", same)
+print("  rows of other ranks checked against local results inside bench.py:", d["exchange"]["rows_checked_against_local_results"])
+print("  exchange:", d["exchange"], " sharding:", d["config"]["sharding"])
+PY
+rm -f $OUT/pool96_one.npz $OUT/pool96_two.npz
+METHODS=auto RANGED=1 python3 $R/tools/time_select.py > $OUT/select_timing_ranged.txt 2>&1
+cd /tmp
+rm -rf $OUT/trace_sel16
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_sel16 -- python3 $R/tools/prof_select16.py > /dev/null 2>&1
+python3 $R/tools/prof_select16.py summarize $OUT/trace_sel16 > $OUT/select16_breakdown.txt 2>&1
 # keep the merged output small: the per-dispatch traces are only needed for the summaries computed above / by the distiller
 find $OUT -name "*kernel_trace.csv" -size +12M -delete
 ls -R $OUT | head -100

@@ -65,7 +65,8 @@ def main():
     os.makedirs(DST, exist_ok=True)
     d = copy_json("bench_default.json", RND + "_bench_default.json")
     copy_json("bench_under_rocprof.json", RND + "_bench_under_rocprof.json")
-    for v in ("f32", "lowres", "lowres_exact", "lowres_gram", "c512", "ripu", "hyper", "pool2975", "resets_kernel", "resets_fills"):
+    for v in ("f32", "lowres", "lowres_exact", "lowres_gram", "c512", "ripu", "hyper", "pool2975", "resets_kernel", "resets_fills",
+              "pool96_one_rank", "pool96_two_ranks_one_gpu"):
         copy_json("bench_%s.json" % v, RND + "_bench_%s.json" % v)
     stats_csv("trace/*/*_kernel_stats.csv", RND + "_kernel_stats.csv")
     stats_csv("trace_ripu/*/*_kernel_stats.csv", RND + "_kernel_stats_ripu.csv", 25)
@@ -102,7 +103,8 @@ def main():
                                                       "GRBM_GUI_ACTIVE for the clock, instruction counts)",
                    "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all waves; GRBM_GUI_ACTIVE / 8 = shader cycles",
                    "per_kernel_avg_per_launch": per}, open(os.path.join(DST, RND + "_pmc_lowres.json"), "w"), indent=1)
-    for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt", "tail_timeline.txt", "ab_lowres_dma.txt"):
+    for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt", "tail_timeline.txt", "ab_lowres_dma.txt", "two_ranks_one_gpu.txt", "select_timing_ranged.txt",
+              "select16_breakdown.txt"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]

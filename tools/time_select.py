@@ -11,6 +11,9 @@ dev = torch.device("cuda:0")
 H, W, n = 1024, 2048, 2331
 mrad = int(os.environ.get("MRAD", "5"))
 methods = os.environ.get("METHODS", "auto,serial").split(",")
+RANGED = os.environ.get("RANGED", "0") == "1"      # the pipeline's case: the scorer supplied the maps' value range (prepared untimed here)
+from halo_amd import _lib
+from halo_amd.core.active.floating_region import new_score_range
 for B in (1, 4, 16, 32):
     g = torch.Generator(device=dev).manual_seed(3)
     base = torch.randn((B, H // 4, W // 4), generator=g, device=dev, dtype=torch.float64)
@@ -25,13 +28,17 @@ for B in (1, 4, 16, 32):
             sc = score0.clone()
             act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
             am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+            rec = None
+            if RANGED and method != "serial":
+                rec = new_score_range(B, dev)
+                _lib.check(_lib.lib().halo_score_range(_lib.ptr(sc), _lib.dtype_code(sc), B, H, W, _lib.ptr(rec), _lib.stream_ptr(dev)), "halo_score_range")
             torch.cuda.synchronize()
             if loaded:
                 with torch.cuda.stream(s2):
                     for _ in range(12):
                         score_maps(logit, feat, "entropy", "radius", True, None, want_maps=False)
             t0 = time.perf_counter()
-            picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt, method=method)
+            picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt, method=method, score_range=rec)
             torch.cuda.current_stream().synchronize()
             dt = (time.perf_counter() - t0) * 1e3
             torch.cuda.synchronize()
