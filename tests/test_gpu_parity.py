@@ -794,6 +794,56 @@ def test_selection_with_the_scorers_range_records(dev):
     assert bits_equal(outs[0], outs[1])
 
 
+def test_score_and_select_replay_from_a_hip_graph(dev):
+    """include/halo_hip.h promises that every call is an asynchronous enqueue with no allocation, no host sync and no global
+    state, hence hipGraph-capturable.  Capture one acquisition (score -> range record -> mask -> select, ~12 launches incl. the
+    selector's memset) into a graph on static buffers, replay it on new inputs, and compare with the eager path bit for bit."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import new_score_range, score_maps, _workspace
+    rng = np.random.default_rng(808)
+    B, O, C, H, W, n = 2, 19, 16, 128, 256, 80
+
+    def inputs(seed):
+        r = np.random.default_rng(seed)
+        return (t(r.standard_normal((B, O, H, W)).astype(np.float32), dev), t(r.standard_normal((B, C, H, W)) * 0.05, dev),
+                t(r.integers(0, O, (B, H, W)).astype(np.int64), dev), t(r.random((B, H, W)) < 0.03, dev))
+
+    def eager(lg, em, gt, act0):
+        act, sel, am = act0.clone(), torch.zeros_like(act0), torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+        rec = new_score_range(B, dev)
+        sc = score_maps(lg, em, "entropy", "radius", True, gt, size=3, active=act, want_maps=False, score_range=rec)[0]
+        pk, nk = greedy_select(sc, n, 1, 5, act, sel, am, gt, score_range=rec)
+        return [x.clone() for x in (sc, pk, nk, act, sel, am)]
+
+    want = [eager(*inputs(s_)) for s_ in (1, 2, 3)]
+    # static buffers of the graph
+    lg, em, gt, act0 = inputs(1)
+    act, sel, am = act0.clone(), torch.zeros_like(act0), torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+    score = torch.empty((B, H, W), dtype=torch.float64, device=dev)
+    picks = torch.zeros((B, n, 3), dtype=torch.float64, device=dev)
+    npk = torch.zeros((B,), dtype=torch.int32, device=dev)
+    rec = new_score_range(B, dev)
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        # warm-up on the capture stream: workspaces get allocated, dynamic-LDS limits raised, outside the capture
+        score_maps(lg, em, "entropy", "radius", True, gt, size=3, active=act, want_maps=False, out=score, score_range=rec)
+        greedy_select(score, n, 1, 5, act, sel, am, gt, out=(picks, npk), score_range=rec)
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            score_maps(lg, em, "entropy", "radius", True, gt, size=3, active=act, want_maps=False, out=score, score_range=rec)
+            greedy_select(score, n, 1, 5, act, sel, am, gt, out=(picks, npk), score_range=rec)
+    for rep, seed in enumerate((1, 2, 3, 2)):
+        l2, e2, g2, a2 = inputs(seed)
+        lg.copy_(l2); em.copy_(e2); gt.copy_(g2); act.copy_(a2); sel.zero_(); am.fill_(255)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        w = want[seed - 1]
+        for got, exp in zip((score, picks, npk, act, sel, am), w):
+            assert bits_equal(got.cpu().numpy(), exp.cpu().numpy()) if got.dtype.is_floating_point else torch.equal(got, exp), (rep, seed)
+
+
 def test_lowres_gram_mode_on_degenerate_grids(dev):
     """single-row / single-column / single-pixel embeddings, odd sizes around the 63-column wave width"""
     from halo_amd.core.active.floating_region import score_maps_lowres
