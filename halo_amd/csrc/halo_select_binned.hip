@@ -46,8 +46,9 @@ constexpr int SW_SURV = 256;     // survivor capacity of one bin (4 per lane of 
 constexpr int FWIN = 1024;       // fine-bin offsets staged in LDS at a time
 
 // per-image arrays: element [b * stride + i]
-constexpr int BIN_CAP = 256;     // slots per fine bin (expected occupancy <= target = 128: equal-width sub-bins of a 1/2048 slice of
+constexpr int BIN_CAP = 128;     // slots per fine bin (expected occupancy <= target = 64: equal-width sub-bins of a 1/2048 slice of
                                  // the value range are Poisson-filled; a fuller bin -- a plateau of ties -- hands the image over)
+constexpr int SW_MB = 4;         // the sweep filters up to SW_MB consecutive bins (<= 256 candidates together) in one pass
 
 struct BinWs {
     SelHdr *hdr;
@@ -87,6 +88,15 @@ __device__ __forceinline__ int coarse_bin(double v, const ValRange &r, double &t
     t = (v - r.lo) * r.scale;
     const int j = (int)t;
     return j > NB1 - 1 ? NB1 - 1 : j;
+}
+
+// ------------------------------------------------------------------ counters to zero
+// A kernel, not hipMemsetAsync: inside a captured hipGraph (ROCm 7.2) a memset node between kernel nodes was observed not to be
+// ordered against them (the histogram kernels of the same replay found counters of the previous one: different picks in 1 of ~3
+// replays of a score + select graph, tests/test_gpu_parity.py::test_score_and_select_replay_from_a_hip_graph); a kernel node is.
+__global__ void __launch_bounds__(256) k_sel_zero(uint4 *__restrict__ p, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ------------------------------------------------------------------ value range
@@ -449,35 +459,52 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     // (key, pos) loads are issued as soon as it is known -- beside a bandwidth-bound kernel a memory round trip takes
     // microseconds, a chunk only ~1 us.  The three register sets rotate by unrolling the loop body three times, so the
     // compiler's counted s_waitcnt vmcnt waits for the oldest set only.
-    struct Chunk { unsigned start, cnt; bool last, valid; };
+    // A chunk = up to SW_MB consecutive non-empty bins holding <= SW_TPB candidates together (a bin has at most BIN_CAP <=
+    // SW_TPB / 2 of them, so it is never split).  Nothing depends on the order inside a chunk -- the resolve step takes its
+    // survivors in exact priority order -- and chunks are still monotone in the value, so merging bins changes no pick; it
+    // halves the number of filter / resolve rounds (two barriers and a serial resolve each) for the same candidates.
+    struct Chunk { unsigned start[SW_MB], cnt[SW_MB], total; bool last, valid; };
     unsigned fw0 = 0, fwn = 0;                   // fwin holds the candidate counts of bins fw0 .. fw0 + fwn - 1
-    unsigned it_f = 0xffffffffu, it_c = 0, it_e = 0;         // iterator: bin, next chunk start, bin end
+    unsigned it_f = 0;                           // next bin to look at
     auto next_chunk = [&]() {
         Chunk c;
-        c.start = 0; c.cnt = 0; c.last = false; c.valid = false;
-        while (it_c >= it_e) {                   // advance to the next non-empty bin
-            ++it_f;
-            if (it_f >= nf) { it_f = nf; return c; }
-            if (fwn == 0 || it_f + 1 > fw0 + fwn) {          // stage the next window of bin offsets (uniform: every thread gets here together)
+#pragma unroll
+        for (int i = 0; i < SW_MB; ++i) { c.start[i] = 0; c.cnt[i] = 0; }
+        c.total = 0; c.last = true; c.valid = false;
+        int nb = 0;
+        while (it_f < nf) {
+            if (fwn == 0 || it_f >= fw0 + fwn) {             // stage the next window of bin counts (uniform: every thread gets here together)
                 lds_barrier();
                 fw0 = it_f;
                 fwn = nf - it_f < (unsigned)FWIN ? nf - it_f : (unsigned)FWIN;
                 for (unsigned i = tid; i < fwn; i += SW_TPB) fwin[i] = fcnt[fw0 + i];
                 __syncthreads();
             }
-            it_c = it_f * (unsigned)BIN_CAP;
-            it_e = it_c + (fwin[it_f - fw0] < (unsigned)BIN_CAP ? fwin[it_f - fw0] : (unsigned)BIN_CAP);
+            unsigned n = fwin[it_f - fw0];
+            n = n < (unsigned)BIN_CAP ? n : (unsigned)BIN_CAP;
+            if (n == 0) { ++it_f; continue; }
+            if (nb == SW_MB || c.total + n > (unsigned)SW_TPB) break;        // this bin opens the next chunk
+#pragma unroll
+            for (int i = 0; i < SW_MB; ++i)
+                if (i == nb) { c.start[i] = it_f * (unsigned)BIN_CAP; c.cnt[i] = n; }
+            c.total += n;
+            ++nb;
+            ++it_f;
         }
-        c.start = it_c;
-        c.cnt = it_e - it_c < (unsigned)SW_TPB ? it_e - it_c : (unsigned)SW_TPB;
-        it_c += c.cnt;
-        c.last = it_c >= it_e;
-        c.valid = true;
+        c.valid = nb > 0;
         return c;
     };
     struct Regs { unsigned long long key; unsigned pos; };
     auto issue = [&](const Chunk &c, Regs &d) {      // unconditional loads (clamped index): no exec-mask branch, so the waits stay counted
-        const unsigned idx = c.valid ? c.start + ((unsigned)tid < c.cnt ? (unsigned)tid : c.cnt - 1u) : 0u;
+        unsigned t = c.valid ? ((unsigned)tid < c.total ? (unsigned)tid : c.total - 1u) : 0u, idx = 0u;
+        bool found = !c.valid;
+#pragma unroll
+        for (int i = 0; i < SW_MB; ++i) {
+            const bool here = !found && t < c.cnt[i];
+            idx = here ? c.start[i] + t : idx;
+            found = found || here;
+            t -= found ? 0u : c.cnt[i];
+        }
         d.key = ckey[idx];
         d.pos = cpos[idx];
     };
@@ -495,7 +522,7 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
         const int x = (int)(pos >> 16), y = (int)(pos & 0xffffu);
         const int cx = (int)__umulhi((unsigned)x, g.cmul), cy = (int)__umulhi((unsigned)y, g.cmul);
         const int lx = x - cx * cs, ly = y - cy * cs;
-        bool alive = (unsigned)tid < c.cnt;
+        bool alive = (unsigned)tid < c.total;
         const int cell0 = cy * g.gstride + cx;                               // padded address of cell (cy-1, cx-1)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -643,7 +670,7 @@ static unsigned sel_target()
 {
     const char *e = getenv("HALO_SEL_TARGET");       // tuning aid: expected candidates per fine bin
     const int v = e ? atoi(e) : 0;
-    return v >= 8 && v <= 256 ? (unsigned)v : 128u;
+    return v >= 8 && v <= BIN_CAP / 2 ? (unsigned)v : (unsigned)(BIN_CAP / 2);      // bins are Poisson-filled: keep 2x headroom
 }
 
 BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t arad, int64_t mrad)
@@ -690,7 +717,7 @@ BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t 
 // cannot bound the range for free): zero the records, then the same reduction the selector runs on its own.
 int score_range_exact(const void *score, int dtype, int64_t B, int64_t hw, void *range_out, hipStream_t st)
 {
-    if (hipMemsetAsync(range_out, 0, (size_t)B * sizeof(SelHdr), st) != hipSuccess) return fail(HALO_E_LAUNCH, "score range: memset failed");
+    hipLaunchKernelGGL(k_sel_zero, dim3(1u), dim3(256), 0, st, (uint4 *)range_out, (size_t)B * sizeof(SelHdr) / 16);
     BinWs ws;
     memset(&ws, 0, sizeof(ws));
     ws.hdr = (SelHdr *)range_out;
@@ -720,7 +747,11 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     ws.plist = (unsigned *)(base + p.off_plist);
     const BinGeom &g = p.g;
     const long long hw = (long long)g.H * g.W;
-    if (hipMemsetAsync(base, 0, p.zero_bytes, st) != hipSuccess) return fail(HALO_E_LAUNCH, "halo_greedy_select: memset failed");
+    {   // zero_bytes is a multiple of 256 (take() aligns every array), base is 256-byte aligned
+        const size_t n16 = p.zero_bytes / 16;
+        const unsigned gz = (unsigned)(cdiv((int64_t)n16, 256) < 512 ? cdiv((int64_t)n16, 256) : 512);
+        hipLaunchKernelGGL(k_sel_zero, dim3(gz ? gz : 1u), dim3(256), 0, st, (uint4 *)base, n16);
+    }
     // 128 blocks per image for the passes with a per-block fixed cost (LDS histogram flush: 2048 atomics; 16 KiB table
     // staging): 1024 blocks measured 2x SLOWER end to end, and a wider scatter grid no faster beside the feature stream.
     const unsigned gx = (unsigned)(cdiv(hw, 256) < 128 ? cdiv(hw, 256) : 128);

@@ -9,7 +9,7 @@ import numpy as np
 
 NB1 = 2048
 SW_SURV = 256
-BIN_CAP = 256     # slots per fine bin (k_sel_place): a fuller bin hands the image over untouched
+BIN_CAP = 128     # slots per fine bin (k_sel_place): a fuller bin hands the image over untouched
 
 
 def order_key(v):
@@ -28,7 +28,7 @@ KEY_NEG_INF = np.uint64(0x000fffffffffffff)
 KEY_POS_INF = np.uint64(0xfff0000000000000)
 
 
-def binned_select(score, n_regions, mrad, target=128, captot=None):
+def binned_select(score, n_regions, mrad, target=64, captot=None):
     """-> (status 'done'|'bail', picks [(h, w)], stats).  `score` (H,W) float32|float64 is not modified."""
     H, W = score.shape
     n = min(int(n_regions), H * W)

@@ -840,8 +840,9 @@ def test_score_and_select_replay_from_a_hip_graph(dev):
         graph.replay()
         torch.cuda.synchronize()
         w = want[seed - 1]
-        for got, exp in zip((score, picks, npk, act, sel, am), w):
-            assert bits_equal(got.cpu().numpy(), exp.cpu().numpy()) if got.dtype.is_floating_point else torch.equal(got, exp), (rep, seed)
+        for name, got, exp in zip(("score", "picks", "n_picked", "active", "selected", "active_mask"), (score, picks, npk, act, sel, am), w):
+            same = bits_equal(got.cpu().numpy(), exp.cpu().numpy()) if got.dtype.is_floating_point else torch.equal(got, exp)
+            assert same, (rep, seed, name, int((got != exp).sum()))
 
 
 def test_lowres_gram_mode_on_degenerate_grids(dev):
