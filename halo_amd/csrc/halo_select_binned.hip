@@ -48,6 +48,7 @@ constexpr int FWIN = 1024;       // fine-bin offsets staged in LDS at a time
 // per-image arrays: element [b * stride + i]
 constexpr int BIN_CAP = 128;     // slots per fine bin (expected occupancy <= target = 64: equal-width sub-bins of a 1/2048 slice of
                                  // the value range are Poisson-filled; a fuller bin -- a plateau of ties -- hands the image over)
+constexpr int PL_U = 8;          // row segments (loads, then returned atomics) a k_sel_place thread keeps in flight
 constexpr int SW_MB = 4;         // the sweep filters up to SW_MB consecutive bins (<= 256 candidates together) in one pass
 
 struct BinWs {
@@ -153,12 +154,12 @@ __global__ void __launch_bounds__(256) k_sel_hist1(const T *__restrict__ score, 
     __syncthreads();
     const T *sc = score + (size_t)b * hw;
     const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += 4 * stride) {
-        double v[4];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += PL_U * stride) {
+        double v[PL_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = i + u * stride < hw ? (double)sc[i + u * stride] : __longlong_as_double(0xfff0000000000000ll);
+        for (int u = 0; u < PL_U; ++u) v[u] = i + u * stride < hw ? (double)sc[i + u * stride] : __longlong_as_double(0xfff0000000000000ll);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PL_U; ++u) {
             const unsigned long long k = order_key(v[u]);
             if (k < KEY_POS_INF && k != KEY_NEG_INF) {
                 double t;
@@ -262,21 +263,21 @@ __global__ void __launch_bounds__(256) k_sel_place(const T *__restrict__ score, 
     unsigned long long *ckey = ws.ckey + (size_t)b * g.nfmax * BIN_CAP;
     unsigned *cpos = ws.cpos + (size_t)b * g.nfmax * BIN_CAP;
     bool overflow = false;
-    // four row segments per iteration: their loads and their returned atomics are in flight together (beside a
+    // PL_U row segments per iteration: their loads and their returned atomics are in flight together (beside a
     // bandwidth-bound kernel each dependent round trip costs microseconds)
     for (int y = blockIdx.x; y < g.H; y += gridDim.x)
-        for (int x0 = 0; x0 < g.W; x0 += 4 * 256) {
-            double v[4];
+        for (int x0 = 0; x0 < g.W; x0 += PL_U * 256) {
+            double v[PL_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PL_U; ++u) {
                 const int x = x0 + u * 256 + tid;
                 v[u] = x < g.W ? (double)sc[(size_t)y * g.W + x] : __longlong_as_double(0xfff0000000000000ll);    // -inf: never a candidate
             }
-            unsigned long long k[4];
-            unsigned f[4], slot[4];
-            bool cand[4];
+            unsigned long long k[PL_U];
+            unsigned f[PL_U], slot[PL_U];
+            bool cand[PL_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PL_U; ++u) {
                 k[u] = order_key(v[u]);
                 cand[u] = k[u] < KEY_POS_INF && k[u] != KEY_NEG_INF;
                 double t = 0.0;
@@ -291,9 +292,9 @@ __global__ void __launch_bounds__(256) k_sel_place(const T *__restrict__ score, 
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) slot[u] = cand[u] ? atomicAdd(&fcur[f[u]], 1u) : 0u;      // four returns in flight
+            for (int u = 0; u < PL_U; ++u) slot[u] = cand[u] ? atomicAdd(&fcur[f[u]], 1u) : 0u;      // PL_U returns in flight
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < PL_U; ++u)
                 if (cand[u]) {
                     if (slot[u] < (unsigned)BIN_CAP) {
                         const size_t sl = (size_t)f[u] * BIN_CAP + slot[u];

@@ -9,18 +9,19 @@ def summarize(d):
     import collections, csv, glob, statistics as st
     f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    sel = [r for r in rows if "k_sel_" in r["Kernel_Name"] or "k_greedy" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"]]
-    # the range records of the RANGED runs are prepared outside the timed call: drop that k_sel_range and its memset (the one
-    # right before it); inside a selection call k_sel_range is followed by k_sel_hist1 with no memset between
+    sel = [r for r in rows if "k_sel_" in r["Kernel_Name"] or "k_greedy" in r["Kernel_Name"]]
+    # the range records of the RANGED runs are prepared outside the timed call (k_sel_zero + k_sel_range back to back, no
+    # k_sel_hist1 behind them): drop that pair
     keep = []
-    for i, r in enumerate(sel):
-        nxt = sel[i + 1]["Kernel_Name"] if i + 1 < len(sel) else ""
-        nxt2 = sel[i + 2]["Kernel_Name"] if i + 2 < len(sel) else ""
-        if "k_sel_range" in r["Kernel_Name"] and "fillBuffer" in nxt:
+    i = 0
+    while i < len(sel):
+        n0 = sel[i]["Kernel_Name"]
+        n1 = sel[i + 1]["Kernel_Name"] if i + 1 < len(sel) else ""
+        n2 = sel[i + 2]["Kernel_Name"] if i + 2 < len(sel) else ""
+        if "k_sel_zero" in n0 and "k_sel_range" in n1 and "k_sel_hist1" not in n2:
+            i += 2
             continue
-        if "fillBuffer" in r["Kernel_Name"] and "k_sel_range" in nxt and "fillBuffer" in nxt2:
-            continue
-        keep.append(r)
+        keep.append(sel[i]); i += 1
     sel = keep
     # split at the biggest pause between selection kernels
     gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]), i) for i, (a, b) in enumerate(zip(sel[:-1], sel[1:]))]
