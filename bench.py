@@ -620,7 +620,11 @@ def main():
             out["cpu_baseline"] = {"value": round(1.0 / s_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
                                    "sample": "1 warm-up + %d timed ring images, oracle/halo_oracle.c (OpenMP, %d threads = usable "
                                              "host cores of %d visible), median s/image = %.2f"
-                                             % (a.cpu_images, cores, os.cpu_count() or 1, s_img)}
+                                             % (a.cpu_images, cores, os.cpu_count() or 1, s_img),
+                                   # the honest anchor for "the reference's PyTorch path on host cores": its own code, measured by the
+                                   # survey in the build container (the reference cannot travel to the GPU box)
+                                   "reference_pytorch_probe": "SURVEY.md section 6: the reference's own code (torch CPU, 8 threads, geoopt/yacs "
+                                                              "stand-ins) scored + selected 0.11-0.17 images/s at this shape"}
             # same inputs -> the GPU picks of image 0 must equal the oracle's
             from halo_amd.core.active.build import acquire_batch
             act = torch.zeros((1, Hh, Ww), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
