@@ -260,14 +260,15 @@ class Pipeline:
         self.slot_lo[k] = (lo, b)
         self.step_no += 1
 
-    def finish_round(self, n_images, host_backend=False):
+    def finish_round(self, n_images, host_backend=False, warm=False):
         """The path's one exchange step: behind the last selection of the round, ONE all-gather of the
         rank's wire block on the communication stream.  Returns (tables, counts) of the whole pool in pool order."""
         from halo_amd.pool import gather_wire, pack_tables_into
         with torch.cuda.stream(self.s_comm):
             for e in self.selected_done:
                 self.s_comm.wait_event(e)
-            n = self.rows_done           # the round's exchange format: one launch for the whole block
+            # the round's exchange format: one launch for the whole block (warm-up: any rows, the tables are still zero)
+            n = min(self.B, self.wire.shape[0]) if warm else self.rows_done
             pack_tables_into(self.wire[:n], self.round_tables[:n], self.round_counts[:n])
             if host_backend:
                 self.s_comm.synchronize()
@@ -485,7 +486,12 @@ def main():
 
     for _ in range(a.warmup):
         pipe.step(False)
+    if a.warmup > 0:
+        # one untimed pass of the round's exchange as well: first use of a kernel / of the communicator costs a code-object
+        # load or a lazy connection set-up (100+ ms on a fresh box), which is what warm-up steps are for
+        pipe.finish_round(n_pool, host_backend, warm=True)
     pipe.drain()
+    pipe.exchange_ms = None
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)

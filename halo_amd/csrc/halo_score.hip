@@ -526,7 +526,16 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
                                                           double *__restrict__ partials)
 {
     __shared__ int lab[RI_TH + 2][RI_TW + 2 + 2];                  // +2: row stride 68 words
+    // A class with n of the window's cnt pixels contributes (-d) * log(d + 1e-6), d = n / cnt: at most 9 x 9 distinct values,
+    // formed once per block by the same expression (same bits) instead of a division and a logarithm per class and pixel.
+    __shared__ float term[10][10];
     const int b = blockIdx.z, tid = threadIdx.x;
+    if (tid < 100) {
+        const int c = tid / 10, n = tid % 10;
+        float tv = 0.0f;
+        if (c > 0 && n > 0 && n <= c) { const float d = (float)n / (float)c; tv = (-d) * det_logf(d + 1e-6f); }
+        term[c][n] = tv;
+    }
     const int X0 = blockIdx.x * RI_TW, Y0 = blockIdx.y * RI_TH;
     const long long hw = (long long)H * W;
     const TL *pp = pred + (size_t)b * hw;
@@ -550,7 +559,9 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
     for (int j = 0; j < 4; ++j) {
         const int x = xb + j;
         if (!live || x >= W) break;
-        const float cnt = (float)(ny * ((x > 0 ? 1 : 0) + 1 + (x < W - 1 ? 1 : 0)));
+        const int cnti = ny * ((x > 0 ? 1 : 0) + 1 + (x < W - 1 ? 1 : 0));
+        const float cnt = (float)cnti;
+        const float *tc = term[cnti];
         float a = 0.0f;
         int cur = -1;
         while (true) {
@@ -565,8 +576,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) n += v[dy][j + dx] == nxt ? 1 : 0;
-            const float d = (float)n / cnt;
-            a = a + (-d) * det_logf(d + 1e-6f);
+            a = a + tc[n];
             cur = nxt;
         }
         const float res = a / logK;
