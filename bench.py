@@ -535,6 +535,24 @@ def main():
 
     feat_ms = pipe.feat_kernel_ms()
     lr_logit_ms, lr_feat_ms = pipe.lowres_pass_ms()
+    flat = None
+    if rank == 0 and not lowres and feat_ms:
+        # this box's own ceiling for the same bytes, after the timed region: a flat non-temporal read (no arithmetic, no
+        # plane structure, nothing written) of the B feature tensors one k_feat_reduce launch streams, nothing beside it
+        from halo_amd import _lib
+        fb = feat[0:B]
+        assert fb.is_contiguous()
+        nb = fb.numel() * fb.element_size()
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        torch.cuda.synchronize(dev)
+        for i in range(7):                       # first pass = warm-up
+            _lib.check(_lib.lib().halo_hbm_read_probe(_lib.ptr(fb), nb, _lib.ptr(sink), 0, _lib.stream_ptr(dev)), "halo_hbm_read_probe")
+            ev[i].record()
+        torch.cuda.synchronize(dev)
+        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(1, 6)]
+        flat = {"GB/s": round(nb / (float(np.mean(ms)) * 1e-3) / 1e9, 1), "avg_ms": round(float(np.mean(ms)), 4), "bytes": nb,
+                "what": "flat non-temporal read of the same feature tensors, alone, after the timed region (halo_hbm_read_probe)"}
     assert pipe.min_picked == n_regions, "selection stopped early"
     assert pipe.tables_consistent, "pick tables of the same images differ between steps (race in the pipeline)"
 
@@ -566,7 +584,8 @@ def main():
                                       if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms)},
+                         "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms),
+                         "flat_read": flat, "frac_of_flat_read": None if not flat else round(achieved / flat["GB/s"], 4)},
             "path_algorithmic_GBps": round(path_bytes_per_image * value / world / 1e9, 1),
             "pipeline_tables_consistent": bool(pipe.tables_consistent),
             "exchange": {"collectives_per_round": 1 if use_dist else 0, "ms": None if pipe.exchange_ms is None else round(pipe.exchange_ms, 3),

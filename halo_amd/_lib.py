@@ -61,6 +61,7 @@ SIGNATURES = {
     "halo_reset_round_state": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "halo_undo_picks": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "halo_device_identity": (_int, [_int, C.c_char_p, _sz]),
+    "halo_hbm_read_probe": (_int, [_vp, _sz, _vp, _int, _vp]),
     "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "halo_score_range_bytes": (_sz, [_i64]),
     "halo_score_range": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp]),

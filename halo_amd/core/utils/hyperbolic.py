@@ -7,8 +7,10 @@ hyperbolic.py:8) runs in halo_amd/csrc/halo_hyperbolic.hip.
 
 Autograd: `HyperMapper.expmap` and `HyperMLR.forward` -- the two ops of the head
 tail the training step differentiates (core/models/classifier.py:553-554) -- are
-torch.autograd.Functions with HIP backward kernels; the other methods (logmap, distances) are
-inference-only and raise if a gradient is requested instead of silently detaching.
+torch.autograd.Functions with HIP backward kernels; logmap and the two distances (no caller
+differentiates them) keep their HIP forward and get their backward from torch autograd over a
+device-side statement of the same formulas; bilinear_align_corners is inference-only and raises
+if a gradient is requested instead of silently detaching.
 """
 import math
 
@@ -25,9 +27,72 @@ PROJ_EPS = 1e-3
 def _no_grad_only(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            "this halo_amd op (logmap / poincare_distance[_origin] / bilinear_align_corners) is inference-only: no caller "
-            "in the reference differentiates it; wrap the call in torch.no_grad().  HyperMapper.expmap and "
-            "HyperMLR.forward ARE differentiable (HIP backward kernels)")
+            "this halo_amd op (bilinear_align_corners) is inference-only: the training path resizes with F.interpolate "
+            "(core/models/classifier.py); wrap the call in torch.no_grad()")
+
+
+# ---- geoopt's formulas in device-side torch arithmetic, for the BACKWARD of the three ops no caller of the reference
+# differentiates (logmap, poincare_distance, poincare_distance_origin: hyperbolic.py:51-83).  Their forward values always come
+# from the HIP kernels; only when a gradient is requested does autograd run through this restatement (geoopt >= 0.3
+# stereographic/math.py: sabs + 1e-15, artanh clamp 1 - 1e-7, norm clamp_min 1e-15, project eps 1e-5 / 4e-3).
+def _t_artan_k(x, c):
+    ks = math.sqrt(abs(-c) + 1e-15)
+    z = (x * ks).clamp(-1 + 1e-7, 1 - 1e-7)
+    return (torch.log1p(z) - torch.log1p(-z)) * (0.5 / ks)
+
+
+def _t_project(x, c):
+    eps = 4e-3 if x.dtype == torch.float32 else 1e-5
+    maxnorm = (1 - eps) / math.sqrt(abs(-c) + 1e-15)
+    norm = x.norm(dim=-1, keepdim=True, p=2).clamp_min(1e-15)
+    return torch.where(norm > maxnorm, x / norm * maxnorm, x)
+
+
+def _t_logmap(x, c):
+    y = x.double()
+    yn = y.norm(dim=-1, p=2, keepdim=True).clamp_min(1e-15)
+    return _t_project((y / yn) * _t_artan_k(yn, c), c)
+
+
+def _t_dist0(x, c, dim):
+    return 2.0 * _t_artan_k(x.norm(dim=dim, p=2), c)
+
+
+def _t_dist(x, y, c):
+    k = -c
+    a = -x
+    x2 = a.pow(2).sum(dim=-1, keepdim=True)
+    y2 = y.pow(2).sum(dim=-1, keepdim=True)
+    xy = (a * y).sum(dim=-1, keepdim=True)
+    num = (1 - 2 * k * xy - k * y2) * a + (1 + k * x2) * y
+    den = (1 - 2 * k * xy + k ** 2 * x2 * y2).clamp_min(1e-15)
+    return 2.0 * _t_artan_k((num / den).norm(dim=-1, p=2), c)
+
+
+class _HipForwardTorchBackward(torch.autograd.Function):
+    """forward(*tensors) on a HIP kernel; backward through `restate(*tensors)`, the same formula in torch ops on the device."""
+
+    @staticmethod
+    def forward(ctx, fwd, restate, *tensors):
+        ctx.restate = restate
+        ctx.save_for_backward(*tensors)
+        with torch.no_grad():
+            return fwd(*tensors)
+
+    @staticmethod
+    def backward(ctx, gout):
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(ctx.needs_input_grad[2 + i]) for i, t in enumerate(ctx.saved_tensors)]
+            out = ctx.restate(*ins)
+            want = [t for t in ins if t.requires_grad]
+            grads = iter(torch.autograd.grad(out, want, gout.to(out.dtype), allow_unused=True))
+        return (None, None) + tuple(next(grads) if t.requires_grad else None for t in ins)
+
+
+def _differentiable(fwd, restate, *tensors):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return _HipForwardTorchBackward.apply(fwd, restate, *tensors)
+    return fwd(*tensors)
 
 
 def _split(shape, dim):
@@ -188,8 +253,11 @@ class HyperMapper(object):
         return torch.where(n > maxnorm, scaled / n * maxnorm, scaled)
 
     def logmap(self, x):
-        """project(logmap0(x.double())) over the last dim (hyperbolic.py:51-60)."""
-        _no_grad_only(x)
+        """project(logmap0(x.double())) over the last dim (hyperbolic.py:51-60).  Differentiable (no caller of the reference
+        asks: the backward runs through device-side torch autograd of the same formula)."""
+        return _differentiable(self._logmap_fwd, lambda t: _t_logmap(t, self.c), x)
+
+    def _logmap_fwd(self, x):
         dev = _lib.require_device(x)
         x = x.double().contiguous()
         y = torch.empty_like(x)
@@ -201,8 +269,10 @@ class HyperMapper(object):
         return y
 
     def poincare_distance(self, x, y):
-        """geoopt dist over the last dim (hyperbolic.py:62-72; no live caller in-tree)."""
-        _no_grad_only(x, y)
+        """geoopt dist over the last dim (hyperbolic.py:62-72; no live caller in-tree).  Differentiable like logmap."""
+        return _differentiable(self._pdist_fwd, lambda a, b: _t_dist(*torch.broadcast_tensors(a, b), self.c), x, y)
+
+    def _pdist_fwd(self, x, y):
         dev = _lib.require_device(x, y)
         in_dtype = torch.promote_types(x.dtype, y.dtype)
         x, y = torch.broadcast_tensors(x, y)
@@ -215,8 +285,10 @@ class HyperMapper(object):
         return out if in_dtype == torch.float64 else out.to(in_dtype)
 
     def poincare_distance_origin(self, x, dim=-1):
-        """geoopt dist0: 2/sqrt(c) artanh(sqrt(c)||x||), dtype preserved (hyperbolic.py:74-83)."""
-        _no_grad_only(x)
+        """geoopt dist0: 2/sqrt(c) artanh(sqrt(c)||x||), dtype preserved (hyperbolic.py:74-83).  Differentiable like logmap."""
+        return _differentiable(lambda t: self._dist0_fwd(t, dim), lambda t: _t_dist0(t, self.c, dim), x)
+
+    def _dist0_fwd(self, x, dim=-1):
         dev = _lib.require_device(x)
         x = x.contiguous()
         d, outer, C, inner = _split(x.shape, dim)

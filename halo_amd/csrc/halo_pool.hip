@@ -4,6 +4,8 @@
 //                           16-byte stores (three torch fills ran at 0.65-1.9 TB/s)
 //   halo_undo_picks         the same state restored from a pick table: only the windows the selection wrote are rewritten
 //   halo_device_identity    PCI bus id + UUID of a device (ranks of one node must hold distinct devices)
+//   halo_hbm_read_probe     measurement aid: a flat non-temporal streaming read of a buffer, the box's own ceiling for the
+//                           bytes the feature kernel streams (bench.py reports it beside the roofline; nothing depends on it)
 #include "halo_common.hpp"
 
 namespace halo {
@@ -125,6 +127,32 @@ extern "C" int halo_undo_picks(const double *picks, const int32_t *n_picked, int
                        (const int *)n_picked, (int)n_regions, (int)H, (int)W, (int)active_radius, (int)mask_radius, active, selected,
                        (long long *)active_mask);
     return check_launch("halo_undo_picks");
+}
+
+// every lane keeps eight 16-byte loads in flight; a workgroup walks the buffer in steps of the whole grid
+__global__ void __launch_bounds__(256) k_read_probe(const u4_t *__restrict__ x, size_t n16, unsigned *__restrict__ sink)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned acc = 0;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(x + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const u4_t v = __builtin_nontemporal_load(x + i); acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x9e3779b9u && sink) atomicXor(sink, acc);      // keeps the loads alive; practically never taken
+}
+
+extern "C" int halo_hbm_read_probe(const void *buf, size_t bytes, void *sink, int blocks, void *stream)
+{
+    if (!buf || (bytes & 15) || ((uintptr_t)buf & 15)) return fail(HALO_E_ARG, "halo_hbm_read_probe: 16-byte aligned buffer and size required");
+    if (bytes == 0) return HALO_OK;
+    if (blocks <= 0) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_read_probe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u4_t *)buf, bytes / 16, (unsigned *)sink);
+    return check_launch("halo_hbm_read_probe");
 }
 
 extern "C" int halo_device_identity(int device, char *buf, size_t len)

@@ -221,7 +221,10 @@ int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int64_t H, int6
  *  - halo_undo_picks: the same state restored after a selection whose state WAS the round-1 state, from its pick
  *    table: only the windows select_pixels_to_label wrote (build.py:52-62) are rewritten.
  *  - halo_device_identity: "pci=<bus id> uuid=<32 hex digits>" of a HIP device ordinal, NUL-terminated, len >= 64
- *    (the ranks of a node must hold distinct devices). */
+ *    (the ranks of a node must hold distinct devices).
+ *  - halo_hbm_read_probe: measurement aid, no reference counterpart: one flat non-temporal streaming read of `bytes` bytes
+ *    (16-byte aligned pointer and size) on `blocks` workgroups of 256 threads (<= 0: 4096); `sink` is 4 writable bytes or
+ *    NULL.  bench.py times it over the tensors the scoring pass streams and reports the rate beside the roofline. */
 int halo_pack_pick_tables(const double *picks, const int32_t *n_picked, int64_t B, int64_t n_regions, int32_t *wire,
                           int64_t wire_row_stride, void *stream);
 int halo_reset_round_state(uint8_t *active, uint8_t *selected, int64_t *active_mask, int64_t n_pixels, void *stream);
@@ -229,6 +232,7 @@ int halo_undo_picks(const double *picks, const int32_t *n_picked, int64_t B, int
                     int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected, int64_t *active_mask,
                     void *stream);
 int halo_device_identity(int device, char *buf, size_t len);
+int halo_hbm_read_probe(const void *buf, size_t bytes, void *sink, int blocks, void *stream);
 
 /* ---- training-side window losses, float32 tensors, float64 sums on the device ----
  *  - NegativeLearningLoss (core/loss/negative_learning_loss.py:6-16): sums = {sum -mask*log(1-p+1e-6), sum mask},

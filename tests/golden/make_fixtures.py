@@ -286,6 +286,27 @@ def gen_grads(hyp):
                     f"{tag}__g_z": z.grad.numpy(), f"{tag}__g_embed": embed.grad.numpy(),
                     f"{tag}__g_P": mlr.P_MLR.grad.numpy(), f"{tag}__g_A": mlr.A_MLR.grad.numpy()})
         print(f"  grads {tag}: |g_z| max {float(z.grad.abs().max()):.3e}, nan {bool(torch.isnan(z.grad).any())}")
+    # the three geoopt-backed ops nothing in the tree differentiates (hyperbolic.py:51-83) are differentiable all the same:
+    # d <op(x), W> / d x under the reference's autograd -- own generator, so the arrays above keep their bits
+    g3 = torch.Generator().manual_seed(77)
+    for c in (1.0, 0.7):
+        m = hyp.HyperMapper(c=c)
+        xh = m.expmap(torch.randn(21, 9, generator=g3, dtype=torch.float32) * 0.5).detach()
+        yh = m.expmap(torch.randn(21, 9, generator=g3, dtype=torch.float32) * 0.5).detach()
+        xh[4] = m.expmap(torch.randn(9, generator=g3, dtype=torch.float32) * 40.0).detach()     # on the projection limit
+        W1 = torch.randn(21, 9, generator=g3, dtype=torch.float64)
+        W2 = torch.randn(21, generator=g3, dtype=torch.float64)
+        tag = f"ops_c{c}"
+        out[f"{tag}__x"], out[f"{tag}__y"], out[f"{tag}__W1"], out[f"{tag}__W2"] = xh.numpy(), yh.numpy(), W1.numpy(), W2.numpy()
+        a = xh.clone().requires_grad_(True)
+        (m.logmap(a) * W1).sum().backward()
+        out[f"{tag}__g_logmap"] = a.grad.numpy()
+        a = xh.clone().requires_grad_(True); b = yh.clone().requires_grad_(True)
+        (m.poincare_distance(a, b) * W2).sum().backward()
+        out[f"{tag}__g_dist_x"], out[f"{tag}__g_dist_y"] = a.grad.numpy(), b.grad.numpy()
+        a = xh.clone().requires_grad_(True)
+        (m.poincare_distance_origin(a) * W2).sum().backward()
+        out[f"{tag}__g_dist0"] = a.grad.numpy()
     np.savez_compressed(os.path.join(OUT_DIR, "grads.npz"), **out)
 
 

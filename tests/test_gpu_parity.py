@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COMBOS, all_case_combos, case_files, max_abs_diff
+from conftest import COMBOS, GOLDEN, all_case_combos, case_files, max_abs_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -481,7 +481,7 @@ def test_helper_methods_vs_reference_and_oracle(golden, dev):
 def test_head_tails(golden, dev):
     """classifier.py:364-379 (v2: resize logits AND embedding) and :552-558 (v3+: logits only)."""
     from halo_amd.core.models.classifier import hyper_head_tail
-    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners
     d = golden("case_b_64x128_c16_o19")
     H, W, C, O = (int(v) for v in d["meta_HWCO"])
     mlr = HyperMLR(C, O, c=1.0).to(dev)
@@ -500,8 +500,43 @@ def test_head_tails(golden, dev):
     assert out_t.requires_grad and np.abs(out_t.detach().cpu().numpy() - d["logit"]).max() < 1e-5
     out_t.sum().backward()
     assert mlr.P_MLR.grad is not None and torch.isfinite(mlr.P_MLR.grad).all()
-    with pytest.raises(NotImplementedError):
-        HyperMapper(1.0).logmap(t(d["embed_lr"], dev).requires_grad_(True))   # inference-only op: refuses to detach silently
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        bilinear_align_corners(t(d["embed_lr"], dev).requires_grad_(True), (H, W))   # refuses to detach silently
+
+
+@pytest.mark.parametrize("c", [1.0, 0.7])
+def test_logmap_and_distance_gradients_vs_reference_autograd(dev, c):
+    """hyperbolic.py:51-83 under the reference's autograd (tests/golden/grads.npz, `ops_c*`): forward values are the HIP kernels'
+    (equal to the no-grad call bit for bit), input gradients equal geoopt's -- row 4 sits on the projection limit."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper
+    g = np.load(os.path.join(GOLDEN, "grads.npz"))
+    tag = f"ops_c{c}"
+    m = HyperMapper(c)
+    x, y = t(g[tag + "__x"], dev), t(g[tag + "__y"], dev)
+    W1, W2 = t(g[tag + "__W1"], dev), t(g[tag + "__W2"], dev)
+
+    def rel(a, ref):
+        return float(np.abs(a.cpu().numpy() - ref).max() / np.abs(ref).max())
+
+    a = x.clone().requires_grad_(True)
+    out = m.logmap(a)
+    assert out.requires_grad and torch.equal(out.detach(), m.logmap(x))
+    (out * W1).sum().backward()
+    assert rel(a.grad, g[tag + "__g_logmap"]) < 1e-12
+    a, b = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    out = m.poincare_distance(a, b)
+    assert torch.equal(out.detach(), m.poincare_distance(x, y))
+    (out * W2).sum().backward()
+    assert rel(a.grad, g[tag + "__g_dist_x"]) < 1e-12 and rel(b.grad, g[tag + "__g_dist_y"]) < 1e-12
+    a = x.clone().requires_grad_(True)
+    out = m.poincare_distance(a, y)                       # one side only
+    (out * W2).sum().backward()
+    assert rel(a.grad, g[tag + "__g_dist_x"]) < 1e-12
+    a = x.clone().requires_grad_(True)
+    out = m.poincare_distance_origin(a)
+    assert torch.equal(out.detach(), m.poincare_distance_origin(x))
+    (out * W2).sum().backward()
+    assert rel(a.grad, g[tag + "__g_dist0"]) < 1e-12
 
 
 def test_select_randomized_shapes_and_radii(dev):
