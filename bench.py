@@ -36,9 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# more hardware queues than ROCm's default 4: the score stream and the selection streams of the
-# batches in flight must not serialise behind each other (read by the HIP runtime at initialisation)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# hardware queues: the package's choice (halo_amd/__init__.py: 2, measured), read by the HIP runtime at initialisation
+import halo_amd  # noqa: E402,F401
 
 import numpy as np
 import torch
@@ -264,6 +263,24 @@ class Pipeline:
         """The path's one exchange step: behind the last selection of the round, ONE all-gather of the
         rank's wire block on the communication stream.  Returns (tables, counts) of the whole pool in pool order."""
         from halo_amd.pool import gather_wire, pack_tables_into
+        variant = os.environ.get("HALO_BENCH_WARM_VARIANT", "") if warm else ""
+        if variant == "waits":
+            for e in self.selected_done:
+                self.s_comm.wait_event(e)
+            return None
+        if variant == "pack_default":
+            n = min(self.B, self.wire.shape[0])
+            pack_tables_into(self.wire[:n], self.round_tables[:n], self.round_counts[:n])
+            return gather_wire(self.wire, n_images, self.n)
+        if variant == "pack_only":
+            with torch.cuda.stream(self.s_comm):
+                n = min(self.B, self.wire.shape[0])
+                pack_tables_into(self.wire[:n], self.round_tables[:n], self.round_counts[:n])
+            return None
+        if variant == "touch":
+            with torch.cuda.stream(self.s_comm):
+                self.wire[:1].zero_()
+            return None
         with torch.cuda.stream(self.s_comm):
             for e in self.selected_done:
                 self.s_comm.wait_event(e)
@@ -486,7 +503,7 @@ def main():
 
     for _ in range(a.warmup):
         pipe.step(False)
-    if a.warmup > 0:
+    if a.warmup > 0 and not os.environ.get("HALO_BENCH_NO_WARM_EXCHANGE"):
         # one untimed pass of the round's exchange as well: first use of a kernel / of the communicator costs a code-object
         # load or a lazy connection set-up (100+ ms on a fresh box), which is what warm-up steps are for
         pipe.finish_round(n_pool, host_backend, warm=True)
@@ -535,6 +552,20 @@ def main():
 
     feat_ms = pipe.feat_kernel_ms()
     lr_logit_ms, lr_feat_ms = pipe.lowres_pass_ms()
+    batch_alone = None
+    if rank == 0 and not lowres and feat_ms and os.environ.get("HALO_BENCH_BATCH_ALONE"):
+        # diagnostic: the scoring call on each resident batch with nothing beside it, after the timed region
+        from halo_amd.core.active.floating_region import score_maps
+        batch_alone = []
+        for lo_ in range(0, R, B):
+            score_maps(logit[lo_:lo_ + B], feat[lo_:lo_ + B], "entropy", "radius", True, None, size=3)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                score_maps(logit[lo_:lo_ + B], feat[lo_:lo_ + B], "entropy", "radius", True, None, size=3)
+            e1.record(); torch.cuda.synchronize(dev)
+            batch_alone.append(round(e0.elapsed_time(e1) / 4, 3))
     flat = None
     if rank == 0 and not lowres and feat_ms:
         # this box's own ceiling for the same bytes, after the timed region: a flat non-temporal read (no arithmetic, no
@@ -585,6 +616,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms),
+                         "avg_launch_ms_even_odd_steps": [round(float(np.mean(feat_ms[0::2])), 4), round(float(np.mean(feat_ms[1::2])), 4)] if len(feat_ms) > 1 else None,
+                         "scoring_call_alone_ms_per_batch": batch_alone,
+                         "launch_ms": [round(v, 3) for v in feat_ms] if os.environ.get("HALO_BENCH_LAUNCH_MS") else None,
                          "flat_read": flat, "frac_of_flat_read": None if not flat else round(achieved / flat["GB/s"], 4)},
             "path_algorithmic_GBps": round(path_bytes_per_image * value / world / 1e9, 1),
             "pipeline_tables_consistent": bool(pipe.tables_consistent),

@@ -10,17 +10,24 @@ import os as _os
 import sys as _sys
 
 
+HW_QUEUES = "2"
+
+
 def _configure_hw_queues():
-    """RegionSelection keeps 4 side streams + the caller's stream busy (bench.py: 1 + 3 + 2); ROCm maps streams onto
-    GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.  The variable is read when the HIP
-    runtime initialises, so it is set here -- at import, normally the first lines of train.py -- unless the user chose a value
-    or the runtime is already up (then RegionSelection warns once if it is too small)."""
+    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The acquisition keeps up to six streams busy
+    (RegionSelection: 4 side streams + the caller's; bench.py: 1 + 3 + 1), and it runs FASTEST on TWO queues: kernels of
+    different streams still overlap inside a queue, while with three or more queues the short kernels that follow a long one on
+    the scoring stream start 40 us late and run up to 3x slower (k_box3_minmax 127 vs 43 us; bench.py, interleaved: 1355-1392
+    images/s on 1-2 queues, 1337-1368 on 3-8; --source lowres 5900 vs 5260, --branch ripu 10 590 vs 9 680;
+    profiles/r03_hw_queues.txt).  The variable is read when the HIP runtime initialises, so it is set here -- at import,
+    normally the first lines of train.py -- unless the user chose a value or the runtime is already up (then RegionSelection
+    warns once)."""
     if "GPU_MAX_HW_QUEUES" in _os.environ:
         return
     torch = _sys.modules.get("torch")
     if torch is not None and getattr(torch, "cuda", None) is not None and torch.cuda.is_initialized():
         return
-    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    _os.environ["GPU_MAX_HW_QUEUES"] = HW_QUEUES
 
 
 _configure_hw_queues()

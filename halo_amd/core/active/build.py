@@ -190,20 +190,17 @@ _QUEUE_WARNED = False
 
 
 def _check_hw_queues(n_streams):
-    """Warn once when fewer hardware queues than concurrently used streams are configured (see halo_amd/__init__.py)."""
+    """Warn once when the HIP runtime came up with more hardware queues than the acquisition runs best on (halo_amd/__init__.py:
+    two; ROCm's default is four) and nobody chose that value."""
     global _QUEUE_WARNED
-    if _QUEUE_WARNED:
+    if _QUEUE_WARNED or "GPU_MAX_HW_QUEUES" in os.environ:
         return
-    try:
-        have = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))      # ROCm's default when unset
-    except ValueError:
-        return
-    if have < n_streams + 1:
-        _QUEUE_WARNED = True
-        import warnings
-        warnings.warn("halo_amd RegionSelection drives %d side streams beside the caller's, but GPU_MAX_HW_QUEUES=%d hardware "
-                      "queues are configured: streams sharing a queue serialise.  Export GPU_MAX_HW_QUEUES=8 (or import halo_amd) "
-                      "before the first HIP call (INTEGRATION.md section 3)." % (n_streams, have), RuntimeWarning, stacklevel=3)
+    _QUEUE_WARNED = True
+    import warnings
+    warnings.warn("halo_amd RegionSelection drives %d side streams beside the caller's; the HIP runtime was initialised before "
+                  "halo_amd was imported, with ROCm's default of 4 hardware queues.  The acquisition measured 2-12 %% faster on "
+                  "GPU_MAX_HW_QUEUES=2: import halo_amd (or export the variable) before the first HIP call (INTEGRATION.md "
+                  "section 3)." % n_streams, RuntimeWarning, stacklevel=3)
 
 
 def _side_streams(dev, n):

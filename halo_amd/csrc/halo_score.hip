@@ -335,11 +335,21 @@ template <typename T, int VEC, int MODE, int UNROLL, int FO>
 __global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, 4))) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
                                                      long long hw, double ks, double rks, T *__restrict__ out,
                                                      double *__restrict__ partials, const float *__restrict__ logit,
-                                                     long long lbstride, int unc_type, float *__restrict__ ent)
+                                                     long long lbstride, int unc_type, float *__restrict__ ent, unsigned xcd_g)
 {
     const int b = blockIdx.y;
+    // workgroup -> chunk of FTPB * VEC pixels.  Workgroups are dealt to the 8 XCDs round-robin; with the plain map the
+    // eight XCDs share every 16 KiB of every plane.  XCD-contiguous in granules of xcd_g chunks instead: the j-th workgroup
+    // of XCD x (j = id >> 3) takes chunk (j / G) * 8G + x * G + j % G, so an XCD's consecutive workgroups read adjacent
+    // 2 KiB runs (tools/feat_microbench2.hip: +1.6-1.9 % for any granule >= 64 KiB; this kernel, interleaved on one
+    // allocation, tools/ab_feat_map.py: -1.5 % f64, -3 % f32 per scoring call; the chunks past the last whole group of 8G
+    // keep the plain map).
+    unsigned bx = blockIdx.x;
+    const unsigned xj = blockIdx.x >> 3;
+    if (xcd_g != 0 && blockIdx.x < (gridDim.x / (8 * xcd_g)) * (8 * xcd_g))
+        bx = (xj / xcd_g) * 8 * xcd_g + (blockIdx.x & 7) * xcd_g + xj % xcd_g;
     // every address below is (block-uniform base, kept in SGPRs) + (this lane's offset inside the block, one VGPR)
-    const long long blk0 = (long long)blockIdx.x * (FTPB * VEC);
+    const long long blk0 = (long long)bx * (FTPB * VEC);
     const unsigned lane0 = threadIdx.x * VEC;
     const long long i0 = blk0 + lane0;
     const bool live = i0 < hw;
@@ -392,13 +402,16 @@ __global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, 4)
             }
         }
     };
-    const bool ent_first = (blockIdx.x & 1) != 0;
+    // (with the XCD-contiguous map the order alternates per granule of an XCD's workgroups -- one resident generation of
+    // 32 CUs x 8 blocks --, which measured 0.4 % better than alternating XCDs on the slow plateau and equal on the fast one)
+    const bool ent_first = ((xcd_g != 0 ? xj / xcd_g : blockIdx.x) & 1) != 0;
     double mn = 0.0, mx = 0.0;
-    // the channel walk: two copies of this short code (before or after the entropy), one of the long entropy code
-    auto walk = [&]() {
-        const T *p = feat + (size_t)b * bstride + blk0;      // advanced by scalar adds: the plane bases stay in SGPRs
-        int c = 0;
-        for (; c + UNROLL <= C; c += UNROLL) {
+    // the channel walk, before or after the entropy (ent_first).  (Tried: a per-block pause point INSIDE the walk -- a hash of the
+    // chunk index, in steps of UNROLL planes, the sums still one sequential chain -- so that the VALU phases of co-resident
+    // blocks spread over the whole walk: 11.42 against 11.13 ms per launch in the bench, five interleaved runs each.)
+    const T *p = feat + (size_t)b * bstride + blk0;          // advanced by scalar adds: the plane bases stay in SGPRs
+    auto walk_to = [&](int c, const int c_end) {
+        for (; c + UNROLL <= c_end; c += UNROLL) {
             T v[UNROLL][VEC];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u, p += hw) VecLoad<T, VEC>::ld(p + lane0, v[u]);
@@ -407,12 +420,14 @@ __global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, 4)
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[j] = fma_t(v[u][j], v[u][j], acc[j]);
         }
-        for (; c < C; ++c, p += hw) {
+        for (; c < c_end; ++c, p += hw) {
             T v[VEC];
             VecLoad<T, VEC>::ld(p + lane0, v);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = fma_t(v[j], v[j], acc[j]);
         }
+    };
+    auto finish = [&]() {
         T r[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -429,18 +444,18 @@ __global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, 4)
         for (int j = 1; j < VEC; ++j) { mn = nan_min(mn, (double)r[j]); mx = nan_max(mx, (double)r[j]); }
     };
     if constexpr (FO > 0) {
-        if (live && !ent_first) walk();
+        if (live && !ent_first) { walk_to(0, C); finish(); }
         entropy_part();
-        if (live && ent_first) walk();
+        if (live && ent_first) { walk_to(0, C); finish(); }
     } else {
-        if (live) walk();
+        if (live) { walk_to(0, C); finish(); }
     }
     // dead lanes of the last block take thread 0's value (always live) so they cannot disturb min/max
     __shared__ double seed[2];
     if (threadIdx.x == 0) { seed[0] = mn; seed[1] = mx; }
     __syncthreads();
     if (!live) { mn = seed[0]; mx = seed[1]; }
-    block_minmax<FTPB>(mn, mx, partials + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    block_minmax<FTPB>(mn, mx, partials + ((size_t)b * gridDim.x + bx) * 2);
 }
 
 // ---------------------------------------------------------------- quantize_uncert_map (floating_region.py:94-110)
@@ -1811,9 +1826,16 @@ static void launch_feat(const T *feat, long long bstride, int C, long long hw, i
 {
     dim3 grid(nblk, B), block(FTPB);
     constexpr int UNROLL = 8;      // channel planes in flight per lane (16: no gain beside the selection kernels, 6 % slower alone)
+    // granule of the XCD-contiguous chunk map: 256 chunks (512 KiB per plane), halved until a group of 8 granules fits
+    const char *eg = getenv("HALO_FEAT_XCD_GRANULE");      // A/B switch, read per call: -1 = the plain map
+    const int env_g = eg ? atoi(eg) : 256;
+    unsigned xcd_g = (unsigned)(env_g < 0 ? 0 : env_g);
+    while (xcd_g > 1 && 8 * xcd_g > (unsigned)nblk) xcd_g >>= 1;
+    if (8 * xcd_g > (unsigned)nblk) xcd_g = 0;
 #define HALO_FEAT(M, FO_)                                                                                               \
     hipLaunchKernelGGL((k_feat_reduce<T, VEC, M, UNROLL, FO_>), grid, block, 0, st, feat, bstride, C, hw, ks, rks, out, \
-                       partials, fl ? fl->logit : nullptr, fl ? fl->bstride : 0ll, fl ? fl->unc_type : 0, fl ? fl->ent : nullptr)
+                       partials, fl ? fl->logit : nullptr, fl ? fl->bstride : 0ll, fl ? fl->unc_type : 0, fl ? fl->ent : nullptr, \
+                       xcd_g)
     const int fo = fl ? fl->O : 0;
     if (mode == 0) {
         if (fo == 19) HALO_FEAT(0, 19); else if (fo == 16) HALO_FEAT(0, 16); else HALO_FEAT(0, 0);

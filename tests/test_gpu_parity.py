@@ -515,6 +515,8 @@ def test_logmap_and_distance_gradients_vs_reference_autograd(dev, c):
     x, y = t(g[tag + "__x"], dev), t(g[tag + "__y"], dev)
     W1, W2 = t(g[tag + "__W1"], dev), t(g[tag + "__W2"], dev)
 
+    GTOL = 1e-9     # row 4: 1 / (1 - z^2) ~ 5e4 amplifies the last-bit differences between the device's and the host's log1p / norm
+
     def rel(a, ref):
         return float(np.abs(a.cpu().numpy() - ref).max() / np.abs(ref).max())
 
@@ -522,21 +524,21 @@ def test_logmap_and_distance_gradients_vs_reference_autograd(dev, c):
     out = m.logmap(a)
     assert out.requires_grad and torch.equal(out.detach(), m.logmap(x))
     (out * W1).sum().backward()
-    assert rel(a.grad, g[tag + "__g_logmap"]) < 1e-12
+    assert rel(a.grad, g[tag + "__g_logmap"]) < GTOL
     a, b = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
     out = m.poincare_distance(a, b)
     assert torch.equal(out.detach(), m.poincare_distance(x, y))
     (out * W2).sum().backward()
-    assert rel(a.grad, g[tag + "__g_dist_x"]) < 1e-12 and rel(b.grad, g[tag + "__g_dist_y"]) < 1e-12
+    assert rel(a.grad, g[tag + "__g_dist_x"]) < GTOL and rel(b.grad, g[tag + "__g_dist_y"]) < GTOL
     a = x.clone().requires_grad_(True)
     out = m.poincare_distance(a, y)                       # one side only
     (out * W2).sum().backward()
-    assert rel(a.grad, g[tag + "__g_dist_x"]) < 1e-12
+    assert rel(a.grad, g[tag + "__g_dist_x"]) < GTOL
     a = x.clone().requires_grad_(True)
     out = m.poincare_distance_origin(a)
     assert torch.equal(out.detach(), m.poincare_distance_origin(x))
     (out * W2).sum().backward()
-    assert rel(a.grad, g[tag + "__g_dist0"]) < 1e-12
+    assert rel(a.grad, g[tag + "__g_dist0"]) < GTOL
 
 
 def test_select_randomized_shapes_and_radii(dev):
@@ -1185,6 +1187,28 @@ def test_fused_tail_equals_the_round2_tail_bitwise(dev):
                             so = so.copy(); so[a[b]] = -np.inf
                         assert bits_equal(new[0][b].cpu().numpy(), so) and bits_equal(new[1][b].cpu().numpy(), io) and \
                             bits_equal(new[2][b].cpu().numpy(), uo), (H, W, dt, unc, pur, norm, b)
+
+
+def test_feature_kernel_chunk_map_is_invisible(dev):
+    """k_feat_reduce deals its 2 KiB pixel chunks to workgroups XCD-contiguously (granule 256 chunks, halved to fit small maps,
+    plain map past the last whole group): the three maps are the same bits as with the plain map (HALO_FEAT_XCD_GRANULE=-1),
+    with odd granules, and as the oracle's -- chunk counts that are / are not multiples of 8 granules, a partial last chunk."""
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(404)
+    for (H, W, C) in ((64, 256, 8), (40, 72, 8), (96, 1000, 4), (128, 1024, 4), (1024, 2048, 2), (5, 11, 3)):
+        for dt in (np.float64, np.float32):
+            logit = rng.standard_normal((2, 19, H, W)).astype(np.float32)
+            emb = (rng.standard_normal((2, C, H, W)) * 0.05).astype(dt)
+            args = (t(logit, dev), t(emb, dev), "entropy", "radius", True, None)
+            new = score_maps(*args, size=3)
+            for g in ("-1", "3", "1", "1000000"):
+                old = _with_env({"HALO_FEAT_XCD_GRANULE": g}, lambda: score_maps(*args, size=3))
+                for x, y in zip(new, old):
+                    assert bits_equal(x.cpu().numpy(), y.cpu().numpy()), (H, W, dt, g)
+            if H * W <= 128 * 1024:
+                so, io, uo = ho.floating_region_score(logit[1:2], emb[1:2], "entropy", "radius", True, None, size=3, purity_type="radius")
+                assert bits_equal(new[0][1].cpu().numpy(), so) and bits_equal(new[1][1].cpu().numpy(), io) and bits_equal(new[2][1].cpu().numpy(), uo)
 
 
 def test_region_selection_full_size_real_geometry_vs_oracle(dev):

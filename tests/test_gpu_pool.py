@@ -86,6 +86,9 @@ def test_device_identity(dev):
     assert assert_distinct_devices(0) == [ident]                      # no process group: one rank
     with pytest.raises(Exception):
         device_identity(torch.cuda.device_count() + 7)
+    # the refused query must not leave a sticky HIP error behind for the next launch of anybody
+    assert float(torch.ones(4, device=dev).sum()) == 4.0
+    torch.cuda.synchronize(dev)
 
 
 def _bench(args, env=None, timeout=1500):
@@ -96,6 +99,38 @@ def _bench(args, env=None, timeout=1500):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0])
+
+
+def test_contiguous_allocation_and_bandwidth_probes(dev):
+    """Measurement aids of halo_amd.pool: a tensor in its own physically contiguous range behaves like any tensor and frees its
+    memory with its last view; the two probes read what they are given (rates are positive, bad geometry is refused)."""
+    from halo_amd import _lib
+    from halo_amd.pool import alloc_contiguous, contiguous_memory_stats, probe_streaming
+    before = contiguous_memory_stats()
+    t = alloc_contiguous((3, 8, 64, 128), torch.float64, dev)                  # planes of 64 KiB
+    assert t.shape == (3, 8, 64, 128) and t.dtype == torch.float64 and t.is_contiguous() and t.device == dev
+    t.copy_(torch.arange(t.numel(), device=dev, dtype=torch.float64).view_as(t))
+    assert float(t.sum()) == float(t.numel() * (t.numel() - 1) // 2)
+    mid = contiguous_memory_stats()
+    assert mid["live"] == before["live"] + 1 and mid["failed"] == before["failed"]
+    assert mid["contiguous_bytes"] + mid["fallback_bytes"] == before["contiguous_bytes"] + before["fallback_bytes"] + t.numel() * 8
+    rows = probe_streaming(t, planes=8, plane_bytes=64 * 128 * 8, window_bytes=2 * 8 * 64 * 128 * 8, reps=2)
+    assert [r[0] for r in rows] == [0, 2 * 8 * 65536] and [r[1] for r in rows] == [2 * 8 * 65536, 8 * 65536]
+    assert all(r[2] > 0 and r[3] > 0 for r in rows)
+    # the walk probe computes sum of squares per pixel over the planes of a group: check it (16 bytes per lane -> 2 doubles)
+    out = torch.zeros((3, 64, 128), dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().halo_hbm_walk_probe(_lib.ptr(t), t.numel() * 8, 65536, 8, _lib.ptr(out), _lib.stream_ptr(dev)), "walk")
+    assert torch.equal(out, (t * t).sum(dim=1))
+    with pytest.raises(_lib.HaloHipError):
+        _lib.check(_lib.lib().halo_hbm_walk_probe(_lib.ptr(t), t.numel() * 8, 1000, 8, _lib.ptr(out), _lib.stream_ptr(dev)), "walk")
+    with pytest.raises(_lib.HaloHipError):
+        _lib.check(_lib.lib().halo_hbm_read_probe(t.data_ptr() + 8, 1024, None, 0, _lib.stream_ptr(dev)), "read")
+    view = t[1:2]
+    del t
+    assert contiguous_memory_stats()["live"] == mid["live"]                    # the view keeps the block alive
+    assert float(view[0, 0, 0, 0]) == 8 * 64 * 128
+    del view
+    assert contiguous_memory_stats()["live"] == before["live"]
 
 
 @pytest.mark.parametrize("resets", ["kernel", "undo"])
