@@ -755,6 +755,7 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     }
     // 128 blocks per image for the passes with a per-block fixed cost (LDS histogram flush: 2048 atomics; 16 KiB table
     // staging): 1024 blocks measured 2x SLOWER end to end, and a wider scatter grid no faster beside the feature stream.
+    // (round 3, two hardware queues: 8 ... 128 blocks per image make no difference to the bench beside the feature stream)
     const unsigned gx = (unsigned)(cdiv(hw, 256) < 128 ? cdiv(hw, 256) : 128);
     const unsigned gy = (unsigned)(g.H < 128 ? g.H : 128);
     dim3 blk(256);

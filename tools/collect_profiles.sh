@@ -19,6 +19,12 @@ done
 for br in ripu hyper; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$br -- python3 $R/bench.py --branch $br --cpu-images 0 --steps 8 --warmup 2 > /dev/null 2>&1
 done
+# the default line six more times, consecutive processes (on some boxes they alternate between two plateaus)
+for rep in 1 2 3 4 5 6; do
+  python3 $R/bench.py --cpu-images 0 2> /dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('run $rep: %.1f images/s  ms_per_step %.3f  k_feat_reduce %.3f ms (frac %.4f)  tail %.3f ms  flat read of the same tensors %.0f GB/s' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], d['ms_per_step'] - r['avg_launch_ms'], r['flat_read']['GB/s']))" >> $OUT/bench_repeats.txt
+done
+python3 $R/tools/ab_feat_map.py 2> /dev/null > $OUT/ab_feat_map.txt
 METHODS=auto,serial python3 $R/tools/time_select.py > $OUT/select_timing.txt 2>&1
 python3 $R/tools/time_region_selection.py > $OUT/region_selection_timing.txt 2>&1
 python3 $R/tools/time_secondary.py > $OUT/secondary_kernels.txt 2>&1

@@ -104,7 +104,7 @@ def main():
                    "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all waves; GRBM_GUI_ACTIVE / 8 = shader cycles",
                    "per_kernel_avg_per_launch": per}, open(os.path.join(DST, RND + "_pmc_lowres.json"), "w"), indent=1)
     for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt", "tail_timeline.txt", "ab_lowres_dma.txt", "two_ranks_one_gpu.txt", "select_timing_ranged.txt",
-              "select16_breakdown.txt"):
+              "select16_breakdown.txt", "bench_repeats.txt", "ab_feat_map.txt"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]

@@ -22,6 +22,10 @@ for B in (1, 4, 16, 32):
     feat = torch.randn((4, 256, H, W), device=dev, dtype=torch.float64) * 0.01
     logit = torch.randn((4, 19, H, W), device=dev)
     s2 = torch.cuda.Stream(dev)
+    # the selection runs where the pipelines run it (bench.py, RegionSelection): on a HIGH-priority stream.  On the default
+    # stream it can share a hardware queue with the streaming stream (GPU_MAX_HW_QUEUES=2, halo_amd/__init__.py) and then waits
+    # for every 131 072-workgroup feature launch ahead of it in that queue to be dispatched (34 ms for B = 16 in one run).
+    hi = torch.cuda.Stream(dev, priority=-1)
     ref = None
     for method in methods:
         def run(loaded):
@@ -38,8 +42,9 @@ for B in (1, 4, 16, 32):
                     for _ in range(12):
                         score_maps(logit, feat, "entropy", "radius", True, None, want_maps=False)
             t0 = time.perf_counter()
-            picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt, method=method, score_range=rec)
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(hi):
+                picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt, method=method, score_range=rec)
+            hi.synchronize()
             dt = (time.perf_counter() - t0) * 1e3
             torch.cuda.synchronize()
             return dt, picks, npk
