@@ -144,6 +144,34 @@ __global__ void __launch_bounds__(256) k_flat_xcd(const d2_t *__restrict__ x, si
     if (a == 123.456) out[0] = a;
 }
 
+// a block owns S consecutive 2 KiB chunks; per group of 8 planes it walks its S chunks one after the other (8 loads in flight),
+// so the 8 pages of the group are used S times in a row and every plane is read in runs of S * 2 KiB; S accumulator pairs per lane
+template <int S, int WPE>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, WPE)))
+k_planes_sub(const double *__restrict__ feat, long long bstride, int C, long long hw, double *__restrict__ out, unsigned G)
+{
+    const int b = blockIdx.y;
+    const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const unsigned bx = G ? (j / G) * 8 * G + xcd * G + j % G : blockIdx.x;
+    const long long i0 = ((long long)bx * S * 128 + threadIdx.x) * 2;
+    const double *p = feat + (size_t)b * bstride + i0;
+    double a0[S], a1[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) a0[s] = a1[s] = 0;
+    for (int c = 0; c + 8 <= C; c += 8) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            d2_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p + (size_t)(c + u) * hw + s * 256));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0[s] = __builtin_fma(v[u].x, v[u].x, a0[s]); a1[s] = __builtin_fma(v[u].y, v[u].y, a1[s]); }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) { d2_t r; r.x = a0[s]; r.y = a1[s]; *reinterpret_cast<d2_t *>(out + (size_t)b * hw + i0 + s * 256) = r; }
+}
+
 // images along x: consecutive blocks work on the same chunk of different images (grid (B, chunks))
 template <int U, int TPB_>
 __global__ void __launch_bounds__(TPB_) __attribute__((amdgpu_waves_per_eu(1, 4)))
@@ -245,6 +273,9 @@ int main()
         snprintf(nm, sizeof nm, "planes XCD granule %u chunks, 128 thr, unroll 16", Gk);
         run(nm, [&] { hipLaunchKernelGGL((k_planes_g<16, 128, 4>), G(128), dim3(128), 0, 0, feat, bs, C, hw, out, Gk); });
     }
+#define SUB(S_, W_, Gk) { char nm[96]; snprintf(nm, sizeof nm, "planes, block owns %d chunks (%d KiB runs), <=%d waves, granule %u", S_, 2 * S_, W_, Gk); \
+    run(nm, [&] { hipLaunchKernelGGL((k_planes_sub<S_, W_>), dim3((unsigned)(hw / 2 / 128 / S_), B), dim3(128), 0, 0, feat, bs, C, hw, out, Gk); }); }
+    SUB(1, 4, 256u) SUB(2, 4, 128u) SUB(4, 4, 64u) SUB(8, 4, 32u) SUB(4, 4, 0u) SUB(4, 8, 64u) SUB(8, 8, 32u) SUB(16, 4, 16u) SUB(2, 4, 256u) SUB(4, 4, 256u)
     run("planes, one image per XCD at a time", [&] { hipLaunchKernelGGL((k_planes_imgxcd<8, 128>), dim3((unsigned)(hw / 2 / 128) * B), dim3(128), 0, 0, feat, bs, C, hw, out, (unsigned)(hw / 2 / 128)); });
     for (int blocks : {4096, 16384}) {
         char nm[96]; snprintf(nm, sizeof nm, "flat nt read, %d workgroups of 256", blocks);
