@@ -263,24 +263,6 @@ class Pipeline:
         """The path's one exchange step: behind the last selection of the round, ONE all-gather of the
         rank's wire block on the communication stream.  Returns (tables, counts) of the whole pool in pool order."""
         from halo_amd.pool import gather_wire, pack_tables_into
-        variant = os.environ.get("HALO_BENCH_WARM_VARIANT", "") if warm else ""
-        if variant == "waits":
-            for e in self.selected_done:
-                self.s_comm.wait_event(e)
-            return None
-        if variant == "pack_default":
-            n = min(self.B, self.wire.shape[0])
-            pack_tables_into(self.wire[:n], self.round_tables[:n], self.round_counts[:n])
-            return gather_wire(self.wire, n_images, self.n)
-        if variant == "pack_only":
-            with torch.cuda.stream(self.s_comm):
-                n = min(self.B, self.wire.shape[0])
-                pack_tables_into(self.wire[:n], self.round_tables[:n], self.round_counts[:n])
-            return None
-        if variant == "touch":
-            with torch.cuda.stream(self.s_comm):
-                self.wire[:1].zero_()
-            return None
         with torch.cuda.stream(self.s_comm):
             for e in self.selected_done:
                 self.s_comm.wait_event(e)
@@ -503,7 +485,7 @@ def main():
 
     for _ in range(a.warmup):
         pipe.step(False)
-    if a.warmup > 0 and not os.environ.get("HALO_BENCH_NO_WARM_EXCHANGE"):
+    if a.warmup > 0:
         # one untimed pass of the round's exchange as well: first use of a kernel / of the communicator costs a code-object
         # load or a lazy connection set-up (100+ ms on a fresh box), which is what warm-up steps are for
         pipe.finish_round(n_pool, host_backend, warm=True)
