@@ -84,6 +84,11 @@ def parse():
                          "fills on a housekeeping stream")
     ap.add_argument("--dump-tables", default="", help="rank 0 writes the round's gathered pick tables / counts / owners (pool "
                                                       "order) to this .npz after the timed region (tests compare world sizes)")
+    ap.add_argument("--tail", choices=["auto", "split", "inline"], default="auto",
+                    help="split = the scorer's tail kernels on their own stream, forked behind the feature pass (halo_score_maps_split), "
+                         "so that they overlap the next step's feature kernel; inline = on the scoring stream, between two feature "
+                         "kernels; auto = split for the 'hyper' purity (0.95 ms of tail: +6 %%), inline otherwise (0.26 ms of tail: "
+                         "beside the next feature kernel it costs that kernel 0.5-0.9 ms, profiles/r03_tail_split.txt)")
     ap.add_argument("--sel-priority", type=int, default=-1, help="stream priority of the selection streams (-1 = high)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
@@ -136,7 +141,7 @@ class Pipeline:
     collect in one wire block that is exchanged ONCE, behind the last step."""
 
     def __init__(self, dev, feat, logit, gt, B, n_regions, rows, depth, lowres=False, branch="halo",
-                 resets="undo", sel_priority=-1, lr_mode="gram"):
+                 resets="undo", sel_priority=-1, lr_mode="gram", tail="auto"):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
@@ -167,6 +172,16 @@ class Pipeline:
         self.reset_done = [torch.cuda.Event() for _ in range(D)]
         self.scored = [torch.cuda.Event() for _ in range(D)]
         self.selected_done = [torch.cuda.Event() for _ in range(D)]
+        # the scorer's tail (min / max, normalise, product, mask: 0.26 ms of small kernels) on its own high-priority stream,
+        # forked behind the feature pass: it overlaps the NEXT step's feature kernel instead of standing between two of them
+        self.split = (tail == "split" or (tail == "auto" and self.pur == "hyper")) and not lowres and self.pur in ("radius", "euc_norm", "hyper")
+        if self.split:
+            from halo_amd.core.active.floating_region import score_workspace
+            self.s_tail = torch.cuda.Stream(dev, priority=-1)
+            self.ws = [score_workspace(B, Hh, Ww, dev) for _ in range(D)]                 # one per call in flight
+            self.maps = [(torch.empty((B, Hh, Ww), dtype=sdt, device=dev), torch.empty((B, Hh, Ww), dtype=torch.float32, device=dev))
+                         for _ in range(D)]
+            self.fork_ev = [(self.lib.halo_event_create(), self.lib.halo_event_create()) for _ in range(D)]   # untimed steps
         self.ev = []                       # (start, stop) HIP events around k_feat_reduce
         self.ev_lr = []                    # low-res source: (logit start, logit stop, embedding start, embedding stop, images)
         self.tables = [torch.zeros((B, n_regions, 3), dtype=torch.float64, device=dev) for _ in range(D)]      # warm-up steps
@@ -236,10 +251,14 @@ class Pipeline:
                                                                score_range=None if self.rng[k] is None else self.rng[k][:b])
                 self.score[k][:b].copy_(sc)
             else:
+                kw = {}
+                if self.split:
+                    kw = dict(tail_stream=self.s_tail, workspace=self.ws[k], maps=(self.maps[k][0][:b], self.maps[k][1][:b]))
                 _, self.imp, self.unc_map = score_maps(lb, fb, self.unc, self.pur, self.norm, gb, size=3, K=self.K, c=1.0,
                                                        active=self.active[k][:b], want_maps=True, out=self.score[k][:b],
-                                                       events=evs, score_range=None if self.rng[k] is None else self.rng[k][:b])
-            self.scored[k].record(self.s_score)
+                                                       events=evs if evs is not None or not self.split else self.fork_ev[k],
+                                                       score_range=None if self.rng[k] is None else self.rng[k][:b], **kw)
+            self.scored[k].record(self.s_tail if self.split else self.s_score)
         with torch.cuda.stream(self.s_sel[k]):
             self.s_sel[k].wait_event(self.scored[k])
             dst = (self.tables[k][:b], self.counts[k][:b]) if row is None else (self.round_tables[row:row + b], self.round_counts[row:row + b])
@@ -288,6 +307,8 @@ class Pipeline:
         for st in self.s_sel:
             st.synchronize()
         self.s_house.synchronize()
+        if self.split:
+            self.s_tail.synchronize()
         self.s_comm.synchronize()
         ee = getattr(self, "_exchange_events", None)
         if ee is not None:
@@ -481,7 +502,7 @@ def main():
     else:
         seeds = [rank * R + s_ for s_ in range(R)]                      # every rank its own R images
     feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, rows, a.depth, lowres, a.branch, a.resets, a.sel_priority, a.lr_mode)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, rows, a.depth, lowres, a.branch, a.resets, a.sel_priority, a.lr_mode, a.tail)
 
     for _ in range(a.warmup):
         pipe.step(False)
@@ -607,6 +628,7 @@ def main():
             "exchange": {"collectives_per_round": 1 if use_dist else 0, "ms": None if pipe.exchange_ms is None else round(pipe.exchange_ms, 3),
                          "bytes_per_rank": int(pipe.wire.numel() * 4), "rows_checked_against_local_results": exchange_checked},
             "state_resets": a.resets, "host_threads_per_rank": host_threads,
+            "tail": "on its own stream beside the next feature kernel (halo_score_maps_split)" if pipe.split else "inline on the scoring stream",
         }
         per_rank = [(shard_range(n_pool, r_, world)[1] - shard_range(n_pool, r_, world)[0]) / rank_dts[r_] for r_ in range(world)]
         out["per_rank_images_per_s"] = {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)}

@@ -31,6 +31,11 @@ def _workspace(dev, nbytes, tag):
     return buf
 
 
+def score_workspace(B, H, W, dev):
+    """A scratch buffer of the scorer's size for a caller that keeps several score_maps calls in flight (one per call)."""
+    return torch.empty(int(_lib.lib().halo_score_workspace_bytes(int(B), int(H), int(W))), dtype=torch.uint8, device=dev)
+
+
 def score_dtype(pur_type, decoder_out):
     if pur_type in ("radius", "euc_norm") and decoder_out is not None and decoder_out.dtype == torch.float64:
         return torch.float64
@@ -46,7 +51,8 @@ def new_score_range(B, dev):
 
 
 def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
-               size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, out=None, events=None, score_range=None):
+               size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, out=None, events=None, score_range=None,
+               tail_stream=None, workspace=None, maps=None):
     """Batched FloatingRegionScore.forward.
 
     logit (B,O,H,W) float32; decoder_out (B,C,H,W) float64|float32; ground_truth (B,H,W) int64;
@@ -54,6 +60,9 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
     out: optional pre-allocated (B,H,W) score tensor to write into (pipelined callers own their
     buffers); events: optional (start, stop) handles from halo_event_create, recorded around the
     feature-reduction kernel; score_range: optional new_score_range(B, dev) to receive the maps' value ranges.
+    tail_stream (pipelined callers): a torch stream that receives everything behind the passes over the inputs
+    (halo_score_maps_split; needs `events`, whose stop event is the fork, a `workspace` of its own per call in flight --
+    score_workspace(B, H, W, dev) -- and preallocated `maps` = (impurity, uncertainty)); the results are complete on it.
     Returns (score, impurity, uncertainty), each (B,H,W); the last two are None if not want_maps.
     """
     if pur_type not in _lib.PUR:
@@ -98,15 +107,33 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
         score = out
     else:
         score = torch.empty((B, H, W), dtype=odt, device=dev)
-    imp = torch.empty((B, H, W), dtype=odt, device=dev) if want_maps else None
-    unc = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_maps else None
+    if maps is not None:
+        imp, unc = maps
+        assert imp.shape == (B, H, W) and imp.dtype == odt and imp.is_contiguous() and unc.shape == (B, H, W) and unc.dtype == torch.float32
+    else:
+        imp = torch.empty((B, H, W), dtype=odt, device=dev) if want_maps else None
+        unc = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_maps else None
     L = _lib.lib()
     nws = L.halo_score_workspace_bytes(B, H, W)
-    ws = _workspace(dev, nws, "score")
+    if workspace is not None:
+        assert workspace.dtype == torch.uint8 and workspace.numel() >= nws and workspace.device == dev
+        ws = workspace
+    else:
+        ws = _workspace(dev, nws, "score")
     psize = size if purity_size is None else purity_size
     ev0, ev1 = events if events is not None else (None, None)
     if score_range is not None:
         assert score_range.is_contiguous() and score_range.device == dev and score_range.numel() >= L.halo_score_range_bytes(B)
+    if tail_stream is not None:
+        assert events is not None and workspace is not None and (maps is not None or not want_maps), \
+            "tail_stream needs events, a workspace of the call's own and preallocated maps"
+        rc = L.halo_score_maps_split(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt),
+                                     _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
+                                     _lib.PUR[pur_type], 1 if normalize else 0, int(size), int(psize), int(K), float(c),
+                                     _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr(dev), _lib.C.c_void_p(tail_stream.cuda_stream), ev0, ev1, _lib.ptr(score_range))
+        _lib.check(rc, "halo_score_maps_split")
+        return score, imp, unc
     rc = L.halo_score_maps_timed(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt),
                                  _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
                                  _lib.PUR[pur_type], 1 if normalize else 0, int(size), int(psize), int(K), float(c),

@@ -1970,7 +1970,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
                       int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                       void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
                       void *ev_feat_stop, const LrDims *lr, void *ev_logit_start = nullptr, void *ev_logit_stop = nullptr,
-                      void *score_range = nullptr)
+                      void *score_range = nullptr, void *tail_stream = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
@@ -2088,6 +2088,14 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
             else { nblk_imp = (int)cdiv(hw, FTPB); launch_feat<float, 1>((const float *)feat, feat_bstride, (int)C, hw, (int)B, mode, ks, rks, (float *)imp_raw, part_imp, nblk_imp, st); }
         }
         if (ev_feat_stop) (void)hipEventRecord((hipEvent_t)ev_feat_stop, st);
+    }
+    // everything behind the passes over the inputs may run on another stream of the caller (halo_score_maps_split): the small
+    // kernels of the tail then overlap the NEXT call's feature pass instead of standing between two of them
+    if (tail_stream && (hipStream_t)tail_stream != st) {
+        if (!need_feat || !ev_feat_stop) return fail(HALO_E_ARG, "halo_score_maps_split: a purity type that reads decoder_out and ev_feat_stop are required with a tail stream");
+        if (hipStreamWaitEvent((hipStream_t)tail_stream, (hipEvent_t)ev_feat_stop, 0) != hipSuccess)
+            return fail(HALO_E_LAUNCH, "halo_score_maps_split: hipStreamWaitEvent: %s", hipGetErrorString(hipGetLastError()));
+        st = (hipStream_t)tail_stream;
     }
     dim3 grid1((unsigned)nblk1, (unsigned)B);
     if (pur_type == HALO_PUR_HYPER) {
@@ -2230,6 +2238,21 @@ extern "C" int halo_score_maps_timed(const float *logit, int64_t logit_bstride, 
     return score_impl(logit, logit_bstride, feat, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
                       normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream,
                       ev_feat_start, ev_feat_stop, nullptr, nullptr, nullptr, score_range);
+}
+
+// halo_score_maps_timed with the tail (min / max, normalisation, product, mask: everything behind the passes over logit and
+// decoder_out) enqueued on `tail_stream`, which first waits for ev_feat_stop (recorded on `stream` behind the feature pass).
+// The outputs are complete on tail_stream; the workspace belongs to the call until then.
+extern "C" int halo_score_maps_split(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                                     int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                                     int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                                     int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                                     void *workspace, size_t workspace_bytes, void *stream, void *tail_stream, void *ev_feat_start,
+                                     void *ev_feat_stop, void *score_range)
+{
+    return score_impl(logit, logit_bstride, feat, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
+                      normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream,
+                      ev_feat_start, ev_feat_stop, nullptr, nullptr, nullptr, score_range, tail_stream);
 }
 
 // FloatingRegionScore.forward on bilinearly upsampled (align_corners=True) low-resolution sources

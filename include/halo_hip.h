@@ -123,6 +123,19 @@ int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void 
                           void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
                           void *ev_feat_stop, void *score_range);
 
+/* halo_score_maps_timed with its tail on a second stream of the caller: the passes over `logit` and `feat` run on `stream`,
+ * ev_feat_stop (required) is recorded behind them, `tail_stream` waits for it and receives every launch after that (min / max,
+ * normalize_map, the product, score[active] = -inf: floating_region.py:204-217 + build.py:146).  The small tail kernels of
+ * one call then overlap the feature pass of the NEXT call on `stream` instead of standing between two of them.  The outputs are
+ * complete on tail_stream; `workspace` belongs to the call until then (one workspace per call in flight).  Needs a purity type
+ * that reads decoder_out.  tail_stream == stream or NULL: the same as halo_score_maps_timed. */
+int halo_score_maps_split(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
+                          int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
+                          int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
+                          int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
+                          void *workspace, size_t workspace_bytes, void *stream, void *tail_stream, void *ev_feat_start,
+                          void *ev_feat_stop, void *score_range);
+
 /* The same forward on LOW-RESOLUTION sources, fusing RegionSelection's two F.interpolate calls
  * (core/active/build.py:122-135) into the scorer: logit_lr (B,O,hl,wl) f32 and feat_lr (B,C,hf,wf)
  * f64|f32 are interpolated on the fly (bilinear, align_corners=True) to (H,W); the C x H x W tensor is

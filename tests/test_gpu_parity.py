@@ -1211,6 +1211,52 @@ def test_feature_kernel_chunk_map_is_invisible(dev):
                 assert bits_equal(new[0][1].cpu().numpy(), so) and bits_equal(new[1][1].cpu().numpy(), io) and bits_equal(new[2][1].cpu().numpy(), uo)
 
 
+def test_scorer_tail_on_a_second_stream_equals_the_inline_call(dev):
+    """halo_score_maps_split: the passes over the inputs on the current stream, everything behind them on `tail_stream` (forked at
+    the stop event) -- same bits as the one-stream call, for every branch that reads decoder_out, with the range record, several
+    calls in flight on rotating workspaces."""
+    from halo_amd import _lib
+    from halo_amd.core.active.floating_region import new_score_range, score_maps, score_workspace
+    rng = np.random.default_rng(515)
+    H, W, C, B = 96, 256, 8, 3
+    tail = torch.cuda.Stream(dev, priority=-1)
+    L = _lib.lib()
+    for dt in (np.float64, np.float32):
+        for unc, pur, norm in (("entropy", "radius", True), ("entropy", "hyper", True), ("entropy", "euc_norm", False), ("none", "radius", True)):
+            calls = []
+            for it in range(3):
+                logit = rng.standard_normal((B, 19, H, W)).astype(np.float32)
+                emb = (rng.standard_normal((B, C, H, W)) * 0.05).astype(dt)
+                act = rng.random((B, H, W)) < 0.1
+                calls.append((t(logit, dev), t(emb, dev), t(act, dev)))
+            want = [score_maps(lg, em, unc, pur, norm, None, size=3, K=7, active=ac, score_range=new_score_range(B, dev)) for lg, em, ac in calls]
+            torch.cuda.synchronize(dev)
+            got, keep = [], []
+            for lg, em, ac in calls:                       # three calls in flight, each with its own workspace / maps / events
+                odt = want[0][0].dtype
+                ws = score_workspace(B, H, W, dev)
+                maps = (torch.empty((B, H, W), dtype=odt, device=dev), torch.empty((B, H, W), dtype=torch.float32, device=dev))
+                ev = (L.halo_event_create(), L.halo_event_create())
+                rec = new_score_range(B, dev)
+                keep.append((ws, ev, rec))
+                got.append(score_maps(lg, em, unc, pur, norm, None, size=3, K=7, active=ac, events=ev, score_range=rec,
+                                      tail_stream=tail, workspace=ws, maps=maps))
+            tail.synchronize()
+            for a, b in zip(want, got):
+                for x, y in zip(a, b):
+                    assert bits_equal(x.cpu().numpy(), y.cpu().numpy()), (dt, unc, pur, norm)
+            for _, ev, _ in keep:
+                L.halo_event_destroy(ev[0]); L.halo_event_destroy(ev[1])
+    lg, em, ac = calls[0]
+    with pytest.raises(AssertionError):
+        score_maps(lg, em, "entropy", "radius", True, None, size=3, tail_stream=tail)            # no events / workspace / maps
+    with pytest.raises(_lib.HaloHipError):
+        ws = score_workspace(B, H, W, dev)
+        maps = (torch.empty((B, H, W), dtype=torch.float32, device=dev), torch.empty((B, H, W), dtype=torch.float32, device=dev))
+        ev = (L.halo_event_create(), L.halo_event_create())
+        score_maps(lg, None, "entropy", "ripu", False, None, size=3, tail_stream=tail, events=ev, workspace=ws, maps=maps)   # no decoder_out pass to fork behind
+
+
 def test_region_selection_full_size_real_geometry_vs_oracle(dev):
     """The real pipeline's geometry at full label size: logits 640x1280 and a C=64 float64 embedding at
     160x320 resized to 1024x2048 inside the scorer (never materialised on the device), 2331 regions --
