@@ -7,6 +7,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${RND}_profiles
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
+# A bench process that starts within a few seconds of the end of another large GPU process lands on a ~3 % slower plateau (every
+# other one of back-to-back runs; profiles/r03_process_alternation.txt): a pause of 5 s before each bench run avoids it, i.e. the
+# numbers below are the ones a single run on an idle GPU gets.
+pause() { sleep 5; }
+pause
 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --cpu-images 0 > $OUT/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/tail_timeline.py $OUT/trace > $OUT/tail_timeline.txt 2>&1
@@ -14,12 +19,13 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --ring 16 > /dev/null 2>&1
 for v in "f32:--feat-dtype f32" "lowres_exact:--source lowres --lr-mode exact" "lowres_gram:--source lowres --lr-mode gram" "c512:--channels 512 --ring 16" "ripu:--branch ripu" "hyper:--branch hyper" "pool2975:--pool-images 2975" "resets_kernel:--resets kernel" "resets_fills:--resets fills"; do
   name=${v%%:*}; args=${v#*:}
+  pause
   python3 $R/bench.py --cpu-images 0 $args > $OUT/bench_$name.json 2> /dev/null
 done
 for br in ripu hyper; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$br -- python3 $R/bench.py --branch $br --cpu-images 0 --steps 8 --warmup 2 > /dev/null 2>&1
 done
-# the default line six more times, consecutive processes (on some boxes they alternate between two plateaus)
+# the default line six more times, consecutive processes WITHOUT a pause: they alternate between two plateaus
 for rep in 1 2 3 4 5 6; do
   python3 $R/bench.py --cpu-images 0 2> /dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('run $rep: %.1f images/s  ms_per_step %.3f  k_feat_reduce %.3f ms (frac %.4f)  tail %.3f ms  flat read of the same tensors %.0f GB/s' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], d['ms_per_step'] - r['avg_launch_ms'], r['flat_read']['GB/s']))" >> $OUT/bench_repeats.txt
@@ -45,7 +51,9 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_select -- python3 $R/tools/time_select.py > /dev/null 2>&1
 # the N > 1 code path at the full shape on the one GPU of the box: two ranks share it over gloo (never a measurement: both ranks
 # stream from the same HBM); the gathered pool tables must equal the one-rank run's
+pause
 python3 $R/bench.py --cpu-images 0 --ring 16 --pool-images 96 --dump-tables $OUT/pool96_one.npz > $OUT/bench_pool96_one_rank.json 2> /dev/null
+pause
 HALO_BENCH_BACKEND=gloo HALO_BENCH_SHARE_GPU=1 python3 $R/bench.py --gpus 2 --cpu-images 0 --ring 16 --pool-images 96 --dump-tables $OUT/pool96_two.npz > $OUT/bench_pool96_two_ranks_one_gpu.json 2> $OUT/bench_pool96_two.err
 python3 - <<PY > $OUT/two_ranks_one_gpu.txt 2>&1
 import json, numpy as np
