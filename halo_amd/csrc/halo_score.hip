@@ -22,7 +22,16 @@
 namespace halo {
 
 constexpr int TPB = 256;
-constexpr int FTPB = 128;   // k_feat_reduce: 128-thread blocks stream ~3 % faster than 256 (tools/feat_microbench.hip)
+#ifndef HALO_FTPB                 // compile-time tuning hooks of k_feat_reduce (variant builds for A/B through HALO_LIB_PATH)
+#define HALO_FTPB 128
+#endif
+#ifndef HALO_FEAT_WAVES
+#define HALO_FEAT_WAVES 4
+#endif
+#ifndef HALO_FEAT_UNROLL
+#define HALO_FEAT_UNROLL 8
+#endif
+constexpr int FTPB = HALO_FTPB;   // k_feat_reduce: 128-thread blocks stream ~3 % faster than 256 (tools/feat_microbench.hip)
 
 // ---------------------------------------------------------------- reductions
 // torch .min()/.max() propagate NaN: once a NaN is seen the result is NaN.
@@ -332,7 +341,7 @@ template <typename T> struct VecLoad<T, 1> {
 // they can be placed: one image's selection beside the stream took 5.3 ms at 6 waves, 2.4-2.6 at 5 (but 5.6 for four
 // images, every other run), 2.0-2.2 at 4 (2.6 for four images), with the same 11.4-11.5 ms per feature launch.
 template <typename T, int VEC, int MODE, int UNROLL, int FO>
-__global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, 4))) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
+__global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, HALO_FEAT_WAVES))) k_feat_reduce(const T *__restrict__ feat, long long bstride, int C,
                                                      long long hw, double ks, double rks, T *__restrict__ out,
                                                      double *__restrict__ partials, const float *__restrict__ logit,
                                                      long long lbstride, int unc_type, float *__restrict__ ent, unsigned xcd_g)
@@ -1825,7 +1834,7 @@ static void launch_feat(const T *feat, long long bstride, int C, long long hw, i
                         T *out, double *partials, int nblk, hipStream_t st, const FusedLogit *fl = nullptr)
 {
     dim3 grid(nblk, B), block(FTPB);
-    constexpr int UNROLL = 8;      // channel planes in flight per lane (16: no gain beside the selection kernels, 6 % slower alone)
+    constexpr int UNROLL = HALO_FEAT_UNROLL;      // channel planes in flight per lane (16: no gain beside the selection kernels, 6 % slower alone)
     // granule of the XCD-contiguous chunk map: 256 chunks (512 KiB per plane), halved until a group of 8 granules fits
     const char *eg = getenv("HALO_FEAT_XCD_GRANULE");      // A/B switch, read per call: -1 = the plain map
     const int env_g = eg ? atoi(eg) : 256;
