@@ -755,7 +755,8 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     }
     // 128 blocks per image for the passes with a per-block fixed cost (LDS histogram flush: 2048 atomics; 16 KiB table
     // staging): 1024 blocks measured 2x SLOWER end to end, and a wider scatter grid no faster beside the feature stream.
-    // (round 3, two hardware queues: 8 ... 128 blocks per image make no difference to the bench beside the feature stream)
+    // (round 3, two hardware queues, 5 s between runs: 128 blocks per image 1370-1375 images/s in the bench, 256 the same, 48 0.4 %
+    // and 16 1.3 % slower -- longer-running passes cost the feature kernel beside them more)
     const unsigned gx = (unsigned)(cdiv(hw, 256) < 128 ? cdiv(hw, 256) : 128);
     const unsigned gy = (unsigned)(g.H < 128 ? g.H : 128);
     dim3 blk(256);
