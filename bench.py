@@ -89,6 +89,10 @@ def parse():
                          "so that they overlap the next step's feature kernel; inline = on the scoring stream, between two feature "
                          "kernels; auto = split for the 'hyper' purity (0.95 ms of tail: +6 %%), inline otherwise (0.26 ms of tail: "
                          "beside the next feature kernel it costs that kernel 0.5-0.9 ms, profiles/r03_tail_split.txt)")
+    ap.add_argument("--settle", type=float, default=5.0,
+                    help="seconds to wait before the GPU is touched when the resident pool is large (> 8 GiB): a run that starts "
+                         "within a few seconds of the end of another large GPU process measures ~3 %% low -- the driver is still "
+                         "busy with the memory that process gave back (profiles/r03_process_alternation.txt); 0 = do not wait")
     ap.add_argument("--sel-priority", type=int, default=-1, help="stream priority of the selection streams (-1 = high)")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
@@ -453,6 +457,10 @@ def main():
     # host pools no wider than this rank's share of the cgroup quota (8 ranks x 16 threads on a 16-core quota only throttle)
     host_threads = max(1, effective_cpus() // local_world)
     torch.set_num_threads(max(1, min(torch.get_num_threads(), host_threads)))
+    pool_bytes = max(a.batch, (a.ring // max(1, a.batch)) * a.batch) * a.channels * a.height * a.width * (8 if a.feat_dtype == "f64" else 4)
+    settled = a.settle if (a.settle > 0 and a.source == "fullres" and pool_bytes > (8 << 30)) else 0.0
+    if settled:
+        time.sleep(settled)                  # before the first HIP call of this process
     assert torch.cuda.is_available(), "bench.py needs ROCm devices"
     # HALO_BENCH_BACKEND=gloo + HALO_BENCH_SHARE_GPU=1: the hardware test of the N > 1 code on a ONE-GPU box -- every rank
     # on device 0, the wire block staged through the host.  Never set for a measurement.
@@ -627,7 +635,7 @@ def main():
             "pipeline_tables_consistent": bool(pipe.tables_consistent),
             "exchange": {"collectives_per_round": 1 if use_dist else 0, "ms": None if pipe.exchange_ms is None else round(pipe.exchange_ms, 3),
                          "bytes_per_rank": int(pipe.wire.numel() * 4), "rows_checked_against_local_results": exchange_checked},
-            "state_resets": a.resets, "host_threads_per_rank": host_threads,
+            "state_resets": a.resets, "host_threads_per_rank": host_threads, "settle_s_before_first_gpu_call": settled,
             "tail": "on its own stream beside the next feature kernel (halo_score_maps_split)" if pipe.split else "inline on the scoring stream",
         }
         per_rank = [(shard_range(n_pool, r_, world)[1] - shard_range(n_pool, r_, world)[0]) / rank_dts[r_] for r_ in range(world)]

@@ -10,7 +10,7 @@ cd /tmp; export TMPDIR=/tmp
 # A bench process that starts within a few seconds of the end of another large GPU process lands on a ~3 % slower plateau (every
 # other one of back-to-back runs; profiles/r03_process_alternation.txt): a pause of 5 s before each bench run avoids it, i.e. the
 # numbers below are the ones a single run on an idle GPU gets.
-pause() { sleep 5; }
+pause() { :; }          # bench.py waits by itself now (--settle 5, before its first GPU call)
 pause
 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --cpu-images 0 > $OUT/bench_under_rocprof.json 2> /dev/null
@@ -27,7 +27,7 @@ for br in ripu hyper; do
 done
 # the default line six more times, consecutive processes WITHOUT a pause: they alternate between two plateaus
 for rep in 1 2 3 4 5 6; do
-  python3 $R/bench.py --cpu-images 0 2> /dev/null | python3 -c "
+  python3 $R/bench.py --cpu-images 0 --settle 0 2> /dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('run $rep: %.1f images/s  ms_per_step %.3f  k_feat_reduce %.3f ms (frac %.4f)  tail %.3f ms  flat read of the same tensors %.0f GB/s' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], d['ms_per_step'] - r['avg_launch_ms'], r['flat_read']['GB/s']))" >> $OUT/bench_repeats.txt
 done
 python3 $R/tools/ab_feat_map.py 2> /dev/null > $OUT/ab_feat_map.txt
