@@ -36,8 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# hardware queues: the package's choice (halo_amd/__init__.py: 2, measured), read by the HIP runtime at initialisation
-import halo_amd  # noqa: E402,F401
+# hardware queues: importing the package changes nothing; the bench opts in to the acquisition's measured optimum (2, read by the
+# HIP runtime at initialisation; HALO_BENCH_HW_QUEUES overrides, an exported GPU_MAX_HW_QUEUES wins) -- halo_amd.configure()
+import halo_amd  # noqa: E402
+if "GPU_MAX_HW_QUEUES" not in os.environ:
+    halo_amd.configure(hw_queues=int(os.environ.get("HALO_BENCH_HW_QUEUES", "2")))
 
 import numpy as np
 import torch
@@ -306,7 +309,9 @@ class Pipeline:
                 self._exchange_events = (e0, e1)
         return out
 
-    def drain(self):
+    def drain(self, check=True):
+        """Wait for every stream of the pipeline; `check=False` (the timed region) leaves the host-synchronising self-checks --
+        full-map reductions, table clones and compares -- to a later self_check() call."""
         self.s_score.synchronize()
         for st in self.s_sel:
             st.synchronize()
@@ -318,12 +323,16 @@ class Pipeline:
         if ee is not None:
             self.exchange_ms = ee[0].elapsed_time(ee[1])
             self._exchange_events = None
+        if check:
+            self.self_check()
+
+    def self_check(self):
+        """Outside the timed region: the round-1 state the undo kernel must have left, and the same ring images giving the
+        same pick tables whichever slot / step / overlap pattern processed them."""
         if self.resets == "undo" and self.step_no >= self.D:      # the restore must have left exactly the loader's round-1 state
             for k in range(self.D):
                 assert not bool(self.active[k].any()) and not bool(self.selected[k].any()) and bool((self.amask[k] == 255).all()), \
                     "halo_undo_picks did not restore the round-1 state of slot %d" % k
-        # self-check under concurrency (outside the timed region): the same ring images must give the same
-        # pick tables whichever slot / step / overlap pattern processed them
         for k, ent in enumerate(self.slot_lo):
             if ent is None:
                 continue
@@ -455,7 +464,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     # host pools no wider than this rank's share of the cgroup quota (8 ranks x 16 threads on a 16-core quota only throttle)
-    host_threads = max(1, effective_cpus() // local_world)
+    host_threads = halo_amd.host_threads_per_rank()                       # usable cores // LOCAL_WORLD_SIZE
     torch.set_num_threads(max(1, min(torch.get_num_threads(), host_threads)))
     pool_bytes = max(a.batch, (a.ring // max(1, a.batch)) * a.batch) * a.channels * a.height * a.width * (8 if a.feat_dtype == "f64" else 4)
     settled = a.settle if (a.settle > 0 and a.source == "fullres" and pool_bytes > (8 << 30)) else 0.0
@@ -478,9 +487,16 @@ def main():
         else:
             dist.init_process_group(backend)
         assert dist.get_world_size() == world
-        if not share_gpu:      # one process per GPU: two ranks on one device would halve every number silently
-            from halo_amd.pool import assert_distinct_devices
-            device_ids = assert_distinct_devices(dev.index)
+    # one process per GPU: two ranks on one device would halve every number silently -- every rank's device identity (PCI bus
+    # id + UUID) is exchanged and must be distinct, unless the test switch shares the one GPU of a test box on purpose
+    from halo_amd.pool import device_identity
+    device_ids = [device_identity(dev.index)]
+    if use_dist:
+        ids = [None] * world
+        dist.all_gather_object(ids, device_ids[0])
+        device_ids = ids
+        if not share_gpu and len(set(device_ids)) != world:
+            raise RuntimeError("ranks share a GPU: %s" % ", ".join("rank %d -> %s" % (r, i) for r, i in enumerate(device_ids)))
     host_backend = use_dist and backend != "nccl"
     fdtype = torch.float64 if a.feat_dtype == "f64" else torch.float32
     a.depth = max(1, a.depth)
@@ -529,9 +545,10 @@ def main():
         pipe.step(True, b, lo=row % R, row=row)
         row += b
     tables, counts = pipe.finish_round(n_pool, host_backend)           # ONE collective per round
-    pipe.drain()
+    pipe.drain(check=False)
     torch.cuda.synchronize(dev)
     dt_rank = time.perf_counter() - t0
+    pipe.self_check()                                                   # host-synchronising checks: after the clock stopped
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -581,20 +598,16 @@ def main():
     if rank == 0 and not lowres and feat_ms:
         # this box's own ceiling for the same bytes, after the timed region: a flat non-temporal read (no arithmetic, no
         # plane structure, nothing written) of the B feature tensors one k_feat_reduce launch streams, nothing beside it
-        from halo_amd import _lib
-        fb = feat[0:B]
-        assert fb.is_contiguous()
-        nb = fb.numel() * fb.element_size()
-        sink = torch.zeros(1, dtype=torch.int32, device=dev)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
-        torch.cuda.synchronize(dev)
-        for i in range(7):                       # first pass = warm-up
-            _lib.check(_lib.lib().halo_hbm_read_probe(_lib.ptr(fb), nb, _lib.ptr(sink), 0, _lib.stream_ptr(dev)), "halo_hbm_read_probe")
-            ev[i].record()
-        torch.cuda.synchronize(dev)
-        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(1, 6)]
-        flat = {"GB/s": round(nb / (float(np.mean(ms)) * 1e-3) / 1e9, 1), "avg_ms": round(float(np.mean(ms)), 4), "bytes": nb,
-                "what": "flat non-temporal read of the same feature tensors, alone, after the timed region (halo_hbm_read_probe)"}
+        # (tools/libhalo_probe.so: a measurement aid outside the product ABI; absent -> the field is null)
+        try:
+            from tools import halo_probe
+            fb = feat[0:B]
+            assert fb.is_contiguous()
+            flat = halo_probe.flat_read_gbps(fb)
+            flat["what"] = "flat non-temporal read of the same feature tensors, alone, after the timed region (tools/halo_probe.hip)"
+        except Exception as exc:                  # never part of the measurement
+            flat = None
+            print("bench.py: flat-read probe unavailable (%s)" % exc, file=sys.stderr)
     assert pipe.min_picked == n_regions, "selection stopped early"
     assert pipe.tables_consistent, "pick tables of the same images differ between steps (race in the pipeline)"
 
@@ -640,8 +653,9 @@ def main():
         }
         per_rank = [(shard_range(n_pool, r_, world)[1] - shard_range(n_pool, r_, world)[0]) / rank_dts[r_] for r_ in range(world)]
         out["per_rank_images_per_s"] = {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)}
-        if device_ids is not None:
-            out["devices"] = device_ids
+        out["devices"] = device_ids                       # rank order; distinct unless HALO_BENCH_SHARE_GPU (test switch)
+        out["distinct_devices"] = len(set(device_ids))
+        assert share_gpu or out["distinct_devices"] == out["n_gpus"], "n_gpus must equal the number of distinct devices"
         if lowres:      # not the BASELINE unit of work: a different (smaller) input boundary, reported for DESIGN.md
             out["config"]["workload"] = "RegionSelection boundary (N1): x4 low-res head outputs (%dx%d), upsample fused into the scorer, " \
                                         "then the same mask + select; NOT the BASELINE unit of work" % (Hh // 4, Ww // 4)

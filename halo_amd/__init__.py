@@ -4,35 +4,41 @@ Host side: Python mirroring the reference's plugin surface (halo_amd.core.*), ca
 hand-written HIP kernels through the C ABI in include/halo_hip.h (halo_amd/csrc/libhalo_hip.so).
 There is no CPU fallback: every op raises if the HIP library or a ROCm device is missing.
 """
-__version__ = "0.4.0"
+__version__ = "0.5.0"
 
 import os as _os
 import sys as _sys
 
 
-HW_QUEUES = "2"
+def configure(hw_queues=None):
+    """Explicit, opt-in process settings for the acquisition.  `import halo_amd` itself changes NOTHING in the process
+    environment (round 3 set GPU_MAX_HW_QUEUES at import; a library must not rewrite a runtime-wide setting of the training
+    process it is imported into).
 
-
-def _configure_hw_queues():
-    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The acquisition keeps up to six streams busy
-    (RegionSelection: 4 side streams + the caller's; bench.py: 1 + 3 + 1), and it runs FASTEST on TWO queues: kernels of
-    different streams still overlap inside a queue, while with three or more queues the short kernels that follow a long one on
-    the scoring stream start 40 us late and run up to 3x slower (k_box3_minmax 127 vs 43 us; bench.py, interleaved: 1355-1392
-    images/s on 1-2 queues, 1337-1368 on 3-8; --source lowres 5900 vs 5260, --branch ripu 10 590 vs 9 680;
-    profiles/r03_hw_queues.txt).  The variable is read when the HIP runtime initialises, so it is set here -- at import,
-    normally the first lines of train.py -- unless the user chose a value or the runtime is already up (then RegionSelection
-    warns once)."""
-    if "GPU_MAX_HW_QUEUES" in _os.environ:
-        return
+    hw_queues: ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and the variable is read once, when the
+    HIP runtime initialises.  The acquisition keeps up to six streams busy (RegionSelection: 4 side streams + the caller's;
+    bench.py: 1 + 3 + 1) and measured fastest on TWO queues (kernels of different streams still overlap inside a queue; with
+    three or more, the short kernels that follow a long one on the scoring stream start late: bench.py +1.4 %, --source lowres
+    +12 %, --branch ripu +9 %, profiles/r03_hw_queues.txt).  That was measured on the acquisition ALONE: the same setting also
+    governs the training iterations' streams (DDP / RCCL communication, H2D copies), which is why it is the caller's decision.
+    Call this before the first HIP call of the process (bench.py and tools/ do); returns the value in force, or raises
+    RuntimeError when the runtime is already up with a different one."""
+    if hw_queues is None:
+        return _os.environ.get("GPU_MAX_HW_QUEUES")
+    want = str(int(hw_queues))
+    have = _os.environ.get("GPU_MAX_HW_QUEUES")
+    if have == want:
+        return want
     torch = _sys.modules.get("torch")
     if torch is not None and getattr(torch, "cuda", None) is not None and torch.cuda.is_initialized():
-        return
-    _os.environ["GPU_MAX_HW_QUEUES"] = HW_QUEUES
+        raise RuntimeError("halo_amd.configure(hw_queues=%s): the HIP runtime is already initialised (GPU_MAX_HW_QUEUES=%s); "
+                           "call configure() before the first HIP call" % (want, have or "unset: ROCm's default, 4"))
+    _os.environ["GPU_MAX_HW_QUEUES"] = want
+    return want
 
-
-_configure_hw_queues()
 
 from . import _lib  # noqa: F401,E402  (does not load the .so until first use)
+from ._host import usable_cpus, host_threads_per_rank  # noqa: F401,E402
 from ._install import install, uninstall  # noqa: F401,E402
 
 

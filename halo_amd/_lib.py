@@ -63,11 +63,6 @@ SIGNATURES = {
     "halo_reset_round_state": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "halo_undo_picks": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "halo_device_identity": (_int, [_int, C.c_char_p, _sz]),
-    "halo_hbm_read_probe": (_int, [_vp, _sz, _vp, _int, _vp]),
-    "halo_hbm_walk_probe": (_int, [_vp, _sz, _sz, _int, _vp, _vp]),
-    "halo_pool_alloc": (_vp, [_sz, _int, _vp]),
-    "halo_pool_free": (None, [_vp, _sz, _int, _vp]),
-    "halo_pool_alloc_stats": (_int, [C.POINTER(C.c_uint64)]),
     "halo_select_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "halo_score_range_bytes": (_sz, [_i64]),
     "halo_score_range": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp]),
@@ -79,7 +74,7 @@ SIGNATURES = {
 
 # must equal HALO_ABI_VERSION of include/halo_hip.h; bumped whenever an exported signature changes, so a stale
 # library with the same symbol names but older argument lists is refused instead of being called with shifted arguments
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lock = threading.Lock()
 _handle = None

@@ -190,17 +190,18 @@ _QUEUE_WARNED = False
 
 
 def _check_hw_queues(n_streams):
-    """Warn once when the HIP runtime came up with more hardware queues than the acquisition runs best on (halo_amd/__init__.py:
-    two; ROCm's default is four) and nobody chose that value."""
+    """Tell the user once that the acquisition alone measured faster on two hardware queues than on ROCm's default of four, when
+    nobody chose a value.  Only a hint: the setting is process-wide (it also governs the training iterations' streams), so the
+    package never sets it by itself -- halo_amd.configure(hw_queues=2), INTEGRATION.md section 3."""
     global _QUEUE_WARNED
     if _QUEUE_WARNED or "GPU_MAX_HW_QUEUES" in os.environ:
         return
     _QUEUE_WARNED = True
     import warnings
-    warnings.warn("halo_amd RegionSelection drives %d side streams beside the caller's; the HIP runtime was initialised before "
-                  "halo_amd was imported, with ROCm's default of 4 hardware queues.  The acquisition measured 2-12 %% faster on "
-                  "GPU_MAX_HW_QUEUES=2: import halo_amd (or export the variable) before the first HIP call (INTEGRATION.md "
-                  "section 3)." % n_streams, RuntimeWarning, stacklevel=3)
+    warnings.warn("halo_amd RegionSelection drives %d side streams beside the caller's and GPU_MAX_HW_QUEUES is unset (ROCm's "
+                  "default: 4 hardware queues).  The acquisition alone measured 2-12 %% faster on 2; if that suits the training "
+                  "process too, call halo_amd.configure(hw_queues=2) (or export the variable) before the first HIP call "
+                  "(INTEGRATION.md section 3)." % n_streams, RuntimeWarning, stacklevel=3)
 
 
 def _side_streams(dev, n):
@@ -305,7 +306,7 @@ def _finish_inner(rec, slots):
     return out
 
 
-def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=8, writer_threads=8,
+def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=8, writer_threads=None,
                     streams=4, return_tables=False, lowres_mode=None):
     """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
     at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
@@ -319,7 +320,7 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     for the GPU: a pool of writer threads waits for each image's event, encodes the PNG and writes the
     indicator.  At most `in_flight` images are between "launched" and "copied back to the host" (bounds device
     and pinned memory; each slot owns its pinned staging buffers); `in_flight=0` runs strictly one image at a
-    time like the reference.  `lowres_mode`: 'gram' (default; environment HALO_LOWRES) evaluates the radius of a float64
+    time like the reference.  `writer_threads` defaults to min(8, usable host cores / LOCAL_WORLD_SIZE).  `lowres_mode`: 'gram' (default; environment HALO_LOWRES) evaluates the radius of a float64
     embedding through per-cell Gram terms (floating_region.score_maps_lowres: bit-identical to its oracle twin, maps within
     1e-12 of upsample-then-score, the reference's files on every test vector); 'exact' interpolates every channel and is
     bit-identical to upsample-then-score (the only route for float32 embeddings)."""
@@ -328,6 +329,10 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     from concurrent.futures import ThreadPoolExecutor
     prm = AcquisitionParams(cfg)
     dev = torch.device("cuda", torch.cuda.current_device())
+    if writer_threads is None:
+        # this rank's share of the usable host cores (8 ranks on a 16-core quota: 2 writers each, not 8 x 8 threads)
+        from ..._host import host_threads_per_rank
+        writer_threads = host_threads_per_rank(cap=8)
     depth = max(1, in_flight)
     side = _side_streams(dev, max(1, min(streams, depth)))
     _check_hw_queues(len(side))

@@ -15,7 +15,6 @@ synchronisation is needed: every rank pads its block to ceil(N / world) rows.
 With `global_budget=None` (default, = reference behaviour) the result does not depend on the
 world size.
 """
-import contextlib
 import math
 import os
 
@@ -182,86 +181,6 @@ def assert_distinct_devices(device_index, group=None):
     if len(set(ids)) != world:
         raise RuntimeError("ranks share a GPU: %s" % ", ".join("rank %d -> %s" % (r, i) for r, i in enumerate(ids)))
     return ids
-
-
-# ---- diagnostics: where a streamed pool lives in HBM.  On MI355X the scorer's walk over C planes 16 MiB apart runs ~7 % slower
-# over some 16-48 GiB stretches of a large allocation than over the rest (6.35 vs 6.83 TB/s per 16 GiB window), while a flat read
-# is equally fast everywhere; that is the "plateau" a run lands on (NOTES.md, tools/probe_placement.py).  The functions below
-# allocate a tensor in one physically contiguous range and time the walk per window.  They are measurement aids: no placement
-# policy is built on them (the windows do not predict the full scoring call well enough), and bench.py takes the memory
-# torch's allocator hands it.
-_TYPESTR = {torch.float64: "<f8", torch.float32: "<f4", torch.int64: "<i8", torch.int32: "<i4", torch.uint8: "|u1"}
-
-
-class _RawBlock(object):
-    """One halo_pool_alloc allocation (physically contiguous when the driver can), exposed through __cuda_array_interface__;
-    freed when the last tensor viewing it is gone."""
-
-    def __init__(self, nbytes, shape, dtype, index):
-        from . import _lib
-        self._lib, self.nbytes, self.index = _lib.lib(), int(nbytes), int(index)
-        self.ptr = self._lib.halo_pool_alloc(self.nbytes, self.index, None)
-        if not self.ptr:
-            raise torch.cuda.OutOfMemoryError("halo_pool_alloc: %d bytes on device %d" % (self.nbytes, self.index))
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": _TYPESTR[dtype], "data": (self.ptr, False), "version": 2,
-                                         "strides": None}
-
-    def __del__(self):
-        if getattr(self, "ptr", None):
-            self._lib.halo_pool_free(self.ptr, self.nbytes, self.index, None)
-            self.ptr = None
-
-
-def alloc_contiguous(shape, dtype, device):
-    """An uninitialised tensor in its own physically contiguous HBM range (hipDeviceMallocContiguous through halo_pool_alloc;
-    plain hipMalloc, counted in contiguous_memory_stats(), when no such range is free).  Not from torch's caching allocator:
-    the memory goes back to the driver when the tensor and its views are gone."""
-    device = torch.device(device)
-    shape = tuple(int(v) for v in shape)
-    nbytes = max(16, math.prod(shape) * torch.empty((), dtype=dtype).element_size())
-    torch.cuda.synchronize(device)
-    with torch.cuda.device(device):
-        torch.zeros(1, device=device)                                   # HIP context up before the raw allocation
-        return torch.as_tensor(_RawBlock(nbytes, shape, dtype, device.index or 0), device=device)
-
-
-def contiguous_memory_stats():
-    """{contiguous_bytes, fallback_bytes (hipMalloc: no contiguous range of that size was free), live, failed} so far."""
-    import ctypes
-    from . import _lib
-    out = (ctypes.c_uint64 * 4)()
-    _lib.check(_lib.lib().halo_pool_alloc_stats(out), "halo_pool_alloc_stats")
-    return {"contiguous_bytes": int(out[0]), "fallback_bytes": int(out[1]), "live": int(out[2]), "failed": int(out[3])}
-
-
-def probe_streaming(t, planes, plane_bytes, window_bytes=16 << 30, reps=3):
-    """Per window of the contiguous tensor `t`: GB/s of the scorer's plane walk (halo_hbm_walk_probe: groups of `planes` planes of
-    `plane_bytes`) and of a flat read (halo_hbm_read_probe).  [(byte offset, bytes, walk GB/s, flat GB/s)]."""
-    from . import _lib
-    L, dev = _lib.lib(), t.device
-    assert t.is_contiguous()
-    group = int(planes) * int(plane_bytes)
-    total = t.numel() * t.element_size()
-    per = max(1, int(window_bytes) // group) * group
-    sink = torch.zeros(1, dtype=torch.int32, device=dev)
-    scratch = torch.empty((per // int(planes),), dtype=torch.uint8, device=dev)
-    out, off = [], 0
-    while off + group <= total:
-        nb = min(per, (total - off) // group * group)
-        rates = []
-        for fn in (lambda: L.halo_hbm_walk_probe(t.data_ptr() + off, nb, int(plane_bytes), int(planes), _lib.ptr(scratch), _lib.stream_ptr(dev)),
-                   lambda: L.halo_hbm_read_probe(t.data_ptr() + off, nb, _lib.ptr(sink), 0, _lib.stream_ptr(dev))):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            _lib.check(fn(), "probe")
-            ev[0].record()
-            for _ in range(reps):
-                _lib.check(fn(), "probe")
-            ev[1].record()
-            torch.cuda.synchronize(dev)
-            rates.append(nb * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9)
-        out.append((off, nb, rates[0], rates[1]))
-        off += nb
-    return out
 
 
 def global_budget_select(tables, counts, total_regions):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 4
+#define HALO_ABI_VERSION 5
 
 enum { HALO_F32 = 0, HALO_F64 = 1 };
 
@@ -235,19 +235,8 @@ int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int64_t H, int6
  *    table: only the windows select_pixels_to_label wrote (build.py:52-62) are rewritten.
  *  - halo_device_identity: "pci=<bus id> uuid=<32 hex digits>" of a HIP device ordinal, NUL-terminated, len >= 64
  *    (the ranks of a node must hold distinct devices).
- *  - halo_pool_alloc / halo_pool_free: device memory in one physically contiguous range (hipExtMallocWithFlags,
- *    hipDeviceMallocContiguous), with the signatures torch.cuda.memory.CUDAPluggableAllocator binds
- *    (void *alloc(size_t, int device, hipStream_t), void free(void *, size_t, int device, hipStream_t)); no reference
- *    counterpart (the reference allocates through torch's default allocator).  Falls back to hipMalloc when no contiguous
- *    range is free; halo_pool_alloc_stats: {contiguous bytes, fallback bytes, live allocations, failed allocations}.
- *  - halo_hbm_read_probe: measurement aid, no reference counterpart: one flat non-temporal streaming read of `bytes` bytes
- *    (16-byte aligned pointer and size) on `blocks` workgroups of 256 threads (<= 0: 4096); `sink` is 4 writable bytes or
- *    NULL.  bench.py times it over the tensors the scoring pass streams and reports the rate beside the roofline.
- *  - halo_hbm_walk_probe: the scoring pass's access pattern and arithmetic and nothing else -- the buffer is bytes / (planes *
- *    plane_bytes) groups of `planes` float64 planes, each walked by 128-thread workgroups that own 2 KiB of every plane
- *    (plane_bytes a multiple of 2048), one fma per element; `out` receives plane_bytes per group.  halo_amd.pool times it per
- *    window of an allocation: on MI355X the walk runs 3-7 % slower over some stretches of HBM than over others, a flat read
- *    does not (NOTES.md). */
+ *  (Round 3 also exported HBM probes and a contiguous-range allocator here; ABI 5 moved those measurement aids to
+ *  tools/halo_probe.hip -- this header keeps only entry points that replace a reference call, plus halo_event_*.) */
 int halo_pack_pick_tables(const double *picks, const int32_t *n_picked, int64_t B, int64_t n_regions, int32_t *wire,
                           int64_t wire_row_stride, void *stream);
 int halo_reset_round_state(uint8_t *active, uint8_t *selected, int64_t *active_mask, int64_t n_pixels, void *stream);
@@ -255,11 +244,6 @@ int halo_undo_picks(const double *picks, const int32_t *n_picked, int64_t B, int
                     int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected, int64_t *active_mask,
                     void *stream);
 int halo_device_identity(int device, char *buf, size_t len);
-void *halo_pool_alloc(size_t size, int device, void *stream);
-void halo_pool_free(void *ptr, size_t size, int device, void *stream);
-int halo_pool_alloc_stats(uint64_t out[4]);
-int halo_hbm_walk_probe(const void *buf, size_t bytes, size_t plane_bytes, int planes, void *out, void *stream);
-int halo_hbm_read_probe(const void *buf, size_t bytes, void *sink, int blocks, void *stream);
 
 /* ---- training-side window losses, float32 tensors, float64 sums on the device ----
  *  - NegativeLearningLoss (core/loss/negative_learning_loss.py:6-16): sums = {sum -mask*log(1-p+1e-6), sum mask},

@@ -133,27 +133,62 @@ def test_direct_png_writer_decodes_to_the_same_mode_L_image(tmp_path):
     assert set(ind) == {"active", "selected"} and ind["active"].dtype == torch.bool and torch.equal(ind["active"], act)
 
 
-def test_hw_queue_default_and_warning(monkeypatch):
-    """the product must not rely on an environment knob only the bench sets.  `import halo_amd` chooses
-    GPU_MAX_HW_QUEUES=2 (measured best, halo_amd/__init__.py) unless the user did (it is read when the HIP runtime starts);
-    RegionSelection warns once when the runtime came up without any choice."""
+def test_import_leaves_the_environment_alone_and_configure_is_explicit(monkeypatch):
+    """VERDICT r3 #5 / ADVICE r3: `import halo_amd` must not set GPU_MAX_HW_QUEUES (a process-wide runtime setting that also
+    governs the training iterations' streams).  halo_amd.configure(hw_queues=2) is the explicit opt-in (bench.py and tools/ call
+    it before the first HIP call); RegionSelection only hints, once, when nobody chose a value."""
     import subprocess
     import sys
     import warnings
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    code = "import sys, os; sys.path.insert(0, %r); import halo_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT
-    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "2"
+    code = ("import sys, os; sys.path.insert(0, %r); import halo_amd; import halo_amd.core.active.build; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES', 'unset')); print(halo_amd.configure(hw_queues=2)); "
+            "print(os.environ['GPU_MAX_HW_QUEUES']); print(halo_amd.configure())") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.split()
+    assert out == ["unset", "2", "2", "2"], out
     env["GPU_MAX_HW_QUEUES"] = "3"
+    code = "import sys, os; sys.path.insert(0, %r); import halo_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT
     assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "3"
     from halo_amd.core.active import build
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
     monkeypatch.setattr(build, "_QUEUE_WARNED", False)
-    with pytest.warns(RuntimeWarning, match="GPU_MAX_HW_QUEUES=2"):
+    with pytest.warns(RuntimeWarning, match=r"halo_amd.configure\(hw_queues=2\)"):
         build._check_hw_queues(4)
+    assert "GPU_MAX_HW_QUEUES" not in os.environ                     # the hint changes nothing
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         build._check_hw_queues(4)                         # once
         monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
         monkeypatch.setattr(build, "_QUEUE_WARNED", False)
         build._check_hw_queues(4)                         # the user's choice: silent
+
+
+def test_product_abi_has_no_measurement_aids():
+    """include/halo_hip.h keeps only entry points that replace a reference call (+ halo_event_*); the HBM
+    probes and the contiguous-range allocator live in tools/libhalo_probe.so, which nothing under halo_amd/ loads."""
+    syms = _declared_symbols()
+    for gone in ("halo_pool_alloc", "halo_pool_free", "halo_pool_alloc_stats", "halo_hbm_read_probe", "halo_hbm_walk_probe"):
+        assert gone not in syms
+    import halo_amd.pool as pool
+    for gone in ("alloc_contiguous", "probe_streaming", "contiguous_memory_stats"):
+        assert not hasattr(pool, gone)
+    import subprocess
+    r = subprocess.run(["grep", "-rl", "halo_probe", os.path.join(ROOT, "halo_amd"), "--include=*.py", "--include=*.hip", "--include=*.hpp"],
+                       capture_output=True, text=True)
+    assert r.stdout.strip() in ("", os.path.join(ROOT, "halo_amd", "csrc", "halo_pool.hip")), r.stdout   # one comment pointing at tools/
+    from tools import halo_probe
+    h = ctypes.CDLL(halo_probe.build())
+    for s_ in ("halo_hbm_read_probe", "halo_hbm_walk_probe", "halo_pool_alloc", "halo_pool_free", "halo_pool_alloc_stats"):
+        assert hasattr(h, s_)
+
+
+def test_writer_threads_follow_the_ranks_share_of_the_host(monkeypatch):
+    from halo_amd import _host
+    monkeypatch.setattr(_host, "usable_cpus", lambda: 16)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert _host.host_threads_per_rank(cap=8) == 2                   # 8 ranks on a 16-core quota: 2 writers each
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert _host.host_threads_per_rank(cap=8) == 8 and _host.host_threads_per_rank() == 16
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "64")
+    assert _host.host_threads_per_rank(cap=8) == 1

@@ -102,10 +102,11 @@ def _bench(args, env=None, timeout=1500):
 
 
 def test_contiguous_allocation_and_bandwidth_probes(dev):
-    """Measurement aids of halo_amd.pool: a tensor in its own physically contiguous range behaves like any tensor and frees its
-    memory with its last view; the two probes read what they are given (rates are positive, bad geometry is refused)."""
-    from halo_amd import _lib
-    from halo_amd.pool import alloc_contiguous, contiguous_memory_stats, probe_streaming
+    """Measurement aids (tools/halo_probe, outside the product ABI): a tensor in its own physically contiguous range behaves like
+    any tensor and frees its memory with its last view; the two probes read what they are given (rates are positive, bad geometry
+    is refused)."""
+    from tools import halo_probe
+    from tools.halo_probe import alloc_contiguous, contiguous_memory_stats, probe_streaming
     before = contiguous_memory_stats()
     t = alloc_contiguous((3, 8, 64, 128), torch.float64, dev)                  # planes of 64 KiB
     assert t.shape == (3, 8, 64, 128) and t.dtype == torch.float64 and t.is_contiguous() and t.device == dev
@@ -119,12 +120,13 @@ def test_contiguous_allocation_and_bandwidth_probes(dev):
     assert all(r[2] > 0 and r[3] > 0 for r in rows)
     # the walk probe computes sum of squares per pixel over the planes of a group: check it (16 bytes per lane -> 2 doubles)
     out = torch.zeros((3, 64, 128), dtype=torch.float64, device=dev)
-    _lib.check(_lib.lib().halo_hbm_walk_probe(_lib.ptr(t), t.numel() * 8, 65536, 8, _lib.ptr(out), _lib.stream_ptr(dev)), "walk")
+    halo_probe.walk_probe(t, t.numel() * 8, 65536, 8, out)
     assert torch.equal(out, (t * t).sum(dim=1))
-    with pytest.raises(_lib.HaloHipError):
-        _lib.check(_lib.lib().halo_hbm_walk_probe(_lib.ptr(t), t.numel() * 8, 1000, 8, _lib.ptr(out), _lib.stream_ptr(dev)), "walk")
-    with pytest.raises(_lib.HaloHipError):
-        _lib.check(_lib.lib().halo_hbm_read_probe(t.data_ptr() + 8, 1024, None, 0, _lib.stream_ptr(dev)), "read")
+    with pytest.raises(halo_probe.ProbeError):
+        halo_probe.walk_probe(t, t.numel() * 8, 1000, 8, out)
+    with pytest.raises(halo_probe.ProbeError):
+        halo_probe.read_probe(t, 1024, None, offset=8)
+    assert halo_probe.flat_read_gbps(t, reps=2)["GB/s"] > 0
     view = t[1:2]
     del t
     assert contiguous_memory_stats()["live"] == mid["live"]                    # the view keeps the block alive
@@ -155,6 +157,34 @@ def test_bench_two_ranks_on_one_gpu_equal_the_one_rank_pool(dev, tmp_path, reset
     a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "two.npz")
     assert int(a["n_pool"]) == int(b["n_pool"]) == 37 and int(b["world"]) == 2
     assert np.array_equal(a["counts"], b["counts"]) and a["tables"].shape == b["tables"].shape
+    assert np.array_equal(a["tables"].view(np.int64), b["tables"].view(np.int64)), "pool tables depend on the world size"
+
+
+def test_bench_eight_ranks_on_one_gpu_score_the_2975_image_pool_like_one_rank(dev, tmp_path):
+    """configs[3] / configs[4] code at world 8 before an 8-GPU node sees it: bench.py --gpus 8 --pool-images 2975
+    at a tiny shape, all eight ranks on the one GPU over gloo.  Seven blocks of 372 images and one of 371, seven ROTATED rings
+    (rank r's ring = the base ring rotated by 372 r mod 16), 47 steps per rank the last a partial batch (372 = 46 x 8 + 4; rank 7:
+    371 = 46 x 8 + 3), the padded wire block (rank 7 pads one row), ONE collective, every gathered row checked against rank 0's own
+    results for the same content -- and the pool's tables bit-identical to the one-rank run of the same pool."""
+    common = ["--height", "64", "--width", "128", "--channels", "8", "--batch", "8", "--ring", "16", "--warmup", "2",
+              "--pool-images", "2975", "--cpu-images", "0"]
+    one = _bench(common + ["--dump-tables", str(tmp_path / "one.npz")])
+    eight = _bench(common + ["--gpus", "8", "--dump-tables", str(tmp_path / "eight.npz")],
+                   env={"HALO_BENCH_BACKEND": "gloo", "HALO_BENCH_SHARE_GPU": "1"}, timeout=2400)
+    assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    assert one["config"]["image_evaluations"] == eight["config"]["image_evaluations"] == 2975
+    assert eight["steps"] == 47 and one["steps"] == 372                 # ceil(372 / 8), ceil(2975 / 8)
+    assert "contiguous blocks of 372 image(s)" in eight["config"]["sharding"]
+    assert eight["exchange"]["collectives_per_round"] == 1 and eight["exchange"]["ms"] is not None
+    assert eight["exchange"]["rows_checked_against_local_results"] == 2975
+    assert eight["exchange"]["bytes_per_rank"] == 372 * (3 * 10 + 1) * 4   # 10 regions per 64x128 image, padded to 372 rows on every rank
+    assert len(eight["devices"]) == 8 and eight["distinct_devices"] == 1    # the test switch: one shared GPU, reported as such
+    assert len(one["devices"]) == 1 and one["distinct_devices"] == 1
+    assert eight["per_rank_images_per_s"]["min"] > 0 and eight["pipeline_tables_consistent"] is True
+    assert eight["host_threads_per_rank"] == max(1, one["host_threads_per_rank"] // 8)
+    a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "eight.npz")
+    assert int(a["n_pool"]) == int(b["n_pool"]) == 2975 and int(b["world"]) == 8
+    assert np.array_equal(a["counts"], b["counts"]) and a["tables"].shape == b["tables"].shape == (2975, 10, 3)
     assert np.array_equal(a["tables"].view(np.int64), b["tables"].view(np.int64)), "pool tables depend on the world size"
 
 

@@ -1,4 +1,4 @@
-"""Multi-process (gloo, world_size 2, CPU) tests of the sharding + all-gather step.
+"""Multi-process (gloo, world_size 2 / 4 / 8, CPU) tests of the sharding + all-gather step.
 
 The scorer is injected: here it is the CPU oracle standing in for the HIP path (tests may call
 the oracle), so what is under test is the host logic of halo_amd/pool.py.
@@ -104,6 +104,64 @@ def test_two_ranks_equal_one_process(tmp_path, n_images):
     assert kept.min() >= np.sort(ref_t.numpy()[:, :, 2].reshape(-1))[-9]
 
 
+def _synthetic_rows(lo, hi, n):
+    """Deterministic pick table of pool images lo..hi-1 (a function of the GLOBAL image index only): what any rank would have
+    produced for them.  Counts vary per image (0..n), scores include -0.0 / inf / NaN bit patterns."""
+    g = torch.arange(lo, hi, dtype=torch.float64)
+    k = torch.arange(n, dtype=torch.float64)
+    picks = torch.zeros((hi - lo, n, 3), dtype=torch.float64)
+    picks[:, :, 0] = (g[:, None] * 7 + k[None, :] * 13) % 65536
+    picks[:, :, 1] = (g[:, None] * 31 + k[None, :] * 3) % 65536
+    picks[:, :, 2] = torch.sin(g[:, None] * 0.37 + k[None, :]) * 1e3
+    if hi > lo:
+        picks[0, 0, 2] = -0.0
+        picks[-1, -1, 2] = float("nan")
+        picks[(hi - lo) // 2, 0, 2] = float("inf")
+    npk = ((torch.arange(lo, hi) * 5) % (n + 1)).to(torch.int32)
+    return picks, npk
+
+
+def _gather_worker(rank, world, port, n_images, n, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from halo_amd.pool import gather_tables, shard_range
+    lo, hi = shard_range(n_images, rank, world)
+    picks, npk = _synthetic_rows(lo, hi, n)
+    tables, counts, owner = gather_tables(picks, npk, n_images)
+    want_t, want_c = _synthetic_rows(0, n_images, n)
+    # the block-local special values sit at each block's own first / middle / last row: rebuild the expectation block by block
+    want_t = torch.cat([_synthetic_rows(*shard_range(n_images, r, world), n)[0] for r in range(world)])
+    ok = (np.array_equal(tables.numpy().view(np.int64), want_t.numpy().view(np.int64))
+          and torch.equal(counts, want_c) and tables.shape == (n_images, n, 3)
+          and list(owner) == [r for r in range(world) for _ in range(*shard_range(n_images, r, world))])
+    open(os.path.join(outdir, "rank%d.%s" % (rank, "ok" if ok else "bad")), "w").write("%d %d" % (lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_images", [(2, 37), (4, 37), (8, 37), (8, 2975), (4, 2975), (8, 5), (8, 8), (4, 1)])
+def test_gather_tables_at_world_2_4_8_with_uneven_and_empty_blocks(tmp_path, world, n_images):
+    """SURVEY 8e at the world sizes the 8-GPU node runs (configs[3]: 2975 images -> seven blocks of 372 and one of 371): every
+    rank packs its block (shorter than ceil(N/world) on the last non-empty rank, EMPTY on the ranks behind it when N < world),
+    pads it to the fixed wire block, and ONE all_gather_into_tensor returns the pool's tables in pool order on every rank, bit for
+    bit (NaN / -0.0 / inf score patterns included), with the owner map shard_range implies."""
+    mp.spawn(_gather_worker, args=(world, _free_port(), n_images, 5, str(tmp_path)), nprocs=world, join=True)
+    done = sorted(os.listdir(tmp_path))
+    assert done == sorted("rank%d.ok" % r for r in range(world)), done
+    from halo_amd.pool import shard_range
+    if (world, n_images) == (8, 2975):
+        sizes = [int(open(tmp_path / ("rank%d.ok" % r)).read().split()[1]) - int(open(tmp_path / ("rank%d.ok" % r)).read().split()[0])
+                 for r in range(8)]
+        assert sizes == [372] * 7 + [371]
+    if (world, n_images) == (8, 5):
+        assert [shard_range(5, r, 8) for r in (4, 5, 7)] == [(4, 5), (5, 5), (5, 5)]
+
+
 # ------------------------------------------------------------------ wire format and the sharded driver
 def test_wire_format_round_trips_bit_exactly():
     from halo_amd.pool import pack_tables, unpack_tables
@@ -175,6 +233,7 @@ def _oracle_driver(cfg, feature_extractor, classifier, loader, round_number):
 
 def _sharded_worker(rank, world, port, n_images, root, n_regions):
     import sys
+    torch.set_num_threads(1)
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -189,31 +248,34 @@ def _sharded_worker(rank, world, port, n_images, root, n_regions):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_regions", [None, 40])
-def test_region_selection_sharded_two_ranks_write_the_single_process_files(tmp_path, n_regions):
+@pytest.mark.parametrize("world,n_images,n_regions", [(2, 5, None), (2, 5, 40), (4, 11, None), (8, 11, 40), (8, 5, None)])
+def test_region_selection_sharded_ranks_write_the_single_process_files(tmp_path, world, n_images, n_regions):
     """SURVEY 8f N2 / 8e: every rank drives its block of the pool and writes its own mask / indicator files;
-    the union of the files and the all-gathered pick tables equal the single-process (reference order) run."""
+    the union of the files and the all-gathered pick tables equal the single-process (reference order) run --
+    at world 2, 4 and 8, with uneven blocks, and with ranks whose block is empty (8 ranks, 5 images)."""
     from PIL import Image
-    from halo_amd.pool import region_selection_sharded
-    n_images = 5
+    from halo_amd.pool import region_selection_sharded, shard_range
     one, two = tmp_path / "one", tmp_path / "two"
     one.mkdir(); two.mkdir()
     ref = region_selection_sharded(_cfg(), None, None, _Pool(str(one), n_images), 1, driver=_oracle_driver,
                                    loader_kwargs=dict(pin_memory=False), n_regions=n_regions)
     assert ref["range"] == (0, n_images) and ref["keep"] is None
-    mp.spawn(_sharded_worker, args=(2, _free_port(), n_images, str(two), n_regions), nprocs=2, join=True)
+    mp.spawn(_sharded_worker, args=(world, _free_port(), n_images, str(two), n_regions), nprocs=world, join=True)
     for i in range(n_images):
         a = np.array(Image.open(one / f"m{i}.png")); b = np.array(Image.open(two / f"m{i}.png"))
         assert Image.open(two / f"m{i}.png").mode == "L" and np.array_equal(a, b), i
         ia, ib = torch.load(one / f"i{i}.pth"), torch.load(two / f"i{i}.pth")
         assert torch.equal(ia["active"], ib["active"]) and torch.equal(ia["selected"], ib["selected"]), i
         assert ib["active"].dtype == torch.bool and int(ib["selected"].sum()) > 0
-    r0, r1 = np.load(two / "rank0.npz"), np.load(two / "rank1.npz")
-    assert list(r0["rng"]) == [0, 3] and list(r1["rng"]) == [3, 5]
-    for r in (r0, r1):
+    ranks = [np.load(two / ("rank%d.npz" % r)) for r in range(world)]
+    blocks = [shard_range(n_images, r, world) for r in range(world)]
+    assert [tuple(r["rng"]) for r in ranks] == blocks            # world 8, 5 images: ranks 5..7 hold EMPTY blocks and still take part
+    if world == 2:
+        assert blocks == [(0, 3), (3, 5)]
+    for r in ranks:
         assert np.array_equal(r["tables"].view(np.int64), ref["tables"].numpy().view(np.int64))
         assert np.array_equal(r["counts"], ref["counts"].numpy())
-        assert list(r["owner"]) == [0, 0, 0, 1, 1]
+        assert list(r["owner"]) == [k for k, (lo, hi) in enumerate(blocks) for _ in range(lo, hi)]
     assert int(ref["counts"].min()) > 0
 
 

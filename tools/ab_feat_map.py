@@ -4,7 +4,8 @@ allocation (the plateau a run lands on is a property of the allocation, NOTES.md
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from halo_amd import _lib
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
+from tools import halo_probe
 from halo_amd.core.active.floating_region import score_maps
 
 dev = torch.device("cuda:0")
@@ -23,7 +24,7 @@ for dt in (torch.float64, torch.float32):
     sink = torch.zeros(1, dtype=torch.int32, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     for i in range(5):
-        _lib.check(_lib.lib().halo_hbm_read_probe(_lib.ptr(feat), nb, _lib.ptr(sink), 0, _lib.stream_ptr(dev)), "probe"); ev[i].record()
+        halo_probe.read_probe(feat, nb, sink); ev[i].record()
     torch.cuda.synchronize()
     flat = np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(1, 4)])
     print(f"{dt}: flat read of this allocation {flat:.3f} ms = {nb / flat / 1e6:.0f} GB/s")

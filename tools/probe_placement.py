@@ -4,7 +4,8 @@ real scoring call; everything is freed before the next placement."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from halo_amd.pool import alloc_contiguous, probe_streaming, contiguous_memory_stats
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
+from tools.halo_probe import alloc_contiguous, probe_streaming, contiguous_memory_stats
 from halo_amd.core.active.floating_region import score_maps
 
 dev = torch.device("cuda:0")

@@ -3,6 +3,7 @@ under rocprofv3 --kernel-trace / --pmc."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.active.floating_region import score_maps
 dev = torch.device("cuda:0")
 B, O, H, W = 16, 19, 1024, 2048

@@ -3,6 +3,7 @@ under rocprofv3 --pmc ... --kernel-trace: both low-res modes (k_feat_reduce_lr_d
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.active.floating_region import score_maps_lowres
 dev = torch.device("cuda:0")
 B, C, O, h, w, H, W = 16, 256, 19, 256, 512, 1024, 2048

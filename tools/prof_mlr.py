@@ -2,6 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
 dev = torch.device("cuda:0")
 x = HyperMapper(1.0).expmap(torch.randn((1, 256, 1024, 2048), device=dev) * 0.1, dim=1)

@@ -3,7 +3,7 @@ eight rounds, so that the counters of k_feat_reduce launches on a fast and on a 
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import halo_amd  # noqa: F401
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.active.floating_region import score_maps
 
 dev = torch.device("cuda:0")

@@ -45,6 +45,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "summarize":
     summarize(sys.argv[2]); sys.exit(0)
 
 import torch
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.active.build import greedy_select
 from halo_amd.core.active.floating_region import score_maps
 dev = torch.device("cuda:0")

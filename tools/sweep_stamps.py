@@ -21,6 +21,7 @@ if "--build" in sys.argv:
     sys.exit(0)
 os.environ["HALO_LIB_PATH"] = SO
 import numpy as np, torch
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.active import build as B
 from halo_amd.core.active.floating_region import _workspace, score_maps
 

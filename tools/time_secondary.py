@@ -5,6 +5,7 @@ for the previous kernels (A/B)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners
 
 dev = torch.device("cuda:0")

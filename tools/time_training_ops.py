@@ -3,6 +3,7 @@ head tail (expmap -> HyperMLR, batch 2, C=64, 160x320) and the two window losses
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
 from halo_amd.core.loss import LocalConsistentLoss, NegativeLearningLoss
 from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
 
