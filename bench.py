@@ -72,10 +72,10 @@ def parse():
     ap.add_argument("--source", choices=["fullres", "lowres"], default="fullres",
                     help="fullres = SURVEY 8(d) unit of work (default, the BASELINE metric); lowres = the "
                          "RegionSelection boundary: x4 low-res head outputs, upsampling fused into the scorer (N1)")
-    ap.add_argument("--lr-mode", choices=["gram", "exact"], default="gram",
-                    help="--source lowres only: 'gram' (the product's default for float64 embeddings) evaluates the embedding's radius "
-                         "through per-cell Gram terms (SURVEY 8f N1); 'exact' interpolates every channel (bit-identical to "
-                         "upsample-then-score)")
+    ap.add_argument("--lr-mode", choices=["gram", "exact"], default="exact",
+                    help="--source lowres only: 'exact' (the product's default) interpolates every channel, bit-identical to "
+                         "upsample-then-score; 'gram' (opt-in) evaluates a float64 embedding's radius through per-cell Gram terms "
+                         "(SURVEY 8f N1), guarded against cancellation")
     ap.add_argument("--cpu-images", type=int, default=8, help="timed images in the CPU-baseline sample, after one "
                                                               "untimed warm-up image (0 = skip)")
     ap.add_argument("--resets", choices=["undo", "kernel", "fills", "side"], default="undo",
@@ -148,7 +148,7 @@ class Pipeline:
     collect in one wire block that is exchanged ONCE, behind the last step."""
 
     def __init__(self, dev, feat, logit, gt, B, n_regions, rows, depth, lowres=False, branch="halo",
-                 resets="undo", sel_priority=-1, lr_mode="gram", tail="auto"):
+                 resets="undo", sel_priority=-1, lr_mode="exact", tail="auto"):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions

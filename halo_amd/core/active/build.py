@@ -320,10 +320,10 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     for the GPU: a pool of writer threads waits for each image's event, encodes the PNG and writes the
     indicator.  At most `in_flight` images are between "launched" and "copied back to the host" (bounds device
     and pinned memory; each slot owns its pinned staging buffers); `in_flight=0` runs strictly one image at a
-    time like the reference.  `writer_threads` defaults to min(8, usable host cores / LOCAL_WORLD_SIZE).  `lowres_mode`: 'gram' (default; environment HALO_LOWRES) evaluates the radius of a float64
-    embedding through per-cell Gram terms (floating_region.score_maps_lowres: bit-identical to its oracle twin, maps within
-    1e-12 of upsample-then-score, the reference's files on every test vector); 'exact' interpolates every channel and is
-    bit-identical to upsample-then-score (the only route for float32 embeddings)."""
+    time like the reference.  `writer_threads` defaults to min(8, usable host cores / LOCAL_WORLD_SIZE).  `lowres_mode`: 'exact' (default; environment HALO_LOWRES) interpolates every channel and is
+    bit-identical to upsample-then-score, the reference's order; 'gram' (opt-in, float64 embeddings) evaluates the radius through
+    per-cell Gram terms (floating_region.score_maps_lowres: bit-identical to its oracle twin, squared norms within 1.3e-10 of
+    the exact order, the reference's files on every test vector -- but not the reference's evaluation order)."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor

@@ -147,8 +147,9 @@ LOWRES_MODES = ("exact", "gram")
 
 
 def lowres_mode(mode=None):
-    """'gram' (default) or 'exact'; None reads HALO_LOWRES from the environment"""
-    mode = os.environ.get("HALO_LOWRES", "gram") if mode is None else mode
+    """'exact' (default: the reference's evaluation order, bit-identical to upsample-then-score) or 'gram' (opt-in);
+    None reads HALO_LOWRES from the environment"""
+    mode = os.environ.get("HALO_LOWRES", "exact") if mode is None else mode
     if mode not in LOWRES_MODES:
         raise ValueError("low-res mode must be one of %s, got %r" % (LOWRES_MODES, mode))
     return mode
@@ -161,11 +162,14 @@ def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, 
     `size`, without materialising the upsampled tensors -- core/active/build.py:122-144 in one call.
     logit_lr (B,O,hl,wl) float32, decoder_lr (B,C,hf,wf) float64|float32.
 
-    mode 'gram' (default for float64 embeddings; float32 ones take 'exact'): the embedding's radius / norm through the 10
-    inner products of each low-res cell's corner vectors -- bit-identical to the CPU oracle's statement of
-    that form (oracle.halo_oracle.gram_radius), within ~1e-15 of upsample-then-reduce, 3x faster at C = 256.
-    mode 'exact': bit-identical to bilinear_align_corners(...) followed by score_maps(...).  Everything else is the same
-    in both modes.  `events`: four optional handles from halo_event_create recorded around the logit and embedding passes."""
+    mode 'exact' (default): bit-identical to bilinear_align_corners(...) followed by score_maps(...) -- the reference's
+    evaluation order (build.py:133-135 then floating_region.py:129-217).
+    mode 'gram' (opt-in: mode="gram" or HALO_LOWRES=gram; float64 embeddings only, float32 ones take 'exact'): the embedding's
+    radius / norm through the 10 inner products of each low-res cell's corner vectors -- bit-identical to the
+    CPU oracle's statement of that form (oracle.halo_oracle.gram_radius), 2x faster at C = 256, but NOT the reference's
+    order: squared norms agree with the exact order to 1.3e-10 relative (observed < 1e-12; pixels whose Gram terms cancel
+    are evaluated in the exact order), which can move a radius-bin boundary of the 'hyper' purity or the order of two
+    near-tied scores.  Everything else is the same in both modes.  `events`: four optional handles from halo_event_create recorded around the logit and embedding passes."""
     if pur_type not in _lib.PUR:
         raise NotImplementedError("Error: purity type '{}' not implemented".format(pur_type))
     mode = lowres_mode(mode)

@@ -168,7 +168,8 @@ __device__ __forceinline__ double dist0_from_ssq(double ssq, double ks, double r
 {
     return 2.0 * (rks * artanh_clamped(__builtin_sqrt(ssq) * ks));
 }
-// float32 tensor: norm, scaling and clamp stay in float32, the logs run in float64
+// float32 tensor: all of it in float32 -- geoopt's stereographic artanh takes its two logs in the input dtype
+// (x.clamp(-1+1e-7, 1-1e-7); 0.5 * (log(1 + x) - log(1 - x))); both arguments are positive normal floats in [2^-23, 2)
 __device__ __forceinline__ float dist0_from_ssq(float ssq, double ks, double rks)
 {
     float n = __builtin_sqrtf(ssq);
@@ -176,9 +177,8 @@ __device__ __forceinline__ float dist0_from_ssq(float ssq, double ks, double rks
     const float lim = (float)(1.0 - 1e-7);
     if (z > lim) z = lim;
     if (z < -lim) z = -lim;
-    double zd = (double)z;
-    const double r = (det_log_core(1.0 + zd) - det_log_core(1.0 - zd)) * 0.5;
-    float a = (float)(zd != zd ? zd : r);
+    float a = (det_logf_core(1.0f + z) - det_logf_core(1.0f - z)) * 0.5f;
+    a = z != z ? z : a;
     return 2.0f * ((float)rks * a);
 }
 

@@ -1488,7 +1488,10 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
         const int sr = ty_lo + r < h - 1 ? ty_lo + r : h - 1;
         int q0 = tx_lo + 2 * pp;
         q0 = q0 + 1 > w - 1 ? w - 2 : q0;                        // pairs past the last column (one of them is read: patched below)
-        sch[i] = (unsigned)ch;
+        // CCF * PER < DMA_UNITS: the trailing units of a wave's last DMA belong to no channel of the chunk (their LDS slots are
+        // never read).  They re-load the chunk's last channel instead of channel c0 + CCF, which for a FULL last chunk
+        // (C a multiple of CCF) would be one plane past the image -- past the tensor for the last image of the batch
+        sch[i] = (unsigned)(ch < CCF ? ch : CCF - 1);
         soff[i] = (unsigned)(sr * w + q0);
     }
     const T *fb = feat + (size_t)b * bstride;
@@ -1584,8 +1587,8 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
 //     D1(y,x) = <v(y,x), v(n(y),n(x))>   D2(y,x) = <v(y,n(x)), v(n(y),x)>
 // k_gram_lr computes the maps in one pass over the low-res tensor (sequential fma chains over the channels);
 // k_radius_gram evaluates the 10-term form per output pixel.  Mathematically the same number as k_feat_reduce_lr,
-// rounded differently (a few 1e-16 of the largest corner norm; a negative rounding residue is clamped to zero), so this
-// mode is NOT bit-identical to upsample-then-score: it is opt-in (halo_score_maps_lr_gram) and float64 only.
+// rounded differently (a few 1e-16 of the largest corner norm; pixels whose terms cancel take the exact order: GRAM_GUARD),
+// so this mode is NOT bit-identical to upsample-then-score: it is opt-in (halo_score_maps_lr_gram) and float64 only.
 constexpr int GRAM_MAPS = 5;
 constexpr int GRAM_COLS = 63;          // columns per wave: lane 63 only supplies the right neighbour of lane 62
 
@@ -1724,8 +1727,17 @@ __global__ void __launch_bounds__(TPB) k_gram_lr2(const double *__restrict__ fea
     }
 }
 
+// Cancellation guard: when neighbouring low-res vectors point in opposing directions the 10 terms cancel and the
+// Gram form keeps only the bits of s that stand above ~2^-53 of the terms' magnitudes t = sum |coef * G|.  A pixel with
+// s < 2^-10 t takes the EXACT evaluation order instead (interpolate every channel, then the fma chain over the squares --
+// what upsample-then-score computes, bit for bit), so the Gram value is only ever used where it carries >= 43 good bits:
+// |s_gram - s_exact| <= 1.3e-10 s for C <= 256 (4 C u 2^10; observed < 1e-12).  oracle/halo_oracle.c:halo_o_gram_radius
+// states the same rule.
+constexpr double GRAM_GUARD = 0x1p-10;
+
 template <int MODE>
-__global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ gram, int h, int w, int H, int W, double sh, double sw,
+__global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ gram, const double *__restrict__ feat, long long bstride,
+                                                     int C, int h, int w, int H, int W, double sh, double sw,
                                                      double ks, double rks, double *__restrict__ out, double *__restrict__ partials)
 {
     const int b = blockIdx.y;
@@ -1743,7 +1755,7 @@ __global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ 
                      c11 = (size_t)ty.i1 * w + tx.i1;
         // <v_a, v_b> for corners a <= b in the order (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
         const double G[10] = {S[c00], Hh[c00], Vv[c00], D1[c00], S[c01], D2[c00], Vv[c01], S[c10], Hh[c10], S[c11]};
-        double s = 0.0;
+        double s = 0.0, t = 0.0;
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -1752,8 +1764,17 @@ __global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ 
                 double coef = wt[a] * wt[c2];
                 if (c2 != a) coef = coef + coef;
                 s = __builtin_fma(coef, G[k], s);
+                t = __builtin_fma(coef, __builtin_fabs(G[k]), t);
             }
-        s = s < 0.0 ? 0.0 : s;                    // rounding residue of a vanishing sum; NaN stays NaN
+        if (s < t * GRAM_GUARD) {                 // cancellation (covers every negative residue); NaN compares false and stays NaN
+            const double *pl = feat + (size_t)b * bstride;
+            double acc = 0.0;
+            for (int ch = 0; ch < C; ++ch, pl += hwl) {
+                const double v = lerp4<double>(pl[c00], pl[c01], pl[c10], pl[c11], wt[0], wt[1], wt[2], wt[3]);
+                acc = __builtin_fma(v, v, acc);
+            }
+            s = acc;
+        }
         double r;
         if constexpr (MODE == 0) r = dist0_from_ssq(s, ks, rks);
         else r = __builtin_sqrt(s);
@@ -2080,8 +2101,8 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
             }
             const double shd = H > 1 ? (double)(lr->hf - 1) / (double)(H - 1) : 0.0, swd = W > 1 ? (double)(lr->wf - 1) / (double)(W - 1) : 0.0;
             nblk_imp = nblk1;
-            if (mode == 0) hipLaunchKernelGGL(k_radius_gram<0>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
-            else hipLaunchKernelGGL(k_radius_gram<1>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
+            if (mode == 0) hipLaunchKernelGGL(k_radius_gram<0>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, (const double *)feat, (long long)feat_bstride, (int)C, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
+            else hipLaunchKernelGGL(k_radius_gram<1>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, (const double *)feat, (long long)feat_bstride, (int)C, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
         } else if (lr) {
             const int rc = feat_dtype == HALO_F64
                 ? launch_feat_lr<double>((const double *)feat, feat_bstride, (int)C, *lr, (int)H, (int)W, (int)B, mode, ks, rks, imp_raw, part_imp, nblk_imp, st)

@@ -83,12 +83,16 @@ __device__ __forceinline__ ValRange sel_range(const SelHdr &h)
     return r;
 }
 
-// coarse bin of a finite value v >= lo; t = position in bin units (monotone in v)
+// coarse bin of a finite value v; t = position in bin units (monotone, non-decreasing in v).  The range record only has to bound
+// the values for the bins to be well filled, NOT for correctness: a value below `lo` is clamped into the lowest bin explicitly
+// (t >= 0: nothing relies on how a negative double converts), one above `hi` into the highest, and the sub-bin of such a value
+// is clamped by its caller -- binning stays monotone, so the picks do not depend on the record.
 __device__ __forceinline__ int coarse_bin(double v, const ValRange &r, double &t)
 {
     t = (v - r.lo) * r.scale;
-    const int j = (int)t;
-    return j > NB1 - 1 ? NB1 - 1 : j;
+    t = t > 0.0 ? t : 0.0;
+    const int j = t < (double)(NB1 - 1) ? (int)t : NB1 - 1;
+    return j;
 }
 
 // ------------------------------------------------------------------ counters to zero

@@ -135,7 +135,9 @@ static double dist0_from_ssq_f64(double ssq, double ks, double rks)
 {
     return 2.0 * (rks * artanh_clamped(sqrt(ssq) * ks));
 }
-/* float32 input: norm, scaling and clamp happen in float32, the logs in float64 */
+/* float32 input: everything in float32 -- geoopt's stereographic artanh is x.clamp(-1+1e-7, 1-1e-7) followed by
+ * 0.5 * (log(1 + x) - log(1 - x)) IN THE INPUT DTYPE (the float64 detour belongs to the older poincare/math.py
+ * Artanh).  The clamp bound 1 - 1e-7 rounds to 1 - 2^-23 in float32. */
 static float dist0_from_ssq_f32(float ssq, double ks, double rks)
 {
     float n = sqrtf(ssq);
@@ -143,8 +145,8 @@ static float dist0_from_ssq_f32(float ssq, double ks, double rks)
     const float lim = (float)(1.0 - 1e-7);
     if (z > lim) z = lim;
     if (z < -lim) z = -lim;
-    double zd = (double)z;
-    float a = (float)((ho_log(1.0 + zd) - ho_log(1.0 - zd)) * 0.5);
+    float a = (ho_logf(1.0f + z) - ho_logf(1.0f - z)) * 0.5f;
+    if (z != z) a = z;
     return 2.0f * ((float)rks * a);
 }
 
@@ -312,7 +314,10 @@ void halo_o_bilinear_f32(const float *src, float *dst, i64 planes, i64 h, i64 w,
  *     D2 = <v(y,n(x)), v(n(y),x)>          (n(.) = neighbour clamped to the grid = the tap i1)
  * as sequential fma chains over the channels from +0, then per output pixel the 10-term fma chain over
  * the corner pairs (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3) with coefficient w_a*w_b, doubled
- * by one addition when a != b; a negative rounding residue is clamped to zero.
+ * by one addition when a != b.  Cancellation guard: with t = the same chain over |<v_a,v_b>|, a pixel with
+ * s < 2^-10 t (every negative rounding residue included) is evaluated in the EXACT order instead -- the four
+ * taps of every channel combined as in halo_o_bilinear_f64, then the fma chain over the squares -- so the Gram
+ * value is only used where it keeps >= 43 bits: |s_gram - s_exact| <= 4 C u 2^10 s (1.2e-10 at C = 256).
  * feat (C,h,w) f64 -> out (H,W) f64; mode 0: dist0 (radius), 1: sqrt (norm).
  * ------------------------------------------------------------------------- */
 void halo_o_gram_radius(const double *feat, i64 C, i64 h, i64 w, i64 H, i64 W, int mode, double c, double *out)
@@ -353,15 +358,27 @@ void halo_o_gram_radius(const double *feat, i64 C, i64 h, i64 w, i64 H, i64 W, i
             const double wt[4] = {ly0 * lx0, ly0 * lx1, ly1 * lx0, ly1 * lx1};
             const i64 c00 = y0 * w + x0, c01 = y0 * w + x1, c10 = y1 * w + x0, c11 = y1 * w + x1;
             const double G[10] = {S[c00], Hh[c00], Vv[c00], D1[c00], S[c01], D2[c00], Vv[c01], S[c10], Hh[c10], S[c11]};
-            double s = 0.0;
+            double s = 0.0, t = 0.0;
             int k = 0;
             for (int a = 0; a < 4; ++a)
                 for (int b = a; b < 4; ++b, ++k) {
                     double coef = wt[a] * wt[b];
                     if (b != a) coef = coef + coef;
                     s = fma(coef, G[k], s);
+                    t = fma(coef, fabs(G[k]), t);
                 }
-            s = s < 0.0 ? 0.0 : s;                      /* NaN stays NaN */
+            if (s < t * 0x1p-10) {                      /* cancellation guard: this pixel in the EXACT order (NaN stays NaN) */
+                double acc = 0.0;
+                for (i64 ch = 0; ch < C; ++ch) {
+                    const double *pl = feat + ch * hwl;
+                    double a = pl[c01] * wt[1];
+                    a = fma(pl[c00], wt[0], a);
+                    a = fma(pl[c10], wt[2], a);
+                    a = fma(pl[c11], wt[3], a);
+                    acc = fma(a, a, acc);
+                }
+                s = acc;
+            }
             out[y * W + x] = mode == 0 ? dist0_from_ssq_f64(s, ks, rks) : sqrt(s);
         }
     }

@@ -79,3 +79,23 @@ def max_abs_diff(a, b):
     if m.all():
         return 0.0
     return float(np.abs(a[~m] - b[~m]).max())
+
+
+def opposing_neighbours_embedding(C=16, h=12, w=20, seed=0):
+    """Adversarial low-res embedding for the Gram form of the radius: a checkerboard of v and -v (1 - eps) with eps
+    from 1e-1 to 1e-12 per cell -- the interpolated vector between two neighbours nearly vanishes and the 10 Gram terms cancel --
+    plus a block of random vectors, a block of random vectors projected onto the ball's boundary (norm 1 - 1e-5) and a block of
+    OPPOSING boundary vectors.  (1, C, h, w) float64."""
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal(C)
+    u /= np.linalg.norm(u)
+    eps = 10.0 ** (-rng.uniform(1, 12, (h, w)))
+    sign = (-1.0) ** np.add.outer(np.arange(h), np.arange(w))
+    emb = np.zeros((1, C, h, w))
+    emb[0] = u[:, None, None] * (0.5 * (1 - eps) * sign)[None]
+    bh, bw = max(1, h // 3), max(1, w // 3)
+    emb[0, :, :bh, :bw] = rng.standard_normal((C, bh, bw)) * 0.1
+    b = rng.standard_normal((C, bh, bw))
+    emb[0, :, -bh:, -bw:] = b / np.linalg.norm(b, axis=0, keepdims=True) * (1 - 1e-5)
+    emb[0, :, -bh:, :bw] = u[:, None, None] * ((1 - 1e-5) * sign[-bh:, :bw])[None]
+    return emb

@@ -10,7 +10,7 @@ functions the reference's hot path calls -- ``expmap0``, ``project``,
 * ``sabs(x) = |x| + 1e-15``
 * ``tanh(x) = x.clamp(-15, 15).tanh()``
 * ``artanh(x) = 0.5 * (log(1 + z) - log(1 - z))``, ``z = x.clamp(-1+1e-7, 1-1e-7)``,
-  evaluated in float64 and cast back
+  evaluated in the INPUT dtype
 * ``tan_k / artan_k`` for k < 0: ``tanh(x*sqrt(sabs(k))) / sqrt(sabs(k))`` and
   ``artanh(x*sqrt(sabs(k))) / sqrt(sabs(k))``
 * ``project``: eps = 4e-3 (float32) / 1e-5 (float64)
@@ -23,11 +23,14 @@ geoopt layer of the fixtures is "parity unpinned" (see DESIGN.md); the
 closed-form known-answer tests in tests/test_oracle_kat.py pin that layer
 independently with mpmath.
 
-Open doubt: ``artanh`` below evaluates its two logarithms in float64 and casts back -- the
-form of geoopt's older ``poincare/math.py`` ``Artanh`` function; ``stereographic/math.py`` may compute
-``0.5 * (log1p(z) - log1p(-z))`` in the INPUT dtype.  For float64 inputs (the reference's HYPER=True path) the two are
-one; for float32 inputs they differ by at most ~3 float32 ulp.  tests/test_oracle_kat.py evaluates dist0 both
-ways in torch and holds the oracle / HIP result within 2e-6 relative of BOTH, so the 1e-4 bar holds whichever it is.
+``artanh`` and float32: rounds 1-3 of this stand-in took the two logarithms in float64 and cast back --
+the form of geoopt's OLDER ``poincare/math.py`` ``Artanh`` autograd function.  ``stereographic/math.py`` (the module the
+reference imports) reads ``x = x.clamp(-1 + 1e-7, 1 - 1e-7); return (torch.log(1 + x).sub(torch.log(1 - x))).mul(0.5)``:
+plain ``log`` (not ``log1p``) in the input dtype.  Round 4 restates it that way here, in the oracle
+(oracle/halo_oracle.c:dist0_from_ssq_f32) and in the device recipe (halo_devmath.hpp:dist0_from_ssq(float)).  For float64
+inputs (the reference's HYPER=True path) nothing changes.  For float32 inputs the rounding of ``1 + z`` / ``1 - z`` to
+float32 is part of the convention: it moves a radius by up to ~1.2e-7 ABSOLUTE against the float64-log form (a large
+relative change only for radii << 1e-3).  tests/test_oracle_kat.py brackets both forms (dist0 and logmap0).
 
 Only the k < 0 (Poincare ball) branch is needed: HyperMapper always passes
 ``k = tensor(-c)`` with c > 0 (hyperbolic.py:26).
@@ -44,11 +47,8 @@ def tanh(x):
 
 
 def artanh(x):
-    z = x.clamp(-1 + 1e-7, 1 - 1e-7)
-    dtype = z.dtype
-    z = z.double()
-    res = (torch.log(1 + z).sub(torch.log(1 - z))).mul(0.5)
-    return res.to(dtype)
+    x = x.clamp(-1 + 1e-7, 1 - 1e-7)
+    return (torch.log(1 + x).sub(torch.log(1 - x))).mul(0.5)
 
 
 def _k_sqrt(k):

@@ -214,6 +214,17 @@ def gen_hypermapper(hyp):
         out[f"{tag}__dist"] = m.poincare_distance(xh, yh).numpy()
         out[f"{tag}__expmap2"] = m.expmap2(x.double()).numpy()
         out[f"{tag}__cosine"] = m.cosine_distance(x[6:], yh[6:].float()).numpy()
+        # float32 points: geoopt's dist0 then stays in float32 (artanh's two logs in the input dtype, shim docstring); rows
+        # scaled to radii from 1e-4 to the clamp at 1 - 1e-7 -- own generator, so the arrays above keep their bits
+        g3 = torch.Generator().manual_seed(101 + int(c * 10))
+        xf = torch.randn(41, 12, generator=g3, dtype=torch.float32)
+        xf = xf / xf.norm(dim=1, keepdim=True)
+        radii = torch.cat([torch.logspace(-4, -0.01, 30), torch.tensor([0.99, 0.999, 0.9999, 0.99999, 0.999999, 0.9999999, 1.0, 1.5,
+                                                                         0.0, 0.3, 0.6])]).float() / math.sqrt(c)
+        xf = (xf * radii[:, None]).contiguous()
+        out[f"{tag}__x_f32"] = xf.numpy()
+        out[f"{tag}__dist0_f32"] = m.poincare_distance_origin(xf).numpy()
+        assert out[f"{tag}__dist0_f32"].dtype == np.float32
     # HyperMetrics.compute (hyperbolic.py:191-228; no caller in-tree) -- its own generator, so the arrays above keep their bits
     g2 = torch.Generator().manual_seed(100)
     for c in (1.0, 0.5):

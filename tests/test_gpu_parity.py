@@ -50,7 +50,7 @@ def _with_env(env, fn):
 
 
 def _lr_mode():
-    """the low-res mode RegionSelection / score_maps_lowres run in by default ('gram' unless HALO_LOWRES says otherwise):
+    """the low-res mode RegionSelection / score_maps_lowres run in by default ('exact' unless HALO_LOWRES says otherwise):
     the oracle driver is asked for the same evaluation order, so the comparisons stay bit-exact"""
     from halo_amd.core.active.floating_region import lowres_mode
     return lowres_mode(None)
@@ -821,6 +821,24 @@ def test_selection_with_the_scorers_range_records(dev):
         am = torch.full((2, H, W), 255, dtype=torch.int64, device=dev)
         outs.append(greedy_select(s2, n, 1, 5, a, sl, am, t(gt[:2], dev), score_range=r_)[0].cpu().numpy())
     assert bits_equal(outs[0], outs[1])
+    # a record that does NOT bound its map: the record of a map in [0, 1] handed over with a map whose values
+    # reach slightly below 0 and above 1 (and far outside) -- binning clamps explicitly, picks are those of the unranged path
+    base = t(rng.random((2, H, W)), dev)
+    rec = new_score_range(2, dev)
+    _lib.check(_lib.lib().halo_score_range(_lib.ptr(base), _lib.dtype_code(base), 2, H, W, _lib.ptr(rec), _lib.stream_ptr(dev)), "halo_score_range")
+    for spread in (1e-9, 1e-3, 0.5, 40.0):
+        wild = base.clone()
+        m = t(rng.random((2, H, W)) < 0.15, dev)
+        wild[m] = wild[m] * (1 + 2 * spread) - spread                  # into [-spread, 1 + spread]
+        outs = []
+        for r_ in (None, rec):
+            s2 = wild.clone()
+            a, sl = torch.zeros((2, H, W), dtype=torch.bool, device=dev), torch.zeros((2, H, W), dtype=torch.bool, device=dev)
+            am = torch.full((2, H, W), 255, dtype=torch.int64, device=dev)
+            pk, nk = greedy_select(s2, n, 1, 5, a, sl, am, t(gt[:2], dev), score_range=r_)
+            outs.append((pk.cpu().numpy(), nk.cpu().numpy(), a.cpu().numpy(), am.cpu().numpy()))
+        assert bits_equal(outs[0][0], outs[1][0]) and all(np.array_equal(x, y) for x, y in zip(outs[0][1:], outs[1][1:])), spread
+        assert float(wild.min()) < 0 and float(wild.max()) > 1
     lg, em = t(rng.standard_normal((1, O, 24, 40)).astype(np.float32), dev), t(rng.standard_normal((1, C, 12, 20)) * 0.1, dev)
     outs = []
     for ranged in (False, True):
@@ -880,6 +898,78 @@ def test_score_and_select_replay_from_a_hip_graph(dev):
         for name, got, exp in zip(("score", "picks", "n_picked", "active", "selected", "active_mask"), (score, picks, npk, act, sel, am), w):
             same = bits_equal(got.cpu().numpy(), exp.cpu().numpy()) if got.dtype.is_floating_point else torch.equal(got, exp)
             assert same, (rep, seed, name, int((got != exp).sum()))
+
+
+@pytest.mark.parametrize("shape", [(16, 12, 20, 48, 80), (256, 12, 20, 45, 77), (7, 9, 9, 64, 64), (64, 16, 32, 64, 128), (32, 30, 44, 120, 176)])
+def test_gram_mode_is_guarded_against_cancellation(dev, shape):
+    """VERDICT r3 #2 on hardware: opposing neighbours (v, -v (1 - eps), eps 1e-1 .. 1e-12) and opposing boundary vectors.
+    HIP 'gram' == its oracle twin bit for bit (the guard's exact-order pixels included; even and odd source widths take
+    k_gram_lr2 / k_gram_lr); against the EXACT-order oracle (ho.bilinear + floating_region_score) the norm tanh(r/2) agrees
+    to 1e-11 relative (bound by construction 6.5e-11), the normalised maps to 1e-10, and picks, masks and pick
+    order are identical."""
+    from conftest import opposing_neighbours_embedding
+    from halo_amd.core.active.build import acquire_batch_lowres
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from oracle import halo_oracle as ho
+    C, h, w, H, W = shape
+    emb = opposing_neighbours_embedding(C, h, w, seed=C)
+    rng = np.random.default_rng(5)
+    logit_lr = rng.standard_normal((1, 19, h, w)).astype(np.float32)
+    lg, em = t(logit_lr, dev), t(emb, dev)
+    r_hip = score_maps_lowres(lg, em, (H, W), "none", "radius", False, None, ksize=3, mode="gram")[1][0].cpu().numpy()
+    assert bits_equal(r_hip, ho.gram_radius(emb[0], (H, W), "radius", 1.0))
+    e_hip = score_maps_lowres(lg, em, (H, W), "none", "euc_norm", False, None, ksize=3, mode="gram")[1][0].cpu().numpy()
+    assert bits_equal(e_hip, ho.gram_radius(emb[0], (H, W), "euc_norm", 1.0))
+    up, lgu = ho.bilinear(emb, (H, W)), ho.bilinear(logit_lr, (H, W))
+    r_exact = ho.dist0(up, 1.0, dim=1)[0]
+    n_exact, n_hip = np.tanh(r_exact / 2), np.tanh(r_hip / 2)
+    assert n_exact.min() < 1e-3 and n_exact.max() > 0.999
+    assert np.max(np.abs(n_hip - n_exact) / np.maximum(n_exact, 1e-300)) <= 1e-11
+    assert (r_hip == r_exact).mean() > 0.3                                  # guarded pixels: the exact order's bits
+    g = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, ksize=3, mode="gram")
+    so, io, uo = ho.floating_region_score(lgu, up, "entropy", "radius", True, None, size=3, purity_type="radius")
+    assert np.max(np.abs(g[0][0].cpu().numpy() - so)) <= 1e-10 and np.max(np.abs(g[1][0].cpu().numpy() - io)) <= 1e-10
+    assert bits_equal(g[2][0].cpu().numpy(), uo)
+    n = max(4, H * W // 900)
+    gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+    act_o = np.zeros((H, W), bool); sel_o = np.zeros((H, W), bool); am_o = np.full((H, W), 255, np.int64)
+    _, _, _, _, picks_o = ho.select_pixels_to_label(so.copy(), n, 1, 5, act_o, sel_o, am_o, gt, True)
+    for mode in ("gram", "exact"):
+        act = torch.zeros((1, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+        picks, npk = acquire_batch_lowres(lg, em, (H, W), t(gt, dev)[None], act, sel, am, unc_type="entropy", pur_type="radius",
+                                          normalize=True, n_regions=n, active_radius=1, mask_radius=5, lowres_mode=mode)
+        k = int(npk[0])
+        assert k == len(picks_o) > 0 and np.array_equal(picks[0, :k, :2].cpu().numpy(), picks_o[:, :2]), mode
+        assert np.array_equal(act[0].cpu().numpy(), act_o) and np.array_equal(am[0].cpu().numpy(), am_o), mode
+        if mode == "exact":
+            assert bits_equal(picks[0, :k].cpu().numpy(), picks_o)
+
+
+@pytest.mark.parametrize("C,hf,wf,H,W", [(42, 10, 20, 64, 128), (21, 10, 20, 64, 128), (28, 16, 32, 64, 128), (14, 16, 32, 64, 128),
+                                          (20, 22, 44, 64, 128), (10, 22, 44, 64, 128), (63, 160, 320, 1024, 2048)])
+def test_lowres_exact_mode_with_whole_channel_chunks(dev, C, hf, wf, H, W):
+    """k_feat_reduce_lr_dmaf stages CCF channels per LDS image (21 / 14 / 10 for its 6x8, 7x10, 8x12 window geometries)
+    and CCF * window < the DMA units of a wave, so the trailing units used to load channel c0 + CCF -- one plane past the image
+    when C is a multiple of CCF, past the TENSOR for the last image of the batch.  They now re-load the chunk's last channel.
+    Whole-chunk channel counts at x6.4 / x4 / x2.9, the embedding allocated exactly (no slack behind the last image), results
+    bit-identical to upsample-then-score and, for the small ones, to the oracle."""
+    from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
+    from halo_amd.core.utils.hyperbolic import bilinear_align_corners
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(C * 7 + hf)
+    B = 2 if H * W < 100000 else 1
+    emb_lr = ho.expmap((rng.standard_normal((B, C, hf, wf)) * 0.2).astype(np.float32), 1.0, dim=1)
+    logit_lr = rng.standard_normal((B, 19, hf, wf)).astype(np.float32)
+    lg, em = t(logit_lr, dev), t(emb_lr, dev)
+    a = score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, ksize=3, mode="exact")
+    b = score_maps(bilinear_align_corners(lg, (H, W)), bilinear_align_corners(em, (H, W)), "entropy", "radius", True, None, size=3)
+    for x, y in zip(a, b):
+        assert bits_equal(x.cpu().numpy(), y.cpu().numpy())
+    if H * W < 100000:
+        so, io, uo = ho.floating_region_score(ho.bilinear(logit_lr[-1:], (H, W)), ho.bilinear(emb_lr[-1:], (H, W)), "entropy", "radius",
+                                              True, None, size=3, purity_type="radius")
+        assert bits_equal(a[0][-1].cpu().numpy(), so) and bits_equal(a[1][-1].cpu().numpy(), io)
 
 
 def test_lowres_gram_mode_on_degenerate_grids(dev):

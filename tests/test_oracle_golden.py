@@ -104,6 +104,14 @@ def test_hypermapper_lastdim(golden):
         assert max_abs_diff(ho.dist0(d[t + "__expmap"], c), d[t + "__dist0"]) < 1e-12
         # near the ball boundary artanh amplifies rounding by 1/(1-z^2) ~ 1e7
         assert max_abs_diff(ho.dist(d[t + "__expmap"], d[t + "__y_h"], c), d[t + "__dist"]) < 1e-8
+        # float32 points (round 4: artanh's logs in the input dtype, as geoopt's stereographic/math.py): the rounding of 1 +- z
+        # to float32 is shared with the reference; what differs is torch's float32 log against the oracle's recipe (<= 1 ulp of
+        # each log value) and, at the clamp, 1 / (1 - z^2) ~ 4e6 times one ulp of the float32 norm
+        got, want = ho.dist0(d[t + "__x_f32"], c), d[t + "__dist0_f32"]
+        assert got.dtype == np.float32 and want.dtype == np.float32
+        z = np.minimum(np.linalg.norm(d[t + "__x_f32"].astype(np.float64), axis=1) * np.sqrt(c), 1 - 2.0 ** -23)
+        tol = 4e-7 + 3 * 6e-8 / (1 - z * z) / np.sqrt(c)
+        assert np.all(np.abs(got.astype(np.float64) - want) <= tol), float(np.abs(got.astype(np.float64) - want).max())
 
 
 @pytest.mark.parametrize("lowres_mode", ["exact", "gram"])
@@ -178,3 +186,40 @@ def test_gram_radius_tracks_upsample_then_reduce():
         b = ho.floating_region_score(lg, None, "entropy", pur, True, None, size=3, purity_type=pur, K=20,
                                      impurity_raw=ho.gram_radius(emb, (64, 128)))
         assert np.mean(a[1] != b[1]) < 0.01            # a radius on a bin edge may land in the neighbouring bin
+
+
+@pytest.mark.parametrize("shape", [(16, 12, 20, 48, 80), (256, 12, 20, 45, 77), (7, 9, 9, 64, 64), (64, 16, 32, 64, 128)])
+def test_gram_radius_is_guarded_against_cancellation(shape):
+    """neighbouring low-res vectors v and -v (1 - eps), eps 1e-1 .. 1e-12, and opposing vectors on the ball's
+    boundary.  Unguarded, the 10-term Gram form loses the squared norm of the interpolated vector to ~1e-16 max||v||^2 (a norm
+    error up to 1e-8 where the true norm is near zero).  Guarded (a pixel whose terms cancel below 2^-10 of their magnitudes is
+    evaluated in the exact order, oracle/halo_oracle.c:halo_o_gram_radius = k_radius_gram): against the EXACT order
+    (ho.bilinear, then the norm) the NORM tanh(r / 2) agrees to 6.5e-11 relative by construction (squared norm: 4 C u 2^10 =
+    1.2e-10 at C = 256) -- asserted here at 1e-11, observed 2e-13 -- and the selection made from either map is the same."""
+    from conftest import opposing_neighbours_embedding
+    C, h, w, H, W = shape
+    emb = opposing_neighbours_embedding(C, h, w, seed=C)
+    up = ho.bilinear(emb, (H, W))
+    r_exact = ho.dist0(up, 1.0, dim=1)[0]
+    r_gram = ho.gram_radius(emb[0], (H, W), "radius", 1.0)
+    n_exact, n_gram = np.tanh(r_exact / 2), np.tanh(r_gram / 2)
+    assert n_exact.min() < 1e-3 and n_exact.max() > 0.999                  # near-vanishing AND boundary pixels are present
+    rel = np.abs(n_gram - n_exact) / np.maximum(n_exact, 1e-300)
+    assert rel.max() <= 1e-11, rel.max()
+    assert (r_gram == r_exact).mean() > 0.3                                # the guarded pixels ARE the exact order, bit for bit
+    e_exact = np.sqrt((up[0] ** 2).sum(0))
+    e_gram = ho.gram_radius(emb[0], (H, W), "euc_norm", 1.0)
+    assert np.max(np.abs(e_gram - e_exact) / np.maximum(e_exact, 1e-300)) <= 1e-11
+    # the driver on such an image: same files / picks in both modes
+    rng = np.random.default_rng(5)
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1,
+                                     MASK_RADIUS_K=5, BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100))
+    im = dict(logit_lr=rng.standard_normal((1, 19, h, w)).astype(np.float32), embed_lr=emb,
+              origin_label=rng.integers(0, 19, (H, W)).astype(np.int64), origin_mask=np.full((H, W), 255, np.int64),
+              active=np.zeros((H, W), bool), selected=np.zeros((H, W), bool))
+    (m_e, a_e, s_e, p_e), = ho.region_selection(cfg, [dict(im)], lowres_mode="exact")
+    (m_g, a_g, s_g, p_g), = ho.region_selection(cfg, [dict(im)], lowres_mode="gram")
+    assert len(p_e) > 0 and np.array_equal(p_e[:, :2], p_g[:, :2]) and np.array_equal(m_e, m_g) and np.array_equal(a_e, a_g)
+    assert np.max(np.abs(p_e[:, 2] - p_g[:, 2])) <= 1e-10
