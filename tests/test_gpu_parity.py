@@ -830,6 +830,7 @@ def test_selection_with_the_scorers_range_records(dev):
         wild = base.clone()
         m = t(rng.random((2, H, W)) < 0.15, dev)
         wild[m] = wild[m] * (1 + 2 * spread) - spread                  # into [-spread, 1 + spread]
+        wild[:, 3, 5], wild[:, H - 2, W - 7], wild[:, 7, 1] = -spread, 1 + spread, -0.0
         outs = []
         for r_ in (None, rec):
             s2 = wild.clone()
