@@ -49,6 +49,7 @@ def release_workspaces():
     through the caching allocator's stream ordering, so this is safe while kernels are still running."""
     from .core.active import build, floating_region
     floating_region._WS.clear()
-    for slot_list in build._SIDE.values():
+    for slot_list in list(build._SIDE.values()) + list(build._SLOTS.values()):
         del slot_list[:]
     build._SIDE.clear()
+    build._SLOTS.clear()

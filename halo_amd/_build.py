@@ -16,6 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libhalo_hip.so")
 SOURCES = ["halo_api.hip", "halo_score.hip", "halo_select.hip", "halo_select_binned.hip", "halo_hyperbolic.hip", "halo_loss.hip", "halo_pool.hip"]
+HOST_SO = os.path.join(CSRC, "libhalo_host.so")          # plain C host helpers (PNG writer of the persistence step), built with gcc
+HOST_SOURCES = ["halo_host.c"]
 HEADERS = ["halo_common.hpp", "halo_devmath.hpp", "halo_select_common.hpp", "halo_select_plan.hpp", os.path.join("..", "..", "include", "halo_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
@@ -38,6 +40,36 @@ def is_stale():
     t = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def host_is_stale():
+    if not os.path.exists(HOST_SO):
+        return True
+    t = os.path.getmtime(HOST_SO)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in HOST_SOURCES)
+
+
+def build_host(force=False):
+    """libhalo_host.so: the CPU-side helpers (no HIP), compiled with the system C compiler."""
+    if not force and not host_is_stale():
+        return HOST_SO
+    import fcntl
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    with open(os.path.join(CSRC, "build", ".lock_host"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not host_is_stale():
+                return HOST_SO
+            cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc") or _hipcc()
+            tmp = HOST_SO + ".tmp.%d" % os.getpid()
+            cmd = [cc, "-O3", "-std=c11", "-fPIC", "-shared", "-Wall"] + [os.path.join(CSRC, f) for f in HOST_SOURCES] + ["-o", tmp]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("host library build failed:\n%s" % r.stdout)
+            os.replace(tmp, HOST_SO)
+            return HOST_SO
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def build(force=False, verbose=False):
@@ -87,3 +119,4 @@ def _build_locked(verbose):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv))

@@ -162,30 +162,59 @@ class AcquisitionParams:
 
 
 class _InFlight:
-    """One image whose staging, scoring, selection and device->host copies have been enqueued on a side stream."""
-    __slots__ = ("done", "path_mask", "path_indicator", "keep", "picks", "npk", "h_mask", "h_active", "h_selected", "slot")
+    """One loader batch (b images of one label size, b = 1 in the reference) whose staging, scoring, selection and device->host
+    copies have been enqueued on a side stream."""
+    __slots__ = ("done", "keep", "picks", "npk", "slot", "buf", "b", "left", "lock")
+
+
+class _SlotBuffers:
+    """Staging memory of one pipeline slot for b images of H x W labels, allocated once and reused by every batch of that shape
+    that passes through the slot (pinning host pages costs milliseconds; per-image device allocations cost allocator traffic on
+    the launching thread): device masks, pinned outputs, and pinned uint8 inputs for the optional narrow staging."""
+
+    def __init__(self, b, H, W, dev):
+        shp = (b, H, W)
+        self.shape, self.dev = shp, dev
+        self.in_mask = self.in_gt = self.d_u8 = None              # narrow staging only (narrow_inputs())
+        self.d_amask = torch.empty(shp, dtype=torch.int64, device=dev)
+        self.d_gt = torch.empty(shp, dtype=torch.int64, device=dev)
+        self.d_active = torch.empty(shp, dtype=torch.bool, device=dev)
+        self.d_selected = torch.empty(shp, dtype=torch.bool, device=dev)
+        self.d_mask8 = torch.empty(shp, dtype=torch.uint8, device=dev)
+        self.out_mask = torch.empty(shp, dtype=torch.uint8, pin_memory=True)
+        self.out_active = torch.empty(shp, dtype=torch.bool, pin_memory=True)
+        self.out_selected = torch.empty(shp, dtype=torch.bool, pin_memory=True)
+        self.out_npk = torch.empty((b,), dtype=torch.int32, pin_memory=True)
+
+    def narrow_inputs(self):
+        if self.in_mask is None:
+            self.in_mask = torch.empty(self.shape, dtype=torch.uint8, pin_memory=True)     # the loader's masks, low byte
+            self.in_gt = torch.empty(self.shape, dtype=torch.uint8, pin_memory=True)
+            self.d_u8 = torch.empty((2,) + self.shape, dtype=torch.uint8, device=self.dev)
+        return self.in_mask, self.in_gt, self.d_u8
 
 
 class _Slot:
-    """One pipeline slot: a side stream position plus its own pinned device->host staging buffers, allocated once
-    per image shape and reused for every image that passes through the slot (pinning host pages costs
-    milliseconds; the caching host allocator gives no guarantee to hand the same block back in time)."""
+    """One pipeline slot: a side stream position plus its staging buffers per batch shape (at most four shapes are kept: a pool
+    of mixed label sizes re-allocates, a uniform one -- Cityscapes -- never does)."""
 
     def __init__(self, stream):
         self.stream = stream
-        self.shape = None
-        self.mask = self.active = self.selected = None
+        self.bufs = {}
 
-    def buffers(self, shape):
-        if self.shape != tuple(shape):
-            self.mask = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
-            self.active = torch.empty(shape, dtype=torch.bool, pin_memory=True)
-            self.selected = torch.empty(shape, dtype=torch.bool, pin_memory=True)
-            self.shape = tuple(shape)
-        return self.mask, self.active, self.selected
+    def buffers(self, b, H, W, dev):
+        key = (int(b), int(H), int(W))
+        buf = self.bufs.pop(key, None)
+        if buf is None:
+            if len(self.bufs) >= 4:
+                self.bufs.pop(next(iter(self.bufs)))
+            buf = _SlotBuffers(key[0], key[1], key[2], dev)
+        self.bufs[key] = buf                                     # most recently used last
+        return buf
 
 
 _SIDE = {}
+_SLOTS = {}
 _QUEUE_WARNED = False
 
 
@@ -213,39 +242,84 @@ def _side_streams(dev, n):
     return have[:n]
 
 
-def _launch_one(prm, logit_lr, embed_lr, size, origin_mask, origin_label, active_cpu, selected_cpu, dev, slot, lowres_mode=None):
-    """Enqueue one image of the pool (build.py:113-166) on `stream`: stage its masks, score -> mask -> select,
-    copy the results back into pinned host buffers.  Fully asynchronous: `rec.done` fires when the host
-    buffers hold the image's final mask / indicator maps."""
+def _low_byte_into(dst_pinned, src):
+    """dst (uint8, pinned) <- the low byte of every element of the loader's integer mask `src` (CPU tensor, any integer dtype):
+    what the reference's uint8 PNG keeps of it anyway (to_np_array, build.py:67-68,162: numpy's int64 -> uint8 cast wraps modulo
+    256).  numpy on purpose: the conversion releases the GIL and wakes no intra-op thread pool (a torch CPU op here starts a
+    pool as wide as the host, which a cgroup quota then throttles)."""
+    np.copyto(dst_pinned.numpy(), src.numpy(), casting="unsafe")
+
+
+def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in, selected_in, dev, slot, lowres_mode=None, stats=None,
+            narrow_masks=False):
+    """Enqueue b images of one label size (build.py:113-166 for each) on the slot's stream: stage their masks, score -> mask ->
+    select as ONE batch, copy the results back into the slot's pinned buffers.  Fully asynchronous: `rec.done` fires when the
+    pinned buffers hold the final mask / indicator maps of all b images.
+
+    Staging: the loader hands `origin_mask` / `origin_label` as int64, 16.8 MB each per 1024x2048 image.  They
+    are copied straight from the loader's (pinned) tensors into the slot's persistent device buffers: 37.7 MB and 0.69 ms of
+    DMA per image, no CPU work, no allocation.  `narrow_masks=True` instead sends their low bytes (all that can reach the files
+    the round writes: the reference casts the final mask to uint8, build.py:67-68,162, and the selection copies labels into it
+    unchanged, build.py:58-62; the label map keeps its width when the scorer itself reads it: oracle_acc / oracle_ripu)
+    through pinned uint8 buffers and widens them on the device -- 8.4 MB over PCIe, but the narrowing costs the launching thread
+    0.5-0.7 ms per mask (a cold 16.8 MB read at one core's DRAM rate) and measured SLOWER end to end
+    (profiles/r04_region_selection_timing.txt); it is for hosts whose PCIe link is the scarcer resource."""
+    import time
     rec = _InFlight()
-    rec.slot = slot
+    rec.slot, rec.b = slot, int(origin_mask.shape[0])
+    H, W = int(origin_mask.shape[-2]), int(origin_mask.shape[-1])
+    buf = rec.buf = slot.buffers(rec.b, H, W, dev)
     stream = slot.stream
+    t0 = time.perf_counter()
+    scorer_reads_gt = prm.unc == "oracle_acc" or prm.pur == "oracle_ripu"
+    narrow_mask = narrow_masks and (not origin_mask.is_cuda) and origin_mask.dtype != torch.uint8 and not origin_mask.dtype.is_floating_point
+    narrow_gt = narrow_masks and (not origin_label.is_cuda) and origin_label.dtype != torch.uint8 \
+        and not origin_label.dtype.is_floating_point and not scorer_reads_gt
+    if narrow_mask or narrow_gt:
+        in_mask, in_gt, d_u8 = buf.narrow_inputs()
+        if narrow_mask:
+            _low_byte_into(in_mask, origin_mask)
+        if narrow_gt:
+            _low_byte_into(in_gt, origin_label)
+    t1 = time.perf_counter()
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))             # the head outputs are complete from here on
     with torch.cuda.stream(stream):
         stream.wait_event(ready)
-        amask = origin_mask.to(dev, non_blocking=True).long().contiguous()
-        gt = origin_label.to(dev, non_blocking=True).long().contiguous()
-        active = active_cpu.to(dev, non_blocking=True).bool().contiguous()
-        selected = selected_cpu.to(dev, non_blocking=True).bool().contiguous()
+        if narrow_mask:
+            d_u8[0].copy_(in_mask, non_blocking=True)
+            buf.d_amask.copy_(d_u8[0])                       # widen on the device
+        else:
+            buf.d_amask.copy_(origin_mask, non_blocking=True)
+        if narrow_gt:
+            d_u8[1].copy_(in_gt, non_blocking=True)
+            buf.d_gt.copy_(d_u8[1])
+        else:
+            buf.d_gt.copy_(origin_label, non_blocking=True)
+        buf.d_active.copy_(active_in, non_blocking=True)
+        buf.d_selected.copy_(selected_in, non_blocking=True)
         # the two F.interpolate(align_corners=True) calls of build.py:122-135 are fused into the scorer:
         # the C x H x W float64 embedding (4.3 GB at C=256) is never written or read
         rec.picks, rec.npk = acquire_batch_lowres(
-                             logit_lr, embed_lr, size, gt[None], active[None], selected[None], amask[None],
+                             logits_lr, embed_lr, size, buf.d_gt, buf.d_active, buf.d_selected, buf.d_amask,
                              unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
                              n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
                              mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
                              K=prm.K, c=prm.scorer.mapper.c, lowres_mode=lowres_mode)
         # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
         # reference's cast-after-copy, build.py:67-68,162)
-        rec.h_mask, rec.h_active, rec.h_selected = slot.buffers(amask.shape)
-        rec.h_mask.copy_(amask.to(torch.uint8), non_blocking=True)
-        rec.h_active.copy_(active, non_blocking=True)
-        rec.h_selected.copy_(selected, non_blocking=True)
-        rec.done = torch.cuda.Event(blocking=True)           # the writer thread sleeps on it instead of spinning
+        buf.d_mask8.copy_(buf.d_amask)
+        buf.out_mask.copy_(buf.d_mask8, non_blocking=True)
+        buf.out_active.copy_(buf.d_active, non_blocking=True)
+        buf.out_selected.copy_(buf.d_selected, non_blocking=True)
+        buf.out_npk.copy_(rec.npk, non_blocking=True)       # (a .item() in the writer thread would queue behind the backbone's kernels)
+        rec.done = torch.cuda.Event(blocking=True)           # the writer threads sleep on it instead of spinning
         rec.done.record(stream)
-    # device tensors the side stream still reads: kept alive until the image is retired
-    rec.keep = (logit_lr, embed_lr, gt, amask, active, selected)
+    # what the side stream still reads: the head outputs and the loader's (pinned) tensors, kept alive until the batch is retired
+    rec.keep = (logits_lr, embed_lr, origin_mask, origin_label, active_in, selected_in)
+    if stats is not None:
+        stats["main_stage_s"] += t1 - t0
+        stats["main_launch_s"] += time.perf_counter() - t1
     return rec
 
 
@@ -256,76 +330,132 @@ def _png_chunk(tag, data):
     return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
 
 
-def write_png_gray8(path, arr):
-    """8-bit greyscale (PIL mode "L") PNG of a (H, W) uint8 array: the file `Image.fromarray(a).save(path)` of
-    build.py:163-164 produces, pixel for pixel, written directly -- filter type 0 on every row and ONE zlib stream
-    with the run-length strategy (masks are long runs of 255 with small labelled windows; zlib releases the GIL, so
-    writer threads run in parallel).  PIL spends ~12 ms per 1024x2048 mask in its row-by-row encoder; this takes
-    about half and decodes to the identical image."""
+def _write_png_gray8_zlib(path, arr):
+    """The pure-Python statement of write_png_gray8 (round 2-3): filter type 0 on every row and ONE zlib stream with the
+    run-length strategy.  ~3-4.5 ms per 1024x2048 mask; kept as the A/B twin of the native encoder (HALO_PNG_ZLIB=1) and for
+    hosts without a C compiler."""
     h, w = arr.shape
     rows = np.empty((h, w + 1), dtype=np.uint8)
     rows[:, 0] = 0                                                   # filter type "None" per scanline
     rows[:, 1:] = arr
     ihdr = struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)              # bit depth 8, colour type 0 (greyscale), no interlace
     z = zlib.compressobj(1, zlib.DEFLATED, 15, 9, zlib.Z_RLE)
-    idat = z.compress(rows.tobytes()) + z.flush()
+    idat = z.compress(rows) + z.flush()
     with open(path, "wb") as f:
         f.write(_PNG_SIGNATURE + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"IDAT", idat) + _png_chunk(b"IEND", b""))
 
 
-def _persist(mask_np, active, selected, path_mask, path_indicator):
+_NATIVE_PNG = None
+
+
+def write_png_gray8(path, arr):
+    """8-bit greyscale (PIL mode "L") PNG of a (H, W) uint8 array: the file `Image.fromarray(a).save(path)` of
+    build.py:163-164 produces, pixel for pixel, written by the native run-length encoder of halo_amd/csrc/halo_host.c (one
+    fixed-Huffman deflate block, runs found 8 bytes at a time: ~0.4 ms per 1024x2048 acquisition mask where PIL's encoder takes
+    ~12 ms and zlib's run-length strategy 3-4.5 ms; the call releases the GIL, so writer threads run in parallel).  Decodes to
+    the identical image."""
+    global _NATIVE_PNG
+    if _NATIVE_PNG is None:
+        try:
+            from ... import _hostlib
+            _hostlib.lib()
+            _NATIVE_PNG = _hostlib.png_gray8_write
+        except Exception as exc:                                      # no C compiler and no prebuilt library: the zlib twin
+            import warnings
+            warnings.warn("halo_amd: libhalo_host.so unavailable (%s); PNG masks go through zlib" % exc, RuntimeWarning)
+            _NATIVE_PNG = False
+    if _NATIVE_PNG and not os.environ.get("HALO_PNG_ZLIB"):
+        if arr.strides[1] != 1 or arr.strides[0] < arr.shape[1]:
+            arr = np.ascontiguousarray(arr)
+        _NATIVE_PNG(path, arr)
+    else:
+        _write_png_gray8_zlib(path, arr)
+
+
+def _persist(mask_np, active, selected, path_mask, path_indicator, stats=None):
     """build.py:162-166: uint8 mode-L PNG + torch.save'd indicator dict (what cityscapes.py:234-251 reads back)."""
+    import time
+    t0 = time.perf_counter()
     if mask_np.ndim == 2 and mask_np.dtype == np.uint8 and mask_np.size and str(path_mask).lower().endswith(".png"):
         write_png_gray8(path_mask, mask_np)
     else:
         Image.fromarray(mask_np).save(path_mask)
+    t1 = time.perf_counter()
     torch.save({"active": active, "selected": selected}, path_indicator)
+    if stats is not None:
+        with stats["lock"]:
+            stats["writer_png_s"] += t1 - t0
+            stats["writer_save_s"] += time.perf_counter() - t1
 
 
-def _finish(rec, slots, backlog):
-    """Writer-thread half of one image: wait for its copies, hand its pipeline slot back, write the two files."""
-    try:
-        return _finish_inner(rec, slots)
-    finally:
-        backlog.release()
-
-
-def _finish_inner(rec, slots):
+def _finish(rec, i, paths, slots, stats=None):
+    """Writer-thread half of image i of a batch: wait for the batch's copies, encode the mask straight out of the slot's pinned
+    buffer, take the two indicator maps out of theirs (the slot goes back when the last image of the batch has been taken),
+    write the indicator."""
+    import time
+    t0 = time.perf_counter()
     try:
         rec.done.synchronize()
-        # ONE streaming copy out of the pinned staging buffers first (the slot is then free for the next image; the
-        # encoders make several passes over their input, and the indicator must hold plain tensors as from `.cpu()`).
-        # numpy copies on purpose: a torch CPU op here would wake an intra-op thread pool as wide as the host
-        mask = rec.h_mask.numpy().copy()
-        active, selected = torch.from_numpy(rec.h_active.numpy().copy()), torch.from_numpy(rec.h_selected.numpy().copy())
-        out = (rec.picks[0], int(rec.npk[0]))
-        rec.keep = rec.h_mask = rec.h_active = rec.h_selected = None
+        t1 = time.perf_counter()
+        buf = rec.buf
+        # the PNG encoder makes ONE pass over the mask: it reads the pinned buffer directly.  The indicator must hold plain
+        # tensors as from `.cpu()`: one streaming copy each (numpy on purpose: a torch CPU op here would wake an intra-op
+        # thread pool as wide as the host)
+        mask = buf.out_mask[i].numpy()
+        direct = mask.size and str(paths[0]).lower().endswith(".png")
+        if direct:
+            write_png_gray8(paths[0], mask)
+        else:
+            mask = mask.copy()
+        t2 = time.perf_counter()
+        active, selected = torch.from_numpy(buf.out_active[i].numpy().copy()), torch.from_numpy(buf.out_selected[i].numpy().copy())
+        out = (rec.picks[i], int(buf.out_npk[i]))
     finally:
-        slots.put(rec.slot)
-    _persist(mask, active, selected, rec.path_mask, rec.path_indicator)
+        with rec.lock:
+            rec.left -= 1
+            last = rec.left == 0
+        if last:
+            rec.keep = rec.buf = None
+            slots.put(rec.slot)
+    t3 = time.perf_counter()
+    if not direct:
+        Image.fromarray(mask).save(paths[0])
+    t4 = time.perf_counter()
+    torch.save({"active": active, "selected": selected}, paths[1])
+    if stats is not None:
+        with stats["lock"]:
+            stats["writer_event_wait_s"] += t1 - t0
+            stats["writer_png_s"] += (t2 - t1) + (t4 - t3)
+            stats["writer_copy_s"] += t3 - t2
+            stats["writer_save_s"] += time.perf_counter() - t4
     return out
 
 
 def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=8, writer_threads=None,
-                    streams=4, return_tables=False, lowres_mode=None):
+                    streams=4, return_tables=False, lowres_mode=None, stats=None, narrow_masks=False):
     """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
     at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
     every file on disk when the call returns.  Returns None like the reference, or -- keyword-only
     `return_tables=True`, used by halo_amd.pool.region_selection_sharded -- the per-image pick tables
     [(picks (n,3) float64 rows (h, w, score), count)] in loader order.
 
-    Inside the images of the pool are independent, so image i's host->device staging,
-    score + selection and device->host copies are enqueued on one of `streams` side streams (round
-    robin) while the backbone processes image i+1 on the caller's stream; the host thread never waits
-    for the GPU: a pool of writer threads waits for each image's event, encodes the PNG and writes the
-    indicator.  At most `in_flight` images are between "launched" and "copied back to the host" (bounds device
-    and pinned memory; each slot owns its pinned staging buffers); `in_flight=0` runs strictly one image at a
-    time like the reference.  `writer_threads` defaults to min(8, usable host cores / LOCAL_WORLD_SIZE).  `lowres_mode`: 'exact' (default; environment HALO_LOWRES) interpolates every channel and is
+    Inside the images of the pool are independent, so a loader batch's host->device staging,
+    score + selection (ONE launch group for the whole batch when its images share a label size; the reference's loader has
+    batch size 1) and device->host copies are enqueued on one of `streams` side streams (round
+    robin) while the backbone processes the next batch on the caller's stream; the host thread never waits
+    for the GPU: a pool of writer threads waits for each batch's event, encodes the PNGs and writes the
+    indicators.  At most `in_flight` batches are between "launched" and "copied back to the host" (bounds device
+    and pinned memory; each slot owns its staging buffers and reuses them from round to round); `in_flight=0` runs strictly
+    one batch at a time like the reference.  `writer_threads` defaults to min(8, usable host cores / LOCAL_WORLD_SIZE).
+    `lowres_mode`: 'exact' (default; environment HALO_LOWRES) interpolates every channel and is
     bit-identical to upsample-then-score, the reference's order; 'gram' (opt-in, float64 embeddings) evaluates the radius through
     per-cell Gram terms (floating_region.score_maps_lowres: bit-identical to its oracle twin, squared norms within 1.3e-10 of
-    the exact order, the reference's files on every test vector -- but not the reference's evaluation order)."""
+    the exact order, the reference's files on every test vector -- but not the reference's evaluation order).
+    `stats`: an optional dict that receives where the host time went (seconds per phase, main thread and writers);
+    `narrow_masks`: see _launch (default False: the loader's int64 masks are DMA'd as they are)."""
     import queue
     import threading
+    import time
     from concurrent.futures import ThreadPoolExecutor
     prm = AcquisitionParams(cfg)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -336,41 +466,70 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     depth = max(1, in_flight)
     side = _side_streams(dev, max(1, min(streams, depth)))
     _check_hw_queues(len(side))
-    backlog = threading.Semaphore(depth + 4 * max(1, writer_threads))   # images whose files are not on disk yet (host copies)
+    # the slots (and their pinned / device staging buffers) live as long as the side streams: the next round reuses them
+    have = _SLOTS.setdefault(dev.index, [])
+    while len(have) < depth:
+        have.append(_Slot(side[len(have) % len(side)]))
     slots = queue.Queue()
     for k in range(depth):
-        slots.put(_Slot(side[k % len(side)]))
+        slots.put(have[k])
+    if stats is not None:
+        for key in ("main_forward_s", "main_stage_s", "main_launch_s", "main_wait_slot_s", "main_loader_s",
+                    "writer_event_wait_s", "writer_copy_s", "writer_png_s", "writer_save_s"):
+            stats[key] = 0.0
+        stats.update(images=0, batches=0, writer_threads=int(writer_threads), in_flight=depth, streams=len(side), lock=threading.Lock())
     feature_extractor.eval()
     classifier.eval()
     moved = False
     pending = []
     with ThreadPoolExecutor(max_workers=max(1, writer_threads)) as writers, torch.no_grad():
         try:
+            t_prev = time.perf_counter()
             for batch in tgt_epoch_loader:
+                t_a = time.perf_counter()
                 images = batch["img"].to(dev, non_blocking=True)
                 if not moved:
                     feature_extractor.to(dev)
                     classifier.to(dev)
                     moved = True
                 logits_lr, embed_lr = classifier(feature_extractor(images), size=images.shape[-2:])
-                for i in range(len(batch["origin_mask"])):          # loader batch size is 1 in the reference
-                    size = (int(batch["size"][i][0]), int(batch["size"][i][1]))
-                    backlog.acquire()
-                    slot = slots.get()                               # blocks only while `in_flight` images hold every slot
+                t_b = time.perf_counter()
+                nb = len(batch["origin_mask"])                      # loader batch size: 1 in the reference
+                sizes = [(int(batch["size"][i][0]), int(batch["size"][i][1])) for i in range(nb)]
+                # images of one label size go through as ONE launch group; otherwise one image at a time
+                groups = [(0, nb)] if all(sz == sizes[0] for sz in sizes) else [(i, i + 1) for i in range(nb)]
+                for lo, hi in groups:
+                    t_d = time.perf_counter()
+                    # blocks only while `in_flight` batches hold every slot (a slot returns when a writer thread has taken its
+                    # batch out of the pinned buffers, so slow writers hold the launches back too: nothing piles up)
+                    slot = slots.get()
+                    t_e = time.perf_counter()
                     try:
-                        rec = _launch_one(prm, logits_lr[i:i + 1], embed_lr[i:i + 1], size, batch["origin_mask"][i],
-                                          batch["origin_label"][i], batch["active"][i], batch["selected"][i], dev, slot,
-                                          lowres_mode)
+                        rec = _launch(prm, logits_lr[lo:hi], embed_lr[lo:hi], sizes[lo], batch["origin_mask"][lo:hi],
+                                      batch["origin_label"][lo:hi], batch["active"][lo:hi], batch["selected"][lo:hi], dev, slot,
+                                      lowres_mode, stats, narrow_masks)
                     except BaseException:
                         slots.put(slot)
-                        backlog.release()
                         raise
-                    rec.path_mask, rec.path_indicator = batch["path_to_mask"][i], batch["path_to_indicator"][i]
-                    pending.append(writers.submit(_finish, rec, slots, backlog))
+                    rec.left, rec.lock = hi - lo, threading.Lock()
+                    for i in range(lo, hi):
+                        pending.append(writers.submit(_finish, rec, i - lo, (batch["path_to_mask"][i], batch["path_to_indicator"][i]),
+                                                      slots, stats))
                     if in_flight <= 0:
-                        pending[-1].result()
+                        for f in pending[-(hi - lo):]:
+                            f.result()
+                    if stats is not None:
+                        stats["main_wait_slot_s"] += t_e - t_d
+                        stats["images"] += hi - lo
+                        stats["batches"] += 1
+                if stats is not None:
+                    stats["main_loader_s"] += t_a - t_prev
+                    stats["main_forward_s"] += t_b - t_a
+                t_prev = time.perf_counter()
         finally:
             results = [f.result() for f in pending]                  # surface I/O errors; all files are on disk
+    if stats is not None:
+        stats.pop("lock", None)
     feature_extractor.train()
     classifier.train()
     return results if return_tables else None

@@ -42,3 +42,25 @@ big = torch.full((1, H, W), 255, dtype=torch.int64).pin_memory()
 print("H2D 16.8MB pinned + sync: %.3f ms" % t(lambda: (big.to(dev, non_blocking=True), torch.cuda.synchronize())))
 big2 = torch.full((1, H, W), 255, dtype=torch.int64)
 print("H2D 16.8MB pageable: %.3f ms" % t(lambda: (big2.to(dev, non_blocking=True), torch.cuda.synchronize())))
+# host-side narrowing of a loader mask (int64 -> its low byte, what the uint8 PNG keeps anyway) into a pinned buffer
+src = torch.randint(0, 256, (H, W), dtype=torch.int64).pin_memory()
+dst = torch.empty((H, W), dtype=torch.uint8, pin_memory=True)
+sn, dn = src.numpy(), dst.numpy()
+print("narrow int64 -> uint8, numpy astype into pinned: %.2f ms" % t(lambda: np.copyto(dn, sn, casting="unsafe")))
+lowbyte = sn.view(np.uint8).reshape(H, W, 8)[:, :, 0]
+print("narrow int64 -> uint8, low-byte strided view copy: %.2f ms" % t(lambda: np.copyto(dn, lowbyte)))
+print("narrow int64 -> uint8, torch .to(uint8) copy_: %.2f ms" % t(lambda: dst.copy_(src)))
+import threading
+for nt in (2, 4, 8):
+    srcs = [src.clone().pin_memory() for _ in range(nt)]; dsts = [torch.empty((H, W), dtype=torch.uint8, pin_memory=True) for _ in range(nt)]
+    def work(k):
+        for _ in range(10):
+            np.copyto(dsts[k].numpy(), srcs[k].numpy(), casting="unsafe")
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(nt)]
+    [x.start() for x in th]; [x.join() for x in th]
+    print("  %d threads narrowing concurrently: %.2f ms per mask per thread" % (nt, (time.perf_counter() - t0) / 10 * 1e3))
+d64 = torch.empty((H, W), dtype=torch.int64, device=dev)
+print("H2D 16.8MB pinned into an EXISTING device tensor + sync: %.3f ms" % t(lambda: (d64.copy_(src, non_blocking=True), torch.cuda.synchronize())))
+d8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
+print("H2D 2MB pinned uint8 + widen on device + sync: %.3f ms" % t(lambda: (d8.copy_(dst, non_blocking=True), d64.copy_(d8), torch.cuda.synchronize())))

@@ -1,7 +1,7 @@
 """Timing aid: the RegionSelection driver end to end (staging, fused resize+score, greedy selection, PNG +
 indicator files) on full-size synthetic pool images, serial vs pipelined (one MI355X).  The backbone is a
 stand-in that only sleeps on the GPU for a configurable time, so the number isolates the acquisition side."""
-import os, sys, tempfile, time, types
+import os, shutil, sys, tempfile, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
@@ -9,7 +9,7 @@ from halo_amd.core.active.build import RegionSelection
 from halo_amd.core.utils.hyperbolic import HyperMapper
 
 dev = torch.device("cuda:0")
-N, H, W, C, O = 48, 1024, 2048, 64, 19
+N, H, W, C, O = int(os.environ.get('HALO_RS_IMAGES', '96')), 1024, 2048, 64, 19
 cfg = types.SimpleNamespace(
     MODEL=types.SimpleNamespace(NUM_CLASSES=O, HYPER=True, CURVATURE=1.0),
     ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
@@ -31,6 +31,7 @@ class Head(torch.nn.Module):
         self.a = torch.randn((4096, 4096), device=dev)
 
     def forward(self, x, size=None):
+        nb = x.shape[0]
         if self.busy_ms > 0:                                          # stand-in for the backbone forward:
             if MODE == "sleep":                                       #   a spin kernel on one CU (GPU mostly idle)
                 torch.cuda._sleep(int(self.busy_ms * 1e-3 * 2.1e9))
@@ -38,7 +39,7 @@ class Head(torch.nn.Module):
                 for _ in range(int(self.busy_ms / GEMM_MS)):
                     self.a @ self.a
             torch.cuda.current_stream().synchronize()
-        return logit, emb
+        return (logit, emb) if nb == 1 else (logit.expand(nb, -1, -1, -1).contiguous(), emb.expand(nb, -1, -1, -1).contiguous())
 
 
 def pool(tmp):
@@ -57,14 +58,38 @@ for _ in range(20):
     a_ @ a_
 torch.cuda.synchronize(); GEMM_MS = (time.perf_counter() - t0) / 20 * 1e3
 print(f"4096^3 f32 GEMM: {GEMM_MS:.2f} ms")
+def fmt(st):
+    n = max(1, st["images"])
+    main = "  ".join("%s %.2f" % (k[5:-2], st[k] / n * 1e3) for k in ("main_loader_s", "main_forward_s", "main_stage_s", "main_launch_s", "main_wait_slot_s"))
+    wr = "  ".join("%s %.2f" % (k[7:-2], st[k] / n * 1e3) for k in ("writer_event_wait_s", "writer_copy_s", "writer_png_s", "writer_save_s"))
+    return "      per image, main thread [ms]: %s | writer threads (%d) [ms, summed over threads]: %s" % (main, st["writer_threads"], wr)
+
+
+def batched(items, nb):
+    """the same pool through a loader of batch size nb (default collate: tensors concatenated, lists extended)"""
+    out = []
+    for k in range(0, len(items), nb):
+        grp = items[k:k + nb]
+        out.append({key: (torch.cat([g_[key] for g_ in grp]).pin_memory() if torch.is_tensor(grp[0][key]) else sum((g_[key] for g_ in grp), []))
+                    for key in grp[0]})
+    return out
+
+
+NARROW = bool(int(os.environ.get("HALO_RS_NARROW", "0")))
 for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
-    for (infl, wr, tag) in ((0, 1, "serial (in_flight=0, 1 writer)"), (8, 8, "pipelined (in_flight=8, 4 streams, 8 writers)"),
-                            (16, 16, "pipelined (in_flight=16, 4 streams, 16 writers)")):
+    for (infl, wr, nb, tag) in ((0, 1, 1, "serial (in_flight=0, 1 writer)"), (8, 8, 1, "pipelined (in_flight=8, 4 streams, 8 writers)"),
+                                (8, 12, 1, "pipelined (in_flight=8, 4 streams, 12 writers)"), (8, None, 1, "pipelined (defaults)"),
+                                (8, None, 2, "pipelined (defaults), loader batch 2"), (8, None, 4, "pipelined (defaults), loader batch 4")):
+        if MODE != "none" and (wr == 12 or nb > 1):
+            continue
         tmp = tempfile.mkdtemp(prefix="halo_rs_t_")
-        items = pool(tmp)
-        RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, in_flight=infl, writer_threads=wr)
+        items = batched(pool(tmp), nb) if nb > 1 else pool(tmp)
+        RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, in_flight=infl, writer_threads=wr, narrow_masks=NARROW)
         torch.cuda.synchronize()
+        st = {}
         t0 = time.perf_counter()
-        RegionSelection(cfg, Ident(), Head(busy), items, 1, in_flight=infl, writer_threads=wr)
+        RegionSelection(cfg, Ident(), Head(busy), items, 1, in_flight=infl, writer_threads=wr, stats=st, narrow_masks=NARROW)
         dt = time.perf_counter() - t0
-        print(f"backbone stand-in {MODE:5s} {busy:4.0f} ms: {tag:48s} {dt / N * 1e3:7.1f} ms/image  ({N / dt:6.1f} images/s)")
+        print(f"backbone stand-in {MODE:5s} {busy:4.0f} ms: {tag:48s} {dt / N * 1e3:7.2f} ms/image  ({N / dt:6.1f} images/s)")
+        print(fmt(st), flush=True)
+        shutil.rmtree(tmp, ignore_errors=True)

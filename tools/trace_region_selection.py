@@ -17,17 +17,18 @@ emb = HyperMapper(1.0).expmap(torch.randn((1, C, 160, 320), generator=g, device=
 logit = torch.nn.functional.interpolate(torch.randn((1, O, 160, 320), generator=g, device=dev), size=(640, 1280), mode="bilinear", align_corners=True)
 prm = B.AcquisitionParams(cfg)
 tmp = tempfile.mkdtemp()
-gt = torch.randint(0, O, (H, W)).pin_memory()
-om = torch.full((H, W), 255, dtype=torch.int64).pin_memory()
-ac = torch.zeros(H, W, dtype=torch.bool).pin_memory()
-se = torch.zeros(H, W, dtype=torch.bool).pin_memory()
+gt = torch.randint(0, O, (1, H, W)).pin_memory()
+om = torch.full((1, H, W), 255, dtype=torch.int64).pin_memory()
+ac = torch.zeros(1, H, W, dtype=torch.bool).pin_memory()
+se = torch.zeros(1, H, W, dtype=torch.bool).pin_memory()
 slot = B._Slot(torch.cuda.Stream(dev, priority=-1))
 for it in range(30):
     torch.cuda.synchronize()
     t = [time.perf_counter()]
-    rec = B._launch_one(prm, logit, emb, (H, W), om, gt, ac, se, dev, slot); t.append(time.perf_counter())
+    rec = B._launch(prm, logit, emb, (H, W), om, gt, ac, se, dev, slot); t.append(time.perf_counter())
     rec.done.synchronize(); t.append(time.perf_counter())
-    m = rec.h_mask.numpy().copy(); a = rec.h_active.clone(); s = rec.h_selected.clone(); t.append(time.perf_counter())
+    m = rec.buf.out_mask[0].numpy().copy()
+    a = torch.from_numpy(rec.buf.out_active[0].numpy().copy()); s = torch.from_numpy(rec.buf.out_selected[0].numpy().copy()); t.append(time.perf_counter())
     B.write_png_gray8(os.path.join(tmp, "m.png"), m); t.append(time.perf_counter())
     torch.save({"active": a, "selected": s}, os.path.join(tmp, "i.pth")); t.append(time.perf_counter())
     n = int(rec.npk[0]); t.append(time.perf_counter())
