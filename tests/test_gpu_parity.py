@@ -1150,6 +1150,73 @@ def test_region_selection_pipelined_pool_vs_oracle(dev):
         assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
 
 
+@pytest.mark.parametrize("variant", ["loader_batch_3", "narrow_masks", "uint8_loader", "oracle_branch_narrow"])
+def test_region_selection_batched_and_narrow_staging_vs_oracle(dev, variant):
+    """Round 4 host side: a loader batch > 1 goes through as ONE launch group when its images share a label size (and one by
+    one when they do not), the masks may travel as low bytes (narrow_masks=True: the label map keeps its width when the scorer
+    reads it, oracle_acc / oracle_ripu), and a loader that already hands uint8 masks is taken as it is.  Label values above 255
+    are included on purpose: only their low byte can reach the uint8 PNG in the reference either (build.py:67-68).  Every
+    file equals the oracle driver's result."""
+    from PIL import Image
+    from halo_amd.core.active.build import RegionSelection
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(77)
+    oracle_branch = variant == "oracle_branch_narrow"
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="oracle_acc" if oracle_branch else "entropy", PURITY="oracle_ripu" if oracle_branch else "radius",
+                                     NORMALIZE=not oracle_branch, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+    tmp = tempfile.mkdtemp(prefix="halo_rs4_")
+    sizes = [(48, 96)] * 3 + [(64, 80), (48, 96), (64, 80)] + [(40, 120)] * 3            # batches: uniform, mixed, uniform
+    per, outs_lr, oracle_in = [], [], []
+    for i, (H, W) in enumerate(sizes):
+        emb_lr = ho.expmap((rng.standard_normal((1, 8, 10, 20)) * 0.2).astype(np.float32), 1.0, dim=1)
+        logit_lr = rng.standard_normal((1, 19, 30, 50)).astype(np.float32)
+        gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+        gt[rng.random((H, W)) < 0.05] = 255
+        om = np.full((H, W), 255, np.int64)
+        prior = rng.random((H, W)) < 0.01
+        om[prior] = gt[prior]
+        if variant == "narrow_masks":
+            gt[rng.random((H, W)) < 0.02] += 256                       # only the low byte reaches the file (reference: uint8 cast)
+        act = rng.random((H, W)) < 0.02
+        per.append(dict(om=om, gt=gt, act=act, H=H, W=W, emb=emb_lr, lg=logit_lr))
+        oracle_in.append(dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act, selected=np.zeros((H, W), bool), origin_mask=om))
+    nb = 3 if variant in ("loader_batch_3", "narrow_masks", "oracle_branch_narrow") else 1
+    items = []
+    for k in range(0, len(per), nb):
+        grp = per[k:k + nb]
+        Hm, Wm = max(g_["H"] for g_ in grp), max(g_["W"] for g_ in grp)
+        if len({(g_["H"], g_["W"]) for g_ in grp}) > 1:
+            # a mixed-size batch cannot be collated into one tensor by a real loader: hand the driver per-image batches
+            for j, g_ in enumerate(grp):
+                items.append(([k + j], g_["H"], g_["W"]))
+        else:
+            items.append((list(range(k, k + len(grp))), Hm, Wm))
+    mdt = torch.uint8 if variant == "uint8_loader" else torch.int64
+    loader, head_outs = [], []
+    for idxs, H, W in items:
+        loader.append({"img": torch.zeros(len(idxs), 3, 8, 8),
+                       "path_to_mask": [os.path.join(tmp, f"m{i}.png") for i in idxs], "path_to_indicator": [os.path.join(tmp, f"i{i}.pth") for i in idxs],
+                       "origin_mask": torch.from_numpy(np.stack([per[i]["om"] for i in idxs])).to(mdt),
+                       "origin_label": torch.from_numpy(np.stack([per[i]["gt"] for i in idxs])).to(mdt if not oracle_branch else torch.int64),
+                       "size": torch.tensor([[H, W]] * len(idxs)), "active": torch.from_numpy(np.stack([per[i]["act"] for i in idxs])),
+                       "selected": torch.zeros(len(idxs), H, W, dtype=torch.bool), "name": [f"img{i}" for i in idxs]})
+        head_outs.append((t(np.concatenate([per[i]["lg"] for i in idxs]), dev), t(np.concatenate([per[i]["emb"] for i in idxs]), dev)))
+    st = {}
+    RegionSelection(cfg, _Fake(), _Fake(head_outs), loader, 1, in_flight=2, writer_threads=3, stats=st,
+                    narrow_masks=variant in ("narrow_masks", "oracle_branch_narrow"))
+    assert st["images"] == len(sizes) and st["batches"] == len(items) and st["main_launch_s"] > 0
+    want = ho.region_selection(cfg, oracle_in, lowres_mode=_lr_mode())
+    for i, (mask, act, sel, _) in enumerate(want):
+        png = np.array(Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8)
+        ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+        assert np.array_equal(png, mask), (variant, i)
+        assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), (variant, i)
+        assert ind["active"].dtype == torch.bool and int(sel.sum()) > 0
+
+
 def test_head_tail_gradients_match_reference_autograd(golden, dev):
     """d loss / d {feat, P_MLR, A_MLR, embed} of the head tail (classifier.py:553-554) from the HIP backward
     kernels + library GEMMs vs the reference's own autograd (tests/golden/grads.npz), including
