@@ -250,7 +250,7 @@ class Pipeline:
             if self.lowres:
                 lev = None
                 if timed:
-                    lev = tuple(self.lib.halo_event_create() for _ in range(4))
+                    lev = tuple(self.lib.halo_event_create() for _ in range(6))
                     self.ev_lr.append(lev + (b,))
                 sc, self.imp, self.unc_map = score_maps_lowres(lb, fb, self.size, self.unc, self.pur, self.norm, gb, ksize=3,
                                                                K=self.K, c=1.0, active=self.active[k][:b], want_maps=True,
@@ -346,18 +346,26 @@ class Pipeline:
                 self.tables_consistent = False
 
     def lowres_pass_ms(self):
-        """(logit pass ms, embedding pass ms) per full-batch timed step of the low-res source"""
+        """per full-batch timed step of the low-res source: {logit, feat (embedding pass), gram, radius (the two kernels of the gram
+        route; None otherwise), tail} -> list of ms"""
         import ctypes
-        lo, fe = [], []
-        for e0, e1, e2, e3, nimg in self.ev_lr:
-            a, b = ctypes.c_float(0), ctypes.c_float(0)
-            ok = self.lib.halo_event_elapsed_ms(e0, e1, ctypes.byref(a)) == 0 and self.lib.halo_event_elapsed_ms(e2, e3, ctypes.byref(b)) == 0
-            if ok and nimg == self.B:
-                lo.append(a.value); fe.append(b.value)
-            for e in (e0, e1, e2, e3):
+        out = {"logit": [], "feat": [], "gram": [], "radius": [], "tail": []}
+
+        def ms(a, b):
+            v = ctypes.c_float(0)
+            return v.value if self.lib.halo_event_elapsed_ms(a, b, ctypes.byref(v)) == 0 else None
+        for e0, e1, e2, e3, e4, e5, nimg in self.ev_lr:
+            vals = {"logit": ms(e0, e1), "feat": ms(e2, e3), "tail": ms(e3, e5)}
+            if self.lr_mode == "gram" and self.feat.dtype == torch.float64:
+                vals["gram"], vals["radius"] = ms(e2, e4), ms(e4, e3)
+            if nimg == self.B:
+                for k, v in vals.items():
+                    if v is not None:
+                        out[k].append(v)
+            for e in (e0, e1, e2, e3, e4, e5):
                 self.lib.halo_event_destroy(e)
         self.ev_lr = []
-        return lo, fe
+        return out
 
     def feat_kernel_ms(self):
         import ctypes
@@ -579,7 +587,8 @@ def main():
         assert torch.equal(tables[known], ref), "rows gathered from other ranks differ from this rank's results for the same images"
 
     feat_ms = pipe.feat_kernel_ms()
-    lr_logit_ms, lr_feat_ms = pipe.lowres_pass_ms()
+    lr_ms = pipe.lowres_pass_ms()
+    lr_logit_ms, lr_feat_ms = lr_ms["logit"], lr_ms["feat"]
     batch_alone = None
     if rank == 0 and not lowres and feat_ms and os.environ.get("HALO_BENCH_BATCH_ALONE"):
         # diagnostic: the scoring call on each resident batch with nothing beside it, after the timed region
@@ -688,6 +697,31 @@ def main():
                                    "avg_launch_ms": round(t_feat, 4), "launches_timed": len(lr_feat_ms),
                                    "valu_slot_frac": round(ach / peak * 10.0 / 9.0, 4)}
             out["lowres_passes_ms"] = {"logit_pass(k_logit_maps_lr, f32 VALU-bound)": round(t_logit, 4), "embedding_pass": round(t_feat, 4)}
+            # one roofline entry per kernel of the low-res step; `roofline` above stays the embedding pass
+            def entry(kernel, bound, work, t_ms, peak, unit, what):
+                ach = work / (t_ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
+                return {"kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                        "avg_launch_ms": round(t_ms, 4), "work_per_launch": work, "what": what}
+            ks = []
+            if lr_ms["logit"]:
+                # 1331 VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/r03_pmc_lowres.json: 697 M per
+                # 16 images): interpolation 4 + lean softmax / entropy ~66 per class; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops
+                ks.append(entry("k_logit_maps_lr<%d>" % O, "valu", 1331.0 / 19 * O * B * Hh * Ww, float(np.mean(lr_ms["logit"])), 78.6, "T lane-ops/s",
+                                "f32 VALU instruction issue (no flops convention: compares, selects and conversions count)"))
+            if lr_ms["gram"]:
+                ks.append(entry("k_gram_lr2", "hbm", B * (C * h4 * w4 * 8 + 5 * h4 * w4 * 8), float(np.mean(lr_ms["gram"])), HBM_PEAK_GBPS, "GB/s",
+                                "low-res float64 embedding read once + five Gram maps written"))
+                ks.append(entry("k_radius_gram", "valu", 155.0 * B * Hh * Ww, float(np.mean(lr_ms["radius"])), 19.65, "T lane-ops/s",
+                                "float64 VALU issue (16 lanes per clock and SIMD): ~155 instructions per output pixel (taps, 10-term form + "
+                                "guard, sqrt, two logs with a division each); also writes the radius map"))
+            elif lr_ms["feat"] and out["roofline"]:
+                ks.append(dict(out["roofline"]))
+            if lr_ms["tail"]:
+                ssz_ = pipe.score[0].element_size()
+                ks.append(entry("k_box3_minmax + k_minmax_finalize2 + k_combine_box3", "hbm", B * Hh * Ww * (ssz_ + 4 + 4 + 1 + 2 * ssz_ + 4),
+                                float(np.mean(lr_ms["tail"])), HBM_PEAK_GBPS, "GB/s",
+                                "radius + entropy read (entropy twice: min/max pass and combine), active read, three maps written"))
+            out["roofline_kernels"] = ks
         for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if out["roofline"] is None or lowres or not os.path.exists(pmc):

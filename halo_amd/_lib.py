@@ -46,7 +46,7 @@ SIGNATURES = {
     "halo_score_maps_lr_gram": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_score_maps_lr_timed": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
-                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
+                                        _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "halo_region_uncertainty": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "halo_region_impurity": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp]),
     "halo_quantize_radius": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _sz, _vp]),

@@ -169,7 +169,8 @@ def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, 
     CPU oracle's statement of that form (oracle.halo_oracle.gram_radius), 2x faster at C = 256, but NOT the reference's
     order: squared norms agree with the exact order to 1.3e-10 relative (observed < 1e-12; pixels whose Gram terms cancel
     are evaluated in the exact order), which can move a radius-bin boundary of the 'hyper' purity or the order of two
-    near-tied scores.  Everything else is the same in both modes.  `events`: four optional handles from halo_event_create recorded around the logit and embedding passes."""
+    near-tied scores.  Everything else is the same in both modes.  `events`: four to six optional handles from halo_event_create recorded around the logit and embedding passes,
+    between the two kernels of the gram route, and behind the tail."""
     if pur_type not in _lib.PUR:
         raise NotImplementedError("Error: purity type '{}' not implemented".format(pur_type))
     mode = lowres_mode(mode)
@@ -211,11 +212,13 @@ def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, 
             _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
             _lib.stream_ptr(dev))
     if events is not None or score_range is not None:
-        # events: (logit start, logit stop, embedding start, embedding stop) from halo_event_create, or None each
+        # events: (logit start, logit stop, embedding start, embedding stop[, embedding mid (gram: between the Gram pass and the
+        # radius pass), tail stop]) from halo_event_create, or None each
         if score_range is not None:
             assert score_range.is_contiguous() and score_range.device == dev and score_range.numel() >= L.halo_score_range_bytes(B)
         name = "halo_score_maps_lr_timed"
-        rc = L.halo_score_maps_lr_timed(*(args + (1 if gram else 0,) + tuple(events or (None,) * 4) + (_lib.ptr(score_range),)))
+        ev = tuple(events or ()) + (None,) * 6
+        rc = L.halo_score_maps_lr_timed(*(args + (1 if gram else 0,) + ev[:4] + (_lib.ptr(score_range),) + ev[4:6]))
     else:
         rc = fn(*args)
     _lib.check(rc, name)

@@ -1654,6 +1654,7 @@ __global__ void __launch_bounds__(TPB) k_gram_lr(const double *__restrict__ feat
 // column the next lane's first (full-wave DPP shift); only lane 63 loads its right neighbour itself (8 bytes per row and
 // channel, clamped at the row's end).  Half the load instructions per byte of k_gram_lr, no idle 64th lane, and 512-column rows
 // split into four full waves.  Same fma chains, same bits.
+template <int UCH, bool NT>
 __global__ void __launch_bounds__(TPB) k_gram_lr2(const double *__restrict__ feat, long long bstride, int C, int h, int w,
                                                   double *__restrict__ gram)
 {
@@ -1696,19 +1697,24 @@ __global__ void __launch_bounds__(TPB) k_gram_lr2(const double *__restrict__ fea
             g[1][q][4] = __builtin_fma(r1[q], c2[q], g[1][q][4]);
         }
     };
+    // UCH channels (3 x 16 bytes each) in flight per lane; NT: the tensor is streamed once (each row a second time, right away,
+    // by the wave of the row pair above it) -- non-temporal loads keep it from displacing the Gram maps in the L2
+    auto ld2 = [](const double *q) -> d2_t {
+        if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(q));
+        else return *reinterpret_cast<const d2_t *>(q);
+    };
     int c = 0;
-    for (; c + 2 <= C; c += 2) {
-        d2_t v[2][3];
-        double xe[2][3];
+    for (; c + UCH <= C; c += UCH) {
+        d2_t v[UCH][3];
+        double xe[UCH][3];
 #pragma unroll
-        for (int u = 0; u < 2; ++u, p += hwl) {
-            v[u][0] = *reinterpret_cast<const d2_t *>(p + a0); v[u][1] = *reinterpret_cast<const d2_t *>(p + a1);
-            v[u][2] = *reinterpret_cast<const d2_t *>(p + a2);
+        for (int u = 0; u < UCH; ++u, p += hwl) {
+            v[u][0] = ld2(p + a0); v[u][1] = ld2(p + a1); v[u][2] = ld2(p + a2);
             xe[u][0] = xe[u][1] = xe[u][2] = 0.0;
             if (last) { xe[u][0] = p[e0]; xe[u][1] = p[e1]; xe[u][2] = p[e2]; }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) accumulate(v[u][0], v[u][1], v[u][2], xe[u][0], xe[u][1], xe[u][2]);
+        for (int u = 0; u < UCH; ++u) accumulate(v[u][0], v[u][1], v[u][2], xe[u][0], xe[u][1], xe[u][2]);
     }
     for (; c < C; ++c, p += hwl) {
         const d2_t v0 = *reinterpret_cast<const d2_t *>(p + a0), v1 = *reinterpret_cast<const d2_t *>(p + a1), v2 = *reinterpret_cast<const d2_t *>(p + a2);
@@ -1746,13 +1752,16 @@ __global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ 
     const bool live = i < hw;
     double mn = 0.0, mx = 0.0;
     if (live) {
-        const int y = (int)(i / W), x = (int)(i % W);
+        // pixel coordinates: 32-bit division where the map allows it (a 64-bit one is ~40 instructions per pixel)
+        int y, x;
+        if (hw <= 0x7fffffffll) { const unsigned iu = (unsigned)i; y = (int)(iu / (unsigned)W); x = (int)(iu - (unsigned)y * (unsigned)W); }
+        else { y = (int)(i / W); x = (int)(i % W); }
         const Taps<double> ty = make_taps<double>(y, sh, h), tx = make_taps<double>(x, sw, w);
         const double wt[4] = {ty.l0 * tx.l0, ty.l0 * tx.l1, ty.l1 * tx.l0, ty.l1 * tx.l1};      // the weights of lerp4
         const size_t hwl = (size_t)h * w;
         const double *S = gram + (size_t)b * GRAM_MAPS * hwl, *Hh = S + hwl, *Vv = Hh + hwl, *D1 = Vv + hwl, *D2 = D1 + hwl;
-        const size_t c00 = (size_t)ty.i0 * w + tx.i0, c01 = (size_t)ty.i0 * w + tx.i1, c10 = (size_t)ty.i1 * w + tx.i0,
-                     c11 = (size_t)ty.i1 * w + tx.i1;
+        const unsigned c00 = (unsigned)(ty.i0 * w + tx.i0), c01 = (unsigned)(ty.i0 * w + tx.i1), c10 = (unsigned)(ty.i1 * w + tx.i0),
+                       c11 = (unsigned)(ty.i1 * w + tx.i1);      // h * w < 2^31 (checked by the host)
         // <v_a, v_b> for corners a <= b in the order (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
         const double G[10] = {S[c00], Hh[c00], Vv[c00], D1[c00], S[c01], D2[c00], Vv[c01], S[c10], Hh[c10], S[c11]};
         double s = 0.0, t = 0.0;
@@ -2000,7 +2009,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
                       int pksize, int64_t K, double c, void *score, void *impurity, float *uncertainty,
                       void *workspace, size_t workspace_bytes, void *stream, void *ev_feat_start,
                       void *ev_feat_stop, const LrDims *lr, void *ev_logit_start = nullptr, void *ev_logit_stop = nullptr,
-                      void *score_range = nullptr, void *tail_stream = nullptr)
+                      void *score_range = nullptr, void *tail_stream = nullptr, void *ev_feat_mid = nullptr, void *ev_tail_stop = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
@@ -2092,13 +2101,20 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
             const bool wide = lr->wf >= 2 && lr->wf % 2 == 0 && feat_bstride % 2 == 0 && aligned16(feat) && aligned16(gram) && getenv("HALO_GRAM_8B") == nullptr;
             if (wide) {
                 const long long nwaves = cdiv(lr->wf, 128) * cdiv(lr->hf, 2);
-                hipLaunchKernelGGL(k_gram_lr2, dim3((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B), block, 0, st, (const double *)feat,
-                                   (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram);
+                const dim3 gg((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B);
+                const char *eu = getenv("HALO_GRAM_UCH"), *en = getenv("HALO_GRAM_NT");           // A/B switches, same bits
+                const int uch = eu ? atoi(eu) : 2, nt = en ? atoi(en) : 0;
+#define HALO_GRAM2(U_, N_) hipLaunchKernelGGL((k_gram_lr2<U_, N_>), gg, block, 0, st, (const double *)feat, (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram)
+                if (uch >= 4) { if (nt) HALO_GRAM2(4, true); else HALO_GRAM2(4, false); }
+                else if (uch == 3) { if (nt) HALO_GRAM2(3, true); else HALO_GRAM2(3, false); }
+                else { if (nt) HALO_GRAM2(2, true); else HALO_GRAM2(2, false); }
+#undef HALO_GRAM2
             } else {
                 const long long nwaves = cdiv(lr->wf, GRAM_COLS) * cdiv(lr->hf, 2);
                 hipLaunchKernelGGL(k_gram_lr, dim3((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B), block, 0, st, (const double *)feat,
                                    (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram);
             }
+            if (ev_feat_mid) (void)hipEventRecord((hipEvent_t)ev_feat_mid, st);       // between the Gram pass and the radius pass
             const double shd = H > 1 ? (double)(lr->hf - 1) / (double)(H - 1) : 0.0, swd = W > 1 ? (double)(lr->wf - 1) / (double)(W - 1) : 0.0;
             nblk_imp = nblk1;
             if (mode == 0) hipLaunchKernelGGL(k_radius_gram<0>, dim3((unsigned)nblk1, (unsigned)B), block, 0, st, gram, (const double *)feat, (long long)feat_bstride, (int)C, lr->hf, lr->wf, (int)H, (int)W, shd, swd, ks, rks, imp_raw, part_imp);
@@ -2189,6 +2205,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
         const int rc = score_range_exact(score, f64out ? HALO_F64 : HALO_F32, B, hw, score_range, st);
         if (rc != HALO_OK) return rc;
     }
+    if (ev_tail_stop) (void)hipEventRecord((hipEvent_t)ev_tail_stop, st);
     return check_launch("halo_score_maps");
 }
 
@@ -2312,6 +2329,7 @@ extern "C" int halo_score_maps_lr_gram(const float *logit_lr, int64_t logit_bstr
     if (hl <= 0 || wl <= 0) return fail(HALO_E_ARG, "halo_score_maps_lr_gram: bad low-res logit size");
     const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
     if (need_feat && (hf <= 0 || wf <= 0)) return fail(HALO_E_ARG, "halo_score_maps_lr_gram: bad low-res embedding size");
+    if (need_feat && hf * wf > 0x7fffffffll) return fail(HALO_E_UNSUPPORTED, "halo_score_maps_lr_gram: low-res planes of more than 2^31 elements");
     if (need_feat && workspace_bytes < halo_score_lr_gram_workspace_bytes(B, O, H, W, hf, wf))
         return fail(HALO_E_WORKSPACE, "halo_score_maps_lr_gram: workspace too small");
     LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf, true};
@@ -2320,16 +2338,16 @@ extern "C" int halo_score_maps_lr_gram(const float *logit_lr, int64_t logit_bstr
                       nullptr, &lr);
 }
 
-// halo_score_maps_lr (gram = 0) / halo_score_maps_lr_gram (gram = 1) with optional hipEvent_t pairs (halo_event_create) recorded on
-// `stream` around the logit pass (k_logit_maps_lr) and around the embedding pass (k_feat_reduce_lr, or k_gram_lr + k_radius_gram)
-// -- bench.py's live kernel times for the low-resolution boundary.
+// halo_score_maps_lr (gram = 0) / halo_score_maps_lr_gram (gram = 1) with optional hipEvent_t handles (halo_event_create) recorded on
+// `stream` around the logit pass (k_logit_maps_lr), around the embedding pass (k_feat_reduce_lr, or k_gram_lr + k_radius_gram, with
+// ev_feat_mid between the two) and behind the tail (ev_tail_stop) -- bench.py's live per-kernel times for the low-resolution boundary.
 extern "C" int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bstride, int64_t hl, int64_t wl, const void *feat_lr,
                                         int feat_dtype, int64_t feat_bstride, int64_t hf, int64_t wf, const int64_t *gt,
                                         const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
                                         int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
                                         void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream,
                                         int gram, void *ev_logit_start, void *ev_logit_stop, void *ev_feat_start, void *ev_feat_stop,
-                                        void *score_range)
+                                        void *score_range, void *ev_feat_mid, void *ev_tail_stop)
 {
     if (hl <= 0 || wl <= 0) return fail(HALO_E_ARG, "halo_score_maps_lr_timed: bad low-res logit size");
     const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
@@ -2339,5 +2357,5 @@ extern "C" int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bst
     LrDims lr{(int)hl, (int)wl, (int)hf, (int)wf, gram != 0};
     return score_impl(logit_lr, logit_bstride, feat_lr, feat_dtype, feat_bstride, gt, active, B, O, C, H, W, unc_type, pur_type,
                       normalize, ksize, pksize, K, c, score, impurity, uncertainty, workspace, workspace_bytes, stream, ev_feat_start,
-                      ev_feat_stop, &lr, ev_logit_start, ev_logit_stop, score_range);
+                      ev_feat_stop, &lr, ev_logit_start, ev_logit_stop, score_range, nullptr, ev_feat_mid, ev_tail_stop);
 }

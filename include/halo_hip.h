@@ -164,15 +164,16 @@ int halo_score_maps_lr_gram(const float *logit_lr, int64_t logit_bstride, int64_
                             void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Either of the two calls above (gram = 0 / 1) with optional hipEvent_t pairs (void*, from halo_event_create; NULL = none) recorded on
- * `stream` around the logit pass and around the embedding pass -- bench.py times the kernels of the low-resolution boundary
- * live with them. */
+ * `stream` around the logit pass, around the embedding pass (ev_feat_mid: between the Gram pass and the radius pass of the
+ * gram route) and behind the tail kernels (ev_tail_stop) -- bench.py times the kernels of the low-resolution boundary live
+ * with them. */
 int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bstride, int64_t hl, int64_t wl, const void *feat_lr,
                              int feat_dtype, int64_t feat_bstride, int64_t hf, int64_t wf, const int64_t *gt,
                              const uint8_t *active, int64_t B, int64_t O, int64_t C, int64_t H, int64_t W, int unc_type,
                              int pur_type, int normalize, int ksize, int pksize, int64_t K, double c, void *score,
                              void *impurity, float *uncertainty, void *workspace, size_t workspace_bytes, void *stream,
                              int gram, void *ev_logit_start, void *ev_logit_stop, void *ev_feat_start, void *ev_feat_stop,
-                             void *score_range);
+                             void *score_range, void *ev_feat_mid, void *ev_tail_stop);
 
 /* Helper methods of FloatingRegionScore that are public by convention:
  *  - compute_region_uncertainty(unc_type, logit, p, ground_truth) / compute_pixel_entropy(p)
