@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(FIN_TPB) k_minmax_finalize2(const double *__re
 //    step, q = n r, two fma corrections (the second one is v_div_fmas), v_div_fixup -- 11 instructions;
 //  * the lean one (softmax_lean + finish_px<LEAN>), unrolled over the classes in registers, taken when every lane of the
 //    wave has finite logits whose spread is at most 64.  Then x - max lies in [-64, 0], so det_expf needs neither its
-//    clamp nor its NaN patch (det_expf_core); every exp is >= 2^-93 and s is in [1, O_T], so v_div_scale would rescale
+//    clamp nor its NaN patch nor its two-step scaling (det_expf_core_small); every exp is >= 2^-93 and s is in [1, O_T], so v_div_scale would rescale
 //    nothing (it does only when the numerator is below 2^-104 or the quotient would be denormal) and the division
 //    sequence with the reciprocal computed once per pixel returns the identical, correctly rounded bits in 5
 //    instructions per class; the probabilities lie in (0, 1], so p + 1e-6 is a positive normal number and the entropy
@@ -160,7 +160,7 @@ __device__ __forceinline__ bool softmax_lean(float (&p)[NP][O_T])
 #pragma unroll
     for (int c = 0; c < O_T; ++c) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) { p[j][c] = det_expf_core(p[j][c] - m[j]); s[j] = s[j] + p[j][c]; }
+        for (int j = 0; j < NP; ++j) { p[j][c] = det_expf_core_small(p[j][c] - m[j]); s[j] = s[j] + p[j][c]; }
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -198,16 +198,20 @@ __device__ __forceinline__ void softmax_general(float (&p)[NP][O_T])
 // From the probabilities of NP pixels: ent (per unc_type) and pred (per pur_type).  LEAN: p came from softmax_lean.
 template <int O_T, int NP, bool LEAN>
 __device__ __forceinline__ void finish_px(float (&p)[NP][O_T], int unc_type, int pur_type, const long long (&g)[NP],
-                                          float (&ent)[NP], int (&pred)[NP])
+                                          float (&ent)[NP], int (&pred)[NP], bool want_pred = true)
 {
     int am[NP];               // torch.argmax: first maximal class
     float best[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) { am[j] = 0; best[j] = p[j][0]; }
+    // (kernel-uniform: the arg-max is 5 instructions per class, and the radius purities with an entropy uncertainty -- the
+    // reference's default configuration -- never read it)
+    if (want_pred || unc_type == HALO_UNC_ORACLE_ACC) {
 #pragma unroll
-    for (int c = 1; c < O_T; ++c)
+        for (int c = 1; c < O_T; ++c)
 #pragma unroll
-        for (int j = 0; j < NP; ++j) { const bool gtb = p[j][c] > best[j]; am[j] = gtb ? c : am[j]; best[j] = gtb ? p[j][c] : best[j]; }
+            for (int j = 0; j < NP; ++j) { const bool gtb = p[j][c] > best[j]; am[j] = gtb ? c : am[j]; best[j] = gtb ? p[j][c] : best[j]; }
+    }
     if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) {
         float a[NP];
 #pragma unroll
@@ -267,7 +271,7 @@ __global__ void __launch_bounds__(TPB) k_logit_maps(const float *__restrict__ lo
 #pragma unroll
     for (int j = 0; j < VEC; ++j) g[j] = need_gt ? gt[(size_t)b * hw + i0 + j] : 0;
     if (softmax_lean<O_T, VEC>(v)) {
-        finish_px<O_T, VEC, true>(v, unc_type, pur_type, g, e, pr);
+        finish_px<O_T, VEC, true>(v, unc_type, pur_type, g, e, pr, pred != nullptr);
     } else {
 #pragma unroll 1
         for (int j = 0; j < VEC; ++j) px_general(lp + j, O_T, hw, 0, unc_type, pur_type, g[j], e[j], pr[j]);
@@ -399,7 +403,7 @@ __global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, HA
 #pragma unroll
                     for (int j = 0; j < NP; ++j) gz[j] = 0;
                     if (softmax_lean<FO, NP>(lv)) {
-                        finish_px<FO, NP, true>(lv, unc_type, HALO_PUR_NONE, gz, e, pr);
+                        finish_px<FO, NP, true>(lv, unc_type, HALO_PUR_NONE, gz, e, pr, false);
                     } else {
 #pragma unroll 1
                         for (int j = 0; j < NP; ++j) px_general(lp + off + j, FO, hw, 0, unc_type, HALO_PUR_NONE, 0, e[j], pr[j]);
@@ -1826,10 +1830,10 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__
     float e[1];
     int pr[1];
     if (softmax_lean<O_T, 1>(p)) {
-        finish_px<O_T, 1, true>(p, unc_type, pur_type, g, e, pr);
+        finish_px<O_T, 1, true>(p, unc_type, pur_type, g, e, pr, pred != nullptr);
     } else {
         softmax_general<O_T, 1>(p);
-        finish_px<O_T, 1, false>(p, unc_type, pur_type, g, e, pr);
+        finish_px<O_T, 1, false>(p, unc_type, pur_type, g, e, pr, pred != nullptr);
     }
     ent[(size_t)b * hw + i] = e[0];
     if (pred) pred[(size_t)b * hw + i] = (short)pr[0];

@@ -46,6 +46,7 @@ static void one32(uint32_t u)
     cmpf("logf", u, halo::det_logf(x), ho_logf(x));
     // the *_core forms on the domains their callers guarantee
     if (x >= -104.0f && x <= 89.0f) cmpf("expf_core", u, halo::det_expf_core(x), ho_expf(x));
+    if (x >= -87.0f && x <= 0.35f) cmpf("expf_core_small", u, halo::det_expf_core_small(x), ho_expf(x));
     if (u >= 0x00800000u && u < 0x7f800000u) cmpf("logf_core", u, halo::det_logf_core(x), ho_logf(x));
 }
 
@@ -56,6 +57,11 @@ int main(int argc, char **argv)
     for (uint64_t i = 0; i < (1ull << 32); i += stride, ++n) one32((uint32_t)i);
     // every pattern from just inside the cut-offs outwards to +-1024, and every NaN / infinity neighbourhood
     for (uint32_t u = __float_as_uint(88.0f); u <= __float_as_uint(1024.0f); ++u, ++n) one32(u);
+    // the lean softmax's whole argument range [-64, 0], every pattern (64 down to 2^-20, and the zeros), and the ends of
+    // det_expf_core_small's domain
+    for (uint32_t u = __float_as_uint(-9.5e-7f); u <= __float_as_uint(-64.0f); ++u, ++n) one32(u);
+    for (uint32_t u = __float_as_uint(-64.0f); u <= __float_as_uint(-87.0f); u += 3, ++n) one32(u);
+    for (uint32_t u = 0; u <= __float_as_uint(0.35f); u += 97, ++n) one32(u);
     for (uint32_t u = __float_as_uint(-103.0f); u <= __float_as_uint(-1024.0f); ++u, ++n) one32(u);
     for (uint32_t u = 0x7f7ffff0u; u < 0x7f800100u; ++u, ++n) { one32(u); one32(u | 0x80000000u); }
     for (uint32_t u = 0; u < 0x00800100u; u += 1 + (u >> 12), ++n) { one32(u); one32(u | 0x80000000u); }
