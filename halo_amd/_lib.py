@@ -15,6 +15,13 @@ UNC_ZEROS = 3
 PUR = {"ripu": 0, "oracle_ripu": 1, "hyper": 2, "none": 3, "radius": 4, "euc_norm": 5}
 E_UNSUPPORTED = -2
 SELECT = {"auto": 0, "serial": 1, "binned": 2}                      # HALO_SELECT_* of include/halo_hip.h
+PAD = {"zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}     # HALO_PAD_*: nn.Conv2d's padding_mode values
+FLAG_NORMALIZE = 1
+
+
+def score_flags(normalize, padding_mode="zeros"):
+    """the flags word of the halo_score_maps* calls: bit 0 normalise, bits 8-9 the padding mode"""
+    return (FLAG_NORMALIZE if normalize else 0) | (PAD[padding_mode] << 8)
 
 _i64, _dbl, _int, _vp, _sz = C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_size_t
 
@@ -48,7 +55,7 @@ SIGNATURES = {
     "halo_score_maps_lr_timed": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                         _int, _int, _int, _int, _int, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "halo_region_uncertainty": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
-    "halo_region_impurity": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp]),
+    "halo_region_impurity": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _int, _vp]),
     "halo_quantize_radius": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _sz, _vp]),
     "halo_loss_workspace_bytes": (_sz, [_i64]),
     "halo_negative_learning_fwd": (_int, [_vp, _i64, _dbl, _vp, _vp, _sz, _vp]),

@@ -52,7 +52,7 @@ def new_score_range(B, dev):
 
 def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
                size=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, out=None, events=None, score_range=None,
-               tail_stream=None, workspace=None, maps=None):
+               tail_stream=None, workspace=None, maps=None, padding_mode="zeros"):
     """Batched FloatingRegionScore.forward.
 
     logit (B,O,H,W) float32; decoder_out (B,C,H,W) float64|float32; ground_truth (B,H,W) int64;
@@ -63,10 +63,13 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
     tail_stream (pipelined callers): a torch stream that receives everything behind the passes over the inputs
     (halo_score_maps_split; needs `events`, whose stop event is the fork, a `workspace` of its own per call in flight --
     score_workspace(B, H, W, dev) -- and preallocated `maps` = (impurity, uncertainty)); the results are complete on it.
+    padding_mode: nn.Conv2d's padding_mode of the two box windows ('zeros' | 'reflect' | 'replicate' | 'circular').
     Returns (score, impurity, uncertainty), each (B,H,W); the last two are None if not want_maps.
     """
     if pur_type not in _lib.PUR:
         raise NotImplementedError("Error: purity type '{}' not implemented".format(pur_type))
+    if padding_mode not in _lib.PAD:
+        raise ValueError("padding_mode must be one of %s, got %r" % (sorted(_lib.PAD), padding_mode))
     dev = _lib.require_device(logit, decoder_out, ground_truth, active)
     assert logit.dim() == 4, "logit must be (B,O,H,W)"
     if logit.dtype != torch.float32:
@@ -129,14 +132,14 @@ def score_maps(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=
             "tail_stream needs events, a workspace of the call's own and preallocated maps"
         rc = L.halo_score_maps_split(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt),
                                      _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
-                                     _lib.PUR[pur_type], 1 if normalize else 0, int(size), int(psize), int(K), float(c),
+                                     _lib.PUR[pur_type], _lib.score_flags(normalize, padding_mode), int(size), int(psize), int(K), float(c),
                                      _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
                                      _lib.stream_ptr(dev), _lib.C.c_void_p(tail_stream.cuda_stream), ev0, ev1, _lib.ptr(score_range))
         _lib.check(rc, "halo_score_maps_split")
         return score, imp, unc
     rc = L.halo_score_maps_timed(_lib.ptr(logit), logit.stride(0), _lib.ptr(feat), fdt, fbs, _lib.ptr(gt),
                                  _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
-                                 _lib.PUR[pur_type], 1 if normalize else 0, int(size), int(psize), int(K), float(c),
+                                 _lib.PUR[pur_type], _lib.score_flags(normalize, padding_mode), int(size), int(psize), int(K), float(c),
                                  _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
                                  _lib.stream_ptr(dev), ev0, ev1, _lib.ptr(score_range))
     _lib.check(rc, "halo_score_maps")
@@ -157,7 +160,7 @@ def lowres_mode(mode=None):
 
 def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, normalize=False, ground_truth=None,
                       ksize=3, purity_size=None, K=100, c=1.0, active=None, want_maps=True, mode=None, events=None,
-                      score_range=None):
+                      score_range=None, padding_mode="zeros"):
     """FloatingRegionScore.forward on the bilinear (align_corners=True) upsampling of LOW-RES sources to
     `size`, without materialising the upsampled tensors -- core/active/build.py:122-144 in one call.
     logit_lr (B,O,hl,wl) float32, decoder_lr (B,C,hf,wf) float64|float32.
@@ -208,7 +211,7 @@ def score_maps_lowres(logit_lr, decoder_lr, size, unc_type=None, pur_type=None, 
     fn, name = (L.halo_score_maps_lr_gram, "halo_score_maps_lr_gram") if gram else (L.halo_score_maps_lr, "halo_score_maps_lr")
     args = (_lib.ptr(logit_lr), logit_lr.stride(0), hl, wl, _lib.ptr(feat), fdt, fbs, hf, wf,
             _lib.ptr(gt), _lib.ptr(act), B, O, Cc, H, W, _lib.UNC.get(unc_type, _lib.UNC_ZEROS),
-            _lib.PUR[pur_type], 1 if normalize else 0, int(ksize), int(psize), int(K), float(c),
+            _lib.PUR[pur_type], _lib.score_flags(normalize, padding_mode), int(ksize), int(psize), int(K), float(c),
             _lib.ptr(score), _lib.ptr(imp), _lib.ptr(unc), _lib.ptr(ws), ws.numel(),
             _lib.stream_ptr(dev))
     if events is not None or score_range is not None:
@@ -234,13 +237,11 @@ class FloatingRegionScore(nn.Module):
         super(FloatingRegionScore, self).__init__()
         self.in_channels = in_channels
         assert size % 2 == 1, "error size"
-        if padding_mode != "zeros":
-            # the reference forwards padding_mode to its two nn.Conv2d box filters (floating_region.py:49,63), but no caller in
-            # its tree ever passes one (build.py:83-88 and visualize.py:22-34 construct the scorer with the default): the
-            # window kernels here implement the zero padding those callers get
-            raise NotImplementedError("halo_amd FloatingRegionScore implements padding_mode='zeros' only (got %r); the reference "
-                                      "forwards the argument to nn.Conv2d (core/active/floating_region.py:49,63) but none of its "
-                                      "callers passes anything else (core/active/build.py:83-88)" % (padding_mode,))
+        if padding_mode not in _lib.PAD:
+            # nn.Conv2d's own check (the reference forwards the argument to it, floating_region.py:49,63)
+            raise ValueError("padding_mode must be one of ['zeros', 'reflect', 'replicate', 'circular'], but got padding_mode='{}'"
+                             .format(padding_mode))
+        self.padding_mode = padding_mode
         if purity_type is None:
             purity_type = cfg.ACTIVE.PURITY
         self.size = size
@@ -271,7 +272,7 @@ class FloatingRegionScore(nn.Module):
         ws = _workspace(dev, H * W * 4 + 256, "unc")
         rc = _lib.lib().halo_region_uncertainty(_lib.ptr(x), x.numel(), 1 if is_prob else 0, _lib.ptr(gt), 1, O, H, W,
                                                 _lib.UNC.get(unc_type, _lib.UNC_ZEROS), int(self.size),
-                                                1 if do_box else 0, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                                (1 if do_box else 0) | (_lib.PAD[self.padding_mode] << 8), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                                 _lib.stream_ptr(dev))
         _lib.check(rc, "halo_region_uncertainty")
         return out
@@ -311,7 +312,7 @@ class FloatingRegionScore(nn.Module):
         imp = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
         cnt = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
         rc = _lib.lib().halo_region_impurity(_lib.ptr(pred), 1, H, W, int(self.purity_size), int(K), _lib.ptr(imp),
-                                             _lib.ptr(cnt), _lib.stream_ptr(dev))
+                                             _lib.ptr(cnt), _lib.PAD[self.padding_mode], _lib.stream_ptr(dev))
         _lib.check(rc, "halo_region_impurity")
         return imp, cnt
 
@@ -342,5 +343,6 @@ class FloatingRegionScore(nn.Module):
             decoder_out = decoder_out.unsqueeze(0)
         gt = None if ground_truth is None else ground_truth.unsqueeze(0)
         score, imp, unc = score_maps(logit, decoder_out, unc_type, pur_type, normalize, gt, size=self.size,
-                                     purity_size=self.purity_size, K=getattr(self, "K", 100), c=self.mapper.c)
+                                     purity_size=self.purity_size, K=getattr(self, "K", 100), c=self.mapper.c,
+                                     padding_mode=self.padding_mode)
         return score[0], imp[0], unc[0]

@@ -506,17 +506,31 @@ __global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const
 // Window class histogram -> sum_c -d*log(d+1e-6) / log(K), classes visited in ascending order
 // (= the reference's sum over the one-hot channel axis; empty classes contribute exactly 0).
 // No one-hot tensor: the <= k*k window labels are re-scanned once per distinct class.
+// nn.Conv2d(padding_mode=...) of the two box filters (floating_region.py:49,63): where a window tap falls outside the image.
+// 'zeros' contributes nothing (and does not count in the purity window); the other three modes read an image pixel
+// (torch pads the input first: F.pad(mode) then an unpadded convolution), so every tap counts.  Valid for pad < n
+// ('reflect') / pad <= n ('circular'), which the host checks as torch does.
+__device__ __forceinline__ int pad_index(int t, int n, int mode)
+{
+    if (t >= 0 && t < n) return t;
+    if (mode == HALO_PAD_ZEROS) return -1;
+    if (mode == HALO_PAD_REPLICATE) return t < 0 ? 0 : n - 1;
+    if (mode == HALO_PAD_REFLECT) return t < 0 ? -t : 2 * (n - 1) - t;
+    return t < 0 ? t + n : t - n;                       // circular
+}
+
 template <typename TL>
 __global__ void __launch_bounds__(TPB) k_region_impurity(const TL *__restrict__ pred, int H, int W, int k,
-                                                         float logK, float *__restrict__ imp, float *__restrict__ count)
+                                                         float logK, float *__restrict__ imp, float *__restrict__ count, int pad)
 {
     const int b = blockIdx.y;
     const long long hw = (long long)H * W;
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= hw) return;
     const int y = (int)(i / W), x = (int)(i % W), r = k / 2;
-    const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
-    const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+    // zero padding: the in-image part of the window; any other mode: the whole window, taps mapped into the image
+    const int y0 = pad ? y - r : (y - r < 0 ? 0 : y - r), y1 = pad ? y + r : (y + r >= H ? H - 1 : y + r);
+    const int x0 = pad ? x - r : (x - r < 0 ? 0 : x - r), x1 = pad ? x + r : (x + r >= W ? W - 1 : x + r);
     const TL *pp = pred + (size_t)b * hw;
     const float cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
     float a = 0.0f;
@@ -525,7 +539,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const TL *__restrict__ 
         int nxt = 0x7fffffff, n = 0;
         for (int yy = y0; yy <= y1; ++yy)
             for (int xx = x0; xx <= x1; ++xx) {
-                const int v = (int)pp[(size_t)yy * W + xx];
+                const int v = (int)pp[(size_t)pad_index(yy, H, pad) * W + pad_index(xx, W, pad)];
                 if (v > cur) {
                     if (v < nxt) { nxt = v; n = 1; }
                     else if (v == nxt) ++n;
@@ -624,15 +638,15 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
 // Returns the number of min/max partials per image written to `partials` (0: none -- the caller runs k_minmax_f32).
 template <typename TL>
 static int launch_region_impurity(const TL *pred, int64_t B, int64_t H, int64_t W, int k, float logK, float *imp, float *count,
-                                  hipStream_t st, double *partials = nullptr)
+                                  hipStream_t st, double *partials = nullptr, int pad = HALO_PAD_ZEROS)
 {
-    if (k == 3 && cdiv(H, RI_TH) <= 65535 && B <= 65535 && !getenv("HALO_IMPURITY_GENERIC")) {     // A/B switch
+    if (pad == HALO_PAD_ZEROS && k == 3 && cdiv(H, RI_TH) <= 65535 && B <= 65535 && !getenv("HALO_IMPURITY_GENERIC")) {     // A/B switch
         const dim3 grid((unsigned)cdiv(W, RI_TW), (unsigned)cdiv(H, RI_TH), (unsigned)B);
         hipLaunchKernelGGL((k_region_impurity3<TL>), grid, dim3(TPB), 0, st, pred, (int)H, (int)W, logK, imp, count, partials);
         return partials ? (int)(grid.x * grid.y) : 0;
     }
     hipLaunchKernelGGL((k_region_impurity<TL>), dim3((unsigned)cdiv(H * W, TPB), (unsigned)B), dim3(TPB), 0, st, pred, (int)H, (int)W, k,
-                       logK, imp, count);
+                       logK, imp, count, pad);
     return 0;
 }
 
@@ -640,7 +654,7 @@ static int launch_region_impurity(const TL *pred, int64_t B, int64_t H, int64_t 
 // k x k all-ones box SUM with zero padding, taps added in row-major order starting from +0.
 // count = in-bounds size of the pk x pk purity window for ripu / oracle_ripu / hyper, else 1.
 __global__ void __launch_bounds__(TPB) k_box_unc(const float *__restrict__ ent, int H, int W, int k, int do_box,
-                                                 int pk, float *__restrict__ unc, double *__restrict__ partials)
+                                                 int pk, float *__restrict__ unc, double *__restrict__ partials, int pad)
 {
     const int b = blockIdx.y;
     const long long hw = (long long)H * W;
@@ -656,15 +670,17 @@ __global__ void __launch_bounds__(TPB) k_box_unc(const float *__restrict__ ent, 
             a = 0.0f;
             for (int dy = -r; dy <= r; ++dy)
                 for (int dx = -r; dx <= r; ++dx) {
-                    const int yy = y + dy, xx = x + dx;
-                    const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ep[(size_t)yy * W + xx] : 0.0f;
+                    const int yy = pad_index(y + dy, H, pad), xx = pad_index(x + dx, W, pad);
+                    const float v = (yy >= 0 && xx >= 0) ? ep[(size_t)yy * W + xx] : 0.0f;
                     a = a + v;
                 }
         } else {
             a = ep[i];
         }
         float cnt = 1.0f;
-        if (pk > 0) {
+        if (pk > 0 && pad) {
+            cnt = (float)(pk * pk);                    // padded taps are image pixels: the purity window is always full
+        } else if (pk > 0) {
             const int r = pk / 2;
             const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
             const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
@@ -2007,6 +2023,18 @@ static int launch_feat_lr(const T *feat, long long bstride, int C, const LrDims 
     return HALO_OK;
 }
 
+// torch's own limits on the padded convolution (F.pad): 'reflect' needs pad < size, 'circular' pad <= size, in both dimensions
+static int check_padding(int pad, int k, int64_t H, int64_t W, const char *who)
+{
+    if (pad < HALO_PAD_ZEROS || pad > HALO_PAD_CIRCULAR) return fail(HALO_E_ARG, "%s: bad padding mode %d", who, pad);
+    const int64_t r = k / 2, m = H < W ? H : W;
+    if (pad == HALO_PAD_REFLECT && r >= m)
+        return fail(HALO_E_ARG, "%s: padding_mode='reflect' needs the padding (%lld) to be smaller than the map (%lld x %lld)", who, (long long)r, (long long)H, (long long)W);
+    if (pad == HALO_PAD_CIRCULAR && r > m)
+        return fail(HALO_E_ARG, "%s: padding_mode='circular' needs the padding (%lld) to be at most the map size (%lld x %lld)", who, (long long)r, (long long)H, (long long)W);
+    return HALO_OK;
+}
+
 static int score_impl(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
                       int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
                       int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
@@ -2016,10 +2044,18 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
                       void *score_range = nullptr, void *tail_stream = nullptr, void *ev_feat_mid = nullptr, void *ev_tail_stop = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
+    // `normalize` is the flags word of include/halo_hip.h: bit 0 = normalise, bits 8-9 = padding mode of the two box windows
+    const int pad = (normalize >> 8) & 3;
+    if (normalize & ~(HALO_FLAG_NORMALIZE | (3 << 8))) return fail(HALO_E_ARG, "halo_score_maps: unknown flag bits 0x%x", normalize);
+    normalize &= HALO_FLAG_NORMALIZE;
     if (!logit || !score || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_score_maps: null/empty argument");
     if (unc_type < 0 || unc_type > HALO_UNC_ZEROS) return fail(HALO_E_ARG, "halo_score_maps: bad unc_type %d", unc_type);
     if (pur_type < 0 || pur_type > HALO_PUR_EUC_NORM) return fail(HALO_E_UNSUPPORTED, "Error: purity type '%d' not implemented", pur_type);
     if (ksize < 1 || !(ksize & 1) || pksize < 1 || !(pksize & 1)) return fail(HALO_E_ARG, "halo_score_maps: window sizes must be odd");
+    {
+        const int rc = check_padding(pad, ksize > pksize ? ksize : pksize, H, W, "halo_score_maps");
+        if (rc != HALO_OK) return rc;
+    }
     const bool need_feat = pur_type == HALO_PUR_HYPER || pur_type == HALO_PUR_RADIUS || pur_type == HALO_PUR_EUC_NORM;
     if (need_feat && (!feat || C <= 0)) return fail(HALO_E_ARG, "halo_score_maps: decoder_out required for this purity type");
     if (need_feat && feat_dtype != HALO_F32 && feat_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_score_maps: bad feat dtype");
@@ -2158,7 +2194,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     if (hist) {
         const float logK = (float)log((double)(pur_type == HALO_PUR_HYPER ? K : O));
         const int np = launch_region_impurity<short>((const short *)pred, B, H, W, pksize, logK, (float *)imp_raw, (float *)nullptr, st,
-                                                     normalize ? part_imp : nullptr);
+                                                     normalize ? part_imp : nullptr, pad);
         nblk_imp = np ? np : nblk1;
         if (normalize && !np) hipLaunchKernelGGL(k_minmax_f32, grid1, block, 0, st, (const float *)imp_raw, hw, part_imp);
     } else if (pur_type == HALO_PUR_NONE) {
@@ -2170,7 +2206,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
     // ---- box-sum of the uncertainty, / count
     const int do_box = (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_ORACLE_ACC) ? 1 : 0;
     int nblk_unc = nblk1;
-    const bool box3 = do_box && ksize == 3 && W % 4 == 0 && aligned16(ent) && aligned16(unc_raw);
+    const bool box3 = do_box && pad == HALO_PAD_ZEROS && ksize == 3 && W % 4 == 0 && aligned16(ent) && aligned16(unc_raw);   // (the 3x3 fast paths pad with zeros)
     // 3 x 3 window + 16-byte aligned maps: the box sum is recomputed inside the combine kernel (no stored copy);
     // HALO_NO_FUSE_TAIL=1 keeps the round-2 sequence (A/B switch, identical results)
     const bool fuse_tail = box3 && B <= 65535 && H <= 65535 && aligned16(imp_raw) && aligned16(score) && (!impurity || aligned16(impurity)) &&
@@ -2189,7 +2225,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
                            hist ? pksize : 0, unc_raw, normalize ? part_unc : nullptr);
     } else {
         hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, ent, (int)H, (int)W, ksize, do_box, hist ? pksize : 0, unc_raw,
-                           normalize ? part_unc : nullptr);
+                           normalize ? part_unc : nullptr, pad);
     }
 
     // ---- global min/max (normalize_map only), then normalise + product
@@ -2220,10 +2256,13 @@ extern "C" int halo_region_uncertainty(const float *x, int64_t bstride, int is_p
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    const int pad = (do_box >> 8) & 3;                    // do_box: bit 0 = box-sum the map, bits 8-9 = padding mode (halo_hip.h)
+    do_box &= 1;
     if (!x || !out || B <= 0 || O <= 0 || H <= 0 || W <= 0) return fail(HALO_E_ARG, "halo_region_uncertainty: null/empty argument");
     if (unc_type < 0 || unc_type > HALO_UNC_ZEROS) return fail(HALO_E_ARG, "halo_region_uncertainty: bad unc_type");
     if (unc_type == HALO_UNC_ORACLE_ACC && !gt) return fail(HALO_E_ARG, "halo_region_uncertainty: ground_truth required");
     if (ksize < 1 || !(ksize & 1)) return fail(HALO_E_ARG, "halo_region_uncertainty: window size must be odd");
+    if (do_box) { const int rc = check_padding(pad, ksize, H, W, "halo_region_uncertainty"); if (rc != HALO_OK) return rc; }
     const long long hw = (long long)H * W;
     if (!workspace || workspace_bytes < (size_t)B * hw * 4 + 256) return fail(HALO_E_WORKSPACE, "halo_region_uncertainty: workspace too small");
     float *ent = (float *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -2235,17 +2274,19 @@ extern "C" int halo_region_uncertainty(const float *x, int64_t bstride, int is_p
         hipLaunchKernelGGL(k_logit_maps_generic, grid1, block, 0, st, x, (long long)bstride, (const long long *)gt, (int)O, hw,
                            unc_type, HALO_PUR_NONE, is_prob, dst, (short *)nullptr);
     if (do_box)
-        hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, (const float *)ent, (int)H, (int)W, ksize, 1, 0, out, (double *)nullptr);
+        hipLaunchKernelGGL(k_box_unc, grid1, block, 0, st, (const float *)ent, (int)H, (int)W, ksize, 1, 0, out, (double *)nullptr, pad);
     return check_launch("halo_region_uncertainty");
 }
 
 // FloatingRegionScore.compute_region_impurity(predict, K) (floating_region.py:112-121)
 extern "C" int halo_region_impurity(const int64_t *pred, int64_t B, int64_t H, int64_t W, int ksize, int64_t K, float *impurity,
-                                    float *count, void *stream)
+                                    float *count, int pad_mode, void *stream)
 {
     if (!pred || !impurity || B <= 0 || H <= 0 || W <= 0 || K < 1) return fail(HALO_E_ARG, "halo_region_impurity: null/empty argument");
     if (ksize < 1 || !(ksize & 1)) return fail(HALO_E_ARG, "halo_region_impurity: window size must be odd");
-    launch_region_impurity<long long>((const long long *)pred, B, H, W, ksize, (float)log((double)K), impurity, count, (hipStream_t)stream);
+    { const int rc = check_padding(pad_mode, ksize, H, W, "halo_region_impurity"); if (rc != HALO_OK) return rc; }
+    launch_region_impurity<long long>((const long long *)pred, B, H, W, ksize, (float)log((double)K), impurity, count, (hipStream_t)stream,
+                                      nullptr, pad_mode);
     return check_launch("halo_region_impurity");
 }
 

@@ -41,6 +41,15 @@ enum { HALO_UNC_ENTROPY = 0, HALO_UNC_PIXEL_ENTROPY = 1, HALO_UNC_ORACLE_ACC = 2
 
 /* pur_type of FloatingRegionScore.forward (floating_region.py:165-202); anything else is the
  * reference's NotImplementedError and must be rejected by the caller. */
+/* padding_mode of FloatingRegionScore's two box windows (floating_region.py:49,63: forwarded to nn.Conv2d): what a window tap
+ * outside the image reads.  ZEROS (every caller in the reference's tree): nothing, and the purity window counts its in-image
+ * taps only; REFLECT / REPLICATE / CIRCULAR: the image pixel torch's F.pad(mode) puts there, so every tap counts. */
+enum { HALO_PAD_ZEROS = 0, HALO_PAD_REFLECT = 1, HALO_PAD_REPLICATE = 2, HALO_PAD_CIRCULAR = 3 };
+/* The `normalize` argument of the halo_score_maps* calls is a flags word: bit 0 = normalise both maps (the reference's
+ * `normalize`), bits 8-9 = HALO_PAD_* << 8.  Passing 0 / 1 keeps its old meaning (zero padding). */
+enum { HALO_FLAG_NORMALIZE = 1 };
+#define HALO_FLAG_PAD(mode) ((mode) << 8)
+
 enum { HALO_PUR_RIPU = 0, HALO_PUR_ORACLE_RIPU = 1, HALO_PUR_HYPER = 2, HALO_PUR_NONE = 3,
        HALO_PUR_RADIUS = 4, HALO_PUR_EUC_NORM = 5 };
 
@@ -178,17 +187,17 @@ int halo_score_maps_lr_timed(const float *logit_lr, int64_t logit_bstride, int64
 /* Helper methods of FloatingRegionScore that are public by convention:
  *  - compute_region_uncertainty(unc_type, logit, p, ground_truth) / compute_pixel_entropy(p)
  *    (floating_region.py:70-92,123-127): x (B,O,H,W) f32 holds logits (is_prob=0) or softmax
- *    probabilities (is_prob=1); do_box applies the k x k box sum; out (B,H,W) f32.
- *    workspace: B*H*W*4 + 256 bytes.
+ *    probabilities (is_prob=1); do_box bit 0 applies the k x k box sum, its bits 8-9 carry the padding mode
+ *    (HALO_FLAG_PAD(HALO_PAD_*)); out (B,H,W) f32.  workspace: B*H*W*4 + 256 bytes.
  *  - compute_region_impurity(predict, K) (floating_region.py:112-121): pred (B,H,W) i64 ->
- *    impurity, count (B,H,W) f32 (count may be NULL).
+ *    impurity, count (B,H,W) f32 (count may be NULL); pad_mode = HALO_PAD_*.
  *  - quantize_uncert_map(decoder_out) (floating_region.py:94-110): -> pred (B,H,W) i64 in [0,K-1].
  *    workspace: halo_score_workspace_bytes(B,H,W). */
 int halo_region_uncertainty(const float *x, int64_t bstride, int is_prob, const int64_t *gt, int64_t B, int64_t O,
                             int64_t H, int64_t W, int unc_type, int ksize, int do_box, float *out, void *workspace,
                             size_t workspace_bytes, void *stream);
 int halo_region_impurity(const int64_t *pred, int64_t B, int64_t H, int64_t W, int ksize, int64_t K, float *impurity,
-                         float *count, void *stream);
+                         float *count, int pad_mode, void *stream);
 int halo_quantize_radius(const void *feat, int feat_dtype, int64_t feat_bstride, int64_t B, int64_t C, int64_t H,
                          int64_t W, int64_t K, double c, int64_t *pred, void *workspace, size_t workspace_bytes,
                          void *stream);

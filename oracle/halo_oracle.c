@@ -412,8 +412,20 @@ static float entropy_px(const float *p, i64 O)
     return a / (float)log(19.0);
 }
 
-/* k x k all-ones conv, zero padding k/2 (floating_region.py:42-51,90): row-major tap order */
-static void box_sum_f32(const float *in, float *out, i64 H, i64 W, int k)
+/* nn.Conv2d(padding_mode=...) (floating_region.py:49,63): index a tap outside [0, n) reads, -1 = nothing ('zeros').
+ * torch pads the input (F.pad: 'reflect' mirrors without repeating the edge, 'replicate' repeats the edge, 'circular'
+ * wraps) and convolves without padding.  0 zeros, 1 reflect, 2 replicate, 3 circular (HALO_PAD_* of include/halo_hip.h). */
+static i64 pad_index(i64 t, i64 n, int mode)
+{
+    if (t >= 0 && t < n) return t;
+    if (mode == 0) return -1;
+    if (mode == 2) return t < 0 ? 0 : n - 1;
+    if (mode == 1) return t < 0 ? -t : 2 * (n - 1) - t;
+    return t < 0 ? t + n : t - n;
+}
+
+/* k x k all-ones conv, padding k/2 (floating_region.py:42-51,90): row-major tap order */
+static void box_sum_f32(const float *in, float *out, i64 H, i64 W, int k, int pad)
 {
     const int r = k / 2;
 #pragma omp parallel for schedule(static)
@@ -422,8 +434,8 @@ static void box_sum_f32(const float *in, float *out, i64 H, i64 W, int k)
             float a = 0.0f;
             for (int dy = -r; dy <= r; ++dy)
                 for (int dx = -r; dx <= r; ++dx) {
-                    i64 yy = y + dy, xx = x + dx;
-                    float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[yy * W + xx] : 0.0f;
+                    const i64 yy = pad_index(y + dy, H, pad), xx = pad_index(x + dx, W, pad);
+                    float v = (yy >= 0 && xx >= 0) ? in[yy * W + xx] : 0.0f;
                     a = a + v;
                 }
             out[y * W + x] = a;
@@ -431,7 +443,7 @@ static void box_sum_f32(const float *in, float *out, i64 H, i64 W, int k)
 }
 
 /* compute_region_impurity (floating_region.py:112-121): window class histogram -> entropy/log(K) */
-static void region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *imp, float *count)
+static void region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *imp, float *count, int pad)
 {
     const int r = k / 2;
     const float logK = (float)log((double)K);
@@ -445,8 +457,8 @@ static void region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *
                 float cnt = 0.0f;
                 for (int dy = -r; dy <= r; ++dy)
                     for (int dx = -r; dx <= r; ++dx) {
-                        i64 yy = y + dy, xx = x + dx;
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { hist[pred[yy * W + xx]] += 1.0f; cnt += 1.0f; }
+                        const i64 yy = pad_index(y + dy, H, pad), xx = pad_index(x + dx, W, pad);
+                        if (yy >= 0 && xx >= 0) { hist[pred[yy * W + xx]] += 1.0f; cnt += 1.0f; }
                     }
                 float a = 0.0f;
                 for (i64 c = 0; c < K; ++c)
@@ -519,6 +531,8 @@ int halo_o_floating_region_score(const float *logit, const void *feat, int feat_
                                  void *score, void *impurity, float *unc_out, int *score_dtype)
 {
     const i64 hw = H * W;
+    const int pad = (normalize >> 8) & 3;                       /* flags word as in include/halo_hip.h: bit 0 normalise, bits 8-9 padding */
+    normalize &= 1;
     if (pur_type < 0 || pur_type > HALO_PUR_EUC_NORM) return -1;
     float *ent = (float *)malloc(sizeof(float) * hw);
     float *cnt = (float *)malloc(sizeof(float) * hw);
@@ -543,7 +557,7 @@ int halo_o_floating_region_score(const float *logit, const void *feat, int feat_
         }
         free(p);
     }
-    if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_ORACLE_ACC) box_sum_f32(ent, unc_out, H, W, ksize);
+    if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_ORACLE_ACC) box_sum_f32(ent, unc_out, H, W, ksize, pad);
     else for (i64 i = 0; i < hw; ++i) unc_out[i] = ent[i];   /* pixel_entropy: no conv; zeros: conv(0)=0 */
 
     /* --- purity (floating_region.py:165-202) --- */
@@ -553,7 +567,7 @@ int halo_o_floating_region_score(const float *logit, const void *feat, int feat_
     double *imp64 = (double *)impurity;
     float *imp32 = (float *)impurity;
     if (pur_type == HALO_PUR_RIPU || pur_type == HALO_PUR_ORACLE_RIPU) {
-        region_impurity(pred, O, pksize, H, W, imp32, cnt);
+        region_impurity(pred, O, pksize, H, W, imp32, cnt, pad);
     } else if (pur_type == HALO_PUR_HYPER) {
         if (feat_dtype == HALO_F64) {
             double *r = (double *)malloc(sizeof(double) * hw);
@@ -568,7 +582,7 @@ int halo_o_floating_region_score(const float *logit, const void *feat, int feat_
             quantize_f32(r, hw, K, pred);
             free(r);
         }
-        region_impurity(pred, K, pksize, H, W, imp32, cnt);
+        region_impurity(pred, K, pksize, H, W, imp32, cnt, pad);
     } else {
 #pragma omp parallel for schedule(static)
         for (i64 i = 0; i < hw; ++i) {
@@ -617,7 +631,7 @@ void halo_o_uncertainty_from_probs(const float *p, const i64 *gt, i64 O, i64 H, 
         }
         free(q);
     }
-    if (do_box) box_sum_f32(ent, out, H, W, ksize);
+    if (do_box & 1) box_sum_f32(ent, out, H, W, ksize, (do_box >> 8) & 3);        /* bits 8-9: padding mode */
     else for (i64 i = 0; i < hw; ++i) out[i] = ent[i];
     free(ent);
 }
@@ -635,9 +649,9 @@ void halo_o_softmax(const float *logit, i64 O, i64 H, i64 W, float *p)
     }
 }
 
-void halo_o_region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *imp, float *count)
+void halo_o_region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *imp, float *count, int pad)
 {
-    region_impurity(pred, K, k, H, W, imp, count);
+    region_impurity(pred, K, k, H, W, imp, count, pad);
 }
 
 void halo_o_quantize(const void *feat, int feat_dtype, i64 C, i64 H, i64 W, i64 K, double c, i64 *pred)

@@ -169,9 +169,12 @@ def gram_radius(feat_lr, size, mode="radius", c=1.0):
     return out
 
 
+PAD = {"zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}
+
+
 def floating_region_score(logit, decoder_out=None, unc_type=None, pur_type=None, normalize=False,
-                          ground_truth=None, size=3, purity_type=None, K=100, c=1.0, impurity_raw=None):
-    """FloatingRegionScore(in_channels=O, size=size, purity_type=purity_type, K=K)(logit, ...).
+                          ground_truth=None, size=3, purity_type=None, K=100, c=1.0, impurity_raw=None, padding_mode="zeros"):
+    """FloatingRegionScore(in_channels=O, padding_mode=padding_mode, size=size, purity_type=purity_type, K=K)(logit, ...).
     impurity_raw: (H,W) float64 map of per-pixel radii / norms to use INSTEAD of reducing decoder_out (gram_radius)."""
     logit = np.ascontiguousarray(logit, dtype=np.float32)
     if logit.ndim == 4:
@@ -202,7 +205,7 @@ def floating_region_score(logit, decoder_out=None, unc_type=None, pur_type=None,
     pk = 3 if purity_type == "hyper" else size
     rc = lib().halo_o_floating_region_score(
         _p(logit), _p(feat), _int(fdt), _p(gt), _i64(O), _i64(Cc), _i64(H), _i64(W),
-        _int(UNC.get(unc_type, 3)), _int(PUR[pur_type]), _int(1 if normalize else 0),
+        _int(UNC.get(unc_type, 3)), _int(PUR[pur_type]), _int((1 if normalize else 0) | (PAD[padding_mode] << 8)),
         _int(size), _int(pk), _i64(K), _dbl(c), _p(score), _p(imp), _p(unc), C.byref(sdt))
     assert rc == 0
     return score, imp, unc
@@ -216,24 +219,24 @@ def softmax(logit):
     return p
 
 
-def uncertainty_from_probs(p, unc_type, ground_truth=None, size=3, do_box=True):
+def uncertainty_from_probs(p, unc_type, ground_truth=None, size=3, do_box=True, padding_mode="zeros"):
     """compute_region_uncertainty / compute_pixel_entropy (floating_region.py:70-92,123-127) -> (1,1,H,W)."""
     p = np.ascontiguousarray(p, dtype=np.float32)
     O, H, W = p.shape
     gt = None if ground_truth is None else np.ascontiguousarray(ground_truth, dtype=np.int64)
     out = np.empty((1, 1, H, W), np.float32)
     lib().halo_o_uncertainty_from_probs(_p(p), _p(gt), _i64(O), _i64(H), _i64(W), _int(UNC.get(unc_type, 3)),
-                                        _int(size), _int(1 if do_box else 0), _p(out))
+                                        _int(size), _int((1 if do_box else 0) | (PAD[padding_mode] << 8)), _p(out))
     return out
 
 
-def region_impurity(predict, K, size=3):
+def region_impurity(predict, K, size=3, padding_mode="zeros"):
     """compute_region_impurity (floating_region.py:112-121) -> (imp, count), each (1,1,H,W)."""
     pred = np.ascontiguousarray(predict, dtype=np.int64)
     H, W = pred.shape
     imp = np.empty((1, 1, H, W), np.float32)
     cnt = np.empty((1, 1, H, W), np.float32)
-    lib().halo_o_region_impurity(_p(pred), _i64(K), _int(size), _i64(H), _i64(W), _p(imp), _p(cnt))
+    lib().halo_o_region_impurity(_p(pred), _i64(K), _int(size), _i64(H), _i64(W), _p(imp), _p(cnt), _int(PAD[padding_mode]))
     return imp, cnt
 
 

@@ -438,6 +438,45 @@ def gen_region_selection(cfg, hyp, fr, ab):
     np.savez_compressed(os.path.join(OUT_DIR, "region_selection.npz"), **out)
 
 
+def gen_padding(cfg, hyp, fr, ab):
+    """FloatingRegionScore(padding_mode=...) for the three non-default modes nn.Conv2d accepts (floating_region.py:49,63; no
+    caller in the reference's tree passes one, so these are the reference's CLASS run directly): forward maps for several
+    branches and window sizes, the helper methods, and the first-round picks."""
+    H, W, C, O = 24, 40, 8, 19
+    cfg.MODEL.NUM_CLASSES = O
+    inp = make_inputs(hyp, H, W, C, O, 77)
+    out = {k: inp[k].numpy() for k in ("logit", "embed", "gt", "prior_active")}
+    out["meta_HWCO"] = np.array([H, W, C, O], dtype=np.int64)
+    combos = [("halo", "entropy", "radius", True, 3, 100), ("ripu5", "entropy", "ripu", False, 5, 100),
+              ("hyperK10", "entropy", "hyper", True, 3, 10), ("oracle", "oracle_acc", "oracle_ripu", False, 3, 100)]
+    for mode in ("reflect", "replicate", "circular"):
+        for tag, unc, pur, norm, size, K in combos:
+            frs = fr.FloatingRegionScore(in_channels=O, padding_mode=mode, size=size, purity_type=pur, K=K)
+            with torch.no_grad():
+                score, imp, uncm = frs(inp["logit"].clone(), decoder_out=inp["embed"].clone(), unc_type=unc, pur_type=pur,
+                                       normalize=norm, ground_truth=inp["gt"].clone())
+            key = f"{mode}__{tag}"
+            out[key + "__score"], out[key + "__impurity"], out[key + "__uncertainty"] = score.numpy().copy(), imp.numpy().copy(), uncm.numpy().copy()
+            out[key + "__params"] = np.array([size, K, int(norm)], dtype=np.int64)
+            active = inp["prior_active"].clone()
+            selected = torch.zeros(H, W, dtype=torch.bool)
+            active_mask = torch.full((H, W), 255, dtype=torch.int64)
+            s = score.clone()
+            s[active] = -float("inf")
+            picks, gap = run_selection(ab, s, 12, 1, 3, active, selected, active_mask, inp["gt"])
+            out[key + "__picks"], out[key + "__active_mask"] = picks, active_mask.numpy().copy()
+            out[key + "__min_rel_gap"] = np.array([gap], dtype=np.float64)
+            print(f"  padding/{key}: picks {len(picks)} min_rel_gap {gap:.3e}")
+        # helper methods with the mode (size 5 windows): box-summed entropy of given probabilities, window histogram impurity
+        frs = fr.FloatingRegionScore(in_channels=O, padding_mode=mode, size=5, purity_type="ripu")
+        with torch.no_grad():
+            p = torch.softmax(inp["logit"][0], dim=0)
+            out[f"{mode}__region_unc_k5"] = frs.compute_region_uncertainty("entropy", inp["logit"][0], p).numpy().copy()
+            imp, cnt = frs.compute_region_impurity(p.argmax(dim=0), O)
+            out[f"{mode}__imp_k5"], out[f"{mode}__cnt_k5"] = imp.numpy().copy(), cnt.numpy().copy()
+    np.savez_compressed(os.path.join(OUT_DIR, "padding.npz"), **out)
+
+
 def main():
     torch.set_num_threads(4)
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -452,6 +491,9 @@ def main():
         return
     if only == "losses":
         gen_losses()
+        return
+    if only == "padding":
+        gen_padding(cfg, hyp, fr, ab)
         return
     print("case A 32x64 C8 O19 (selection runs to exhaustion)")
     gen_case(cfg, hyp, fr, ab, "case_a_32x64_c8_o19", 32, 64, 8, 19, 11, 200, COMBOS)
@@ -473,6 +515,8 @@ def main():
     gen_losses()
     print("RegionSelection driver, 2 rounds")
     gen_region_selection(cfg, hyp, fr, ab)
+    print("padding modes of the two box windows")
+    gen_padding(cfg, hyp, fr, ab)
 
 
 if __name__ == "__main__":

@@ -86,9 +86,10 @@ def test_reference_error_behaviour():
     with pytest.raises(NotImplementedError, match="purity type 'bogus' not implemented"):   # :199-202
         frs(torch.zeros(1, 19, 4, 4), unc_type="entropy", pur_type="bogus")
     assert FloatingRegionScore(size=5, purity_type="hyper", K=7).purity_size == 3           # :54-55
-    # a padding mode no caller of the reference passes: refused with the reason, not silently zero-padded
-    with pytest.raises(NotImplementedError, match=r"padding_mode='zeros' only.*floating_region.py:49,63.*build.py:83-88"):
-        FloatingRegionScore(size=3, padding_mode="reflect")
+    # nn.Conv2d's own argument check (the reference forwards padding_mode to it, floating_region.py:49,63)
+    assert FloatingRegionScore(size=3, padding_mode="reflect").padding_mode == "reflect"
+    with pytest.raises(ValueError, match="padding_mode must be one of"):
+        FloatingRegionScore(size=3, padding_mode="mirror")
 
 
 def test_hypermlr_parameters_match_reference_names_and_dtypes():

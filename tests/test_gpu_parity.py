@@ -973,6 +973,59 @@ def test_lowres_exact_mode_with_whole_channel_chunks(dev, C, hf, wf, H, W):
         assert bits_equal(a[0][-1].cpu().numpy(), so) and bits_equal(a[1][-1].cpu().numpy(), io)
 
 
+@pytest.mark.parametrize("mode", ["reflect", "replicate", "circular"])
+def test_padding_modes_vs_reference_and_oracle(golden, dev, mode):
+    """FloatingRegionScore(padding_mode=...) on the device (the generic box / window-histogram kernels with the
+    tap index mapped into the image; the 3x3 fast paths are zero-padding only): bit-identical to the oracle, within 5e-6 of
+    the reference's own class (tests/golden/padding.npz), identical first-round picks; the helper methods and the batched /
+    low-resolution entry points take the mode too; torch's limits on the padding are reported as errors."""
+    from halo_amd import _lib
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import FloatingRegionScore, score_maps, score_maps_lowres
+    from oracle import halo_oracle as ho
+    d = golden("padding")
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    lg, em, gt = t(d["logit"], dev), t(d["embed"], dev), t(d["gt"], dev)
+    for tag, unc, pur in (("halo", "entropy", "radius"), ("ripu5", "entropy", "ripu"), ("hyperK10", "entropy", "hyper"),
+                          ("oracle", "oracle_acc", "oracle_ripu")):
+        key = f"{mode}__{tag}"
+        size, K, norm = (int(v) for v in d[key + "__params"])
+        frs = FloatingRegionScore(in_channels=O, padding_mode=mode, size=size, purity_type=pur, K=K)
+        s, i, u = frs(lg, em, unc_type=unc, pur_type=pur, normalize=bool(norm), ground_truth=gt)
+        so, io, uo = ho.floating_region_score(d["logit"], d["embed"], unc, pur, bool(norm), d["gt"], size=size, purity_type=pur, K=K,
+                                              padding_mode=mode)
+        assert bits_equal(s.cpu().numpy(), so) and bits_equal(i.cpu().numpy(), io) and bits_equal(u.cpu().numpy(), uo), key
+        assert max_abs_diff(s.cpu().numpy(), d[key + "__score"]) < 5e-6 and max_abs_diff(u.cpu().numpy(), d[key + "__uncertainty"]) < 5e-6, key
+        act = t(d["prior_active"], dev)[None].clone(); sel = torch.zeros_like(act)
+        am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+        sc = s[None].clone()
+        sc[act] = -float("inf")
+        picks, npk = greedy_select(sc, 12, 1, 3, act, sel, am, gt[None])
+        assert np.array_equal(picks[0, :int(npk[0]), :2].cpu().numpy(), d[key + "__picks"][:, :2]), key
+        assert np.array_equal(am[0].cpu().numpy(), d[key + "__active_mask"]), key
+    frs = FloatingRegionScore(in_channels=O, padding_mode=mode, size=5, purity_type="ripu")
+    p = torch.softmax(lg[0], dim=0)
+    assert max_abs_diff(frs.compute_region_uncertainty("entropy", lg[0], p).cpu().numpy(), d[f"{mode}__region_unc_k5"]) < 2.5e-5
+    imp, cnt = frs.compute_region_impurity(p.argmax(dim=0), O)
+    assert max_abs_diff(imp.cpu().numpy(), d[f"{mode}__imp_k5"]) < 1e-6 and np.array_equal(cnt.cpu().numpy(), d[f"{mode}__cnt_k5"])
+    # batched + low-resolution entry points: same mode, bit-identical to the oracle on the upsampled inputs
+    rng = np.random.default_rng(9)
+    logit_lr = rng.standard_normal((2, O, 8, 12)).astype(np.float32)
+    emb_lr = ho.expmap((rng.standard_normal((2, 6, 8, 12)) * 0.2).astype(np.float32), 1.0, dim=1)
+    a = score_maps_lowres(t(logit_lr, dev), t(emb_lr, dev), (32, 48), "entropy", "radius", True, None, ksize=3, mode="exact", padding_mode=mode)
+    for b in range(2):
+        so, io, uo = ho.floating_region_score(ho.bilinear(logit_lr[b:b + 1], (32, 48)), ho.bilinear(emb_lr[b:b + 1], (32, 48)), "entropy",
+                                              "radius", True, None, size=3, purity_type="radius", padding_mode=mode)
+        assert bits_equal(a[0][b].cpu().numpy(), so) and bits_equal(a[2][b].cpu().numpy(), uo)
+    # torch refuses a reflect padding that is not smaller than the map (and a circular one larger than it)
+    tiny = torch.zeros((1, O, 2, 2), device=dev)
+    if mode == "reflect":
+        with pytest.raises(_lib.HaloHipError, match="reflect"):
+            score_maps(tiny, None, "entropy", "ripu", False, None, size=5, padding_mode=mode)
+    with pytest.raises(ValueError):
+        score_maps(tiny, None, "entropy", "ripu", False, None, size=3, padding_mode="mirror")
+
+
 def test_lowres_gram_mode_on_degenerate_grids(dev):
     """single-row / single-column / single-pixel embeddings, odd sizes around the 63-column wave width"""
     from halo_amd.core.active.floating_region import score_maps_lowres

@@ -223,3 +223,31 @@ def test_gram_radius_is_guarded_against_cancellation(shape):
     (m_g, a_g, s_g, p_g), = ho.region_selection(cfg, [dict(im)], lowres_mode="gram")
     assert len(p_e) > 0 and np.array_equal(p_e[:, :2], p_g[:, :2]) and np.array_equal(m_e, m_g) and np.array_equal(a_e, a_g)
     assert np.max(np.abs(p_e[:, 2] - p_g[:, 2])) <= 1e-10
+
+
+@pytest.mark.parametrize("mode", ["reflect", "replicate", "circular"])
+def test_padding_modes_vs_reference(golden, mode):
+    """FloatingRegionScore(padding_mode=...) -- forwarded to the two nn.Conv2d box filters in the reference
+    (floating_region.py:49,63), default 'zeros' in every caller of its tree -- against the reference's own outputs
+    (tests/golden/padding.npz: the reference's class run with each mode): maps within 5e-6, the quantised / arg-max
+    branches' counts exactly k*k everywhere (padded taps are image pixels), first-round picks identical."""
+    d = golden("padding")
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    for tag, unc, pur in (("halo", "entropy", "radius"), ("ripu5", "entropy", "ripu"), ("hyperK10", "entropy", "hyper"),
+                          ("oracle", "oracle_acc", "oracle_ripu")):
+        key = f"{mode}__{tag}"
+        size, K, norm = (int(v) for v in d[key + "__params"])
+        s, i, u = ho.floating_region_score(d["logit"], d["embed"], unc, pur, bool(norm), d["gt"], size=size, purity_type=pur, K=K,
+                                           padding_mode=mode)
+        assert s.dtype == d[key + "__score"].dtype
+        assert max_abs_diff(u, d[key + "__uncertainty"]) < 5e-6 and max_abs_diff(i, d[key + "__impurity"]) < 5e-6, key
+        assert max_abs_diff(s, d[key + "__score"]) < 5e-6, key
+        act = d["prior_active"].copy(); sel = np.zeros((H, W), bool); am = np.full((H, W), 255, np.int64)
+        s[act] = -np.inf
+        _, _, _, _, picks = ho.select_pixels_to_label(s, 12, 1, 3, act, sel, am, d["gt"], True)
+        assert np.array_equal(picks[:, :2], d[key + "__picks"][:, :2]), key
+        assert np.array_equal(am, d[key + "__active_mask"]), key
+    p = ho.softmax(d["logit"][0])
+    assert max_abs_diff(ho.uncertainty_from_probs(p, "entropy", None, 5, True, padding_mode=mode), d[f"{mode}__region_unc_k5"]) < 2.5e-5    # 25-tap float32 sums up to ~20: a few ulps of 16 (1.9e-6)
+    imp, cnt = ho.region_impurity(p.argmax(0), O, 5, padding_mode=mode)
+    assert max_abs_diff(imp, d[f"{mode}__imp_k5"]) < 1e-6 and np.array_equal(cnt, d[f"{mode}__cnt_k5"]) and float(cnt.min()) == 25.0
