@@ -4,7 +4,7 @@ import threading
 
 from . import _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lock = threading.Lock()
 _handle = None
 
@@ -25,6 +25,18 @@ def lib():
                 h.halo_png_gray8_encode.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t]
                 h.halo_png_gray8_write.restype = C.c_int
                 h.halo_png_gray8_write.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+                h.halo_crc32.restype = C.c_uint32
+                h.halo_crc32.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+                h.halo_compose_mask.restype = C.c_int
+                h.halo_compose_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                                C.c_int64, C.c_int64]
+                h.halo_write_indicator.restype = C.c_int
+                h.halo_write_indicator.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                   C.c_size_t, C.c_void_p, C.c_void_p]
+                h.halo_retire_image.restype = C.c_int
+                h.halo_retire_image.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                                                C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
                 _handle = h
     return _handle
 
@@ -36,3 +48,25 @@ def png_gray8_write(path, arr):
     rc = lib().halo_png_gray8_write(os.fsencode(path), arr.ctypes.data, arr.shape[0], arr.shape[1], arr.strides[0])
     if rc != 0:
         raise OSError("halo_png_gray8_write(%r) failed (%d)" % (path, rc))
+
+
+def retire_image(path_png, path_indicator, origin_mask, origin_label, picks, k, radius, active, selected, template):
+    """One image's two files in one GIL-free call (halo_retire_image): origin_mask / origin_label (H, W) contiguous integer
+    numpy arrays, picks (>= k, 3) contiguous float64, active / selected (H, W) contiguous bool / uint8 arrays (pinned staging
+    memory is fine), template: the shape's _IndicatorTemplate (raw bytes + field offsets) or None to skip the indicator."""
+    import os
+    H, W = origin_mask.shape
+    for a in (origin_mask, origin_label, active, selected):
+        assert a.shape == (H, W) and a.flags["C_CONTIGUOUS"]
+    assert picks.dtype.itemsize == 8 and picks.flags["C_CONTIGUOUS"] and picks.shape[0] >= k and (k == 0 or picks.shape[1] == 3)
+    if template is not None:
+        tpl, tlen, off_a, off_s, fa, fs = template.raw.ctypes.data, template.raw.size, template.off["active"], template.off["selected"], \
+            template.crc["active"].ctypes.data, template.crc["selected"].ctypes.data
+        pind = os.fsencode(path_indicator)
+    else:
+        tpl, tlen, off_a, off_s, fa, fs, pind = None, 0, 0, 0, None, None, None
+    rc = lib().halo_retire_image(os.fsencode(path_png), pind, origin_mask.ctypes.data, origin_mask.dtype.itemsize, origin_label.ctypes.data,
+                                 origin_label.dtype.itemsize, H, W, picks.ctypes.data, int(k), int(radius), active.ctypes.data,
+                                 selected.ctypes.data, tpl, tlen, off_a, off_s, fa, fs)
+    if rc != 0:
+        raise OSError("halo_retire_image(%r, %r) failed (%d)" % (path_png, path_indicator, rc))

@@ -164,18 +164,17 @@ class AcquisitionParams:
 class _InFlight:
     """One loader batch (b images of one label size, b = 1 in the reference) whose staging, scoring, selection and device->host
     copies have been enqueued on a side stream."""
-    __slots__ = ("done", "keep", "picks", "npk", "slot", "buf", "b", "left", "lock")
+    __slots__ = ("done", "keep", "picks", "npk", "slot", "buf", "b", "left", "lock", "table", "radius")
 
 
 class _SlotBuffers:
     """Staging memory of one pipeline slot for b images of H x W labels, allocated once and reused by every batch of that shape
     that passes through the slot (pinning host pages costs milliseconds; per-image device allocations cost allocator traffic on
-    the launching thread): device masks, pinned outputs, and pinned uint8 inputs for the optional narrow staging."""
+    the launching thread): device masks and pinned outputs."""
 
     def __init__(self, b, H, W, dev):
         shp = (b, H, W)
         self.shape, self.dev = shp, dev
-        self.in_mask = self.in_gt = self.d_u8 = None              # narrow staging only (narrow_inputs())
         self.d_amask = torch.empty(shp, dtype=torch.int64, device=dev)
         self.d_gt = torch.empty(shp, dtype=torch.int64, device=dev)
         self.d_active = torch.empty(shp, dtype=torch.bool, device=dev)
@@ -185,13 +184,13 @@ class _SlotBuffers:
         self.out_active = torch.empty(shp, dtype=torch.bool, pin_memory=True)
         self.out_selected = torch.empty(shp, dtype=torch.bool, pin_memory=True)
         self.out_npk = torch.empty((b,), dtype=torch.int32, pin_memory=True)
+        self.out_picks = None
 
-    def narrow_inputs(self):
-        if self.in_mask is None:
-            self.in_mask = torch.empty(self.shape, dtype=torch.uint8, pin_memory=True)     # the loader's masks, low byte
-            self.in_gt = torch.empty(self.shape, dtype=torch.uint8, pin_memory=True)
-            self.d_u8 = torch.empty((2,) + self.shape, dtype=torch.uint8, device=self.dev)
-        return self.in_mask, self.in_gt, self.d_u8
+    def picks_out(self, n):
+        """pinned (b, n, 3) float64 for the round's pick tables"""
+        if self.out_picks is None or self.out_picks.shape[1] != n:
+            self.out_picks = torch.empty((self.shape[0], int(n), 3), dtype=torch.float64, pin_memory=True)
+        return self.out_picks
 
 
 class _Slot:
@@ -242,85 +241,95 @@ def _side_streams(dev, n):
     return have[:n]
 
 
-def _low_byte_into(dst_pinned, src):
-    """dst (uint8, pinned) <- the low byte of every element of the loader's integer mask `src` (CPU tensor, any integer dtype):
-    what the reference's uint8 PNG keeps of it anyway (to_np_array, build.py:67-68,162: numpy's int64 -> uint8 cast wraps modulo
-    256).  numpy on purpose: the conversion releases the GIL and wakes no intra-op thread pool (a torch CPU op here starts a
-    pool as wide as the host, which a cgroup quota then throttles)."""
-    np.copyto(dst_pinned.numpy(), src.numpy(), casting="unsafe")
-
-
 def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in, selected_in, dev, slot, lowres_mode=None, stats=None,
-            narrow_masks=False):
-    """Enqueue b images of one label size (build.py:113-166 for each) on the slot's stream: stage their masks, score -> mask ->
-    select as ONE batch, copy the results back into the slot's pinned buffers.  Fully asynchronous: `rec.done` fires when the
-    pinned buffers hold the final mask / indicator maps of all b images.
+            mask_staging="table"):
+    """Enqueue b images of one label size (build.py:113-166 for each) on the slot's stream: stage what the device needs, score ->
+    mask -> select as ONE batch, copy the results back into the slot's pinned buffers.  Fully asynchronous: `rec.done` fires
+    when the pinned buffers hold the results of all b images.
 
-    Staging: the loader hands `origin_mask` / `origin_label` as int64, 16.8 MB each per 1024x2048 image.  They
-    are copied straight from the loader's (pinned) tensors into the slot's persistent device buffers: 37.7 MB and 0.69 ms of
-    DMA per image, no CPU work, no allocation.  `narrow_masks=True` instead sends their low bytes (all that can reach the files
-    the round writes: the reference casts the final mask to uint8, build.py:67-68,162, and the selection copies labels into it
-    unchanged, build.py:58-62; the label map keeps its width when the scorer itself reads it: oracle_acc / oracle_ripu)
-    through pinned uint8 buffers and widens them on the device -- 8.4 MB over PCIe, but the narrowing costs the launching thread
-    0.5-0.7 ms per mask (a cold 16.8 MB read at one core's DRAM rate) and measured SLOWER end to end
-    (profiles/r04_region_selection_timing.txt); it is for hosts whose PCIe link is the scarcer resource."""
+    What crosses PCIe.  The loader hands `origin_mask` / `origin_label` as int64, 16.8 MB each per 1024x2048
+    image, and the reference copies both to the GPU only to write `active_mask[window] = ground_truth[window]` at the round's
+    <= 2331 picks (build.py:58-62) before the mask comes back and is cast to uint8 (build.py:67-68,162).
+      mask_staging="table" (default): neither map travels.  The device scores and selects (it needs `active` and `selected`:
+        4.2 MB in, 4.2 MB + the 56 KB pick table out); the writer thread composes the file's mask on the host: the low byte of
+        `origin_mask` (what the uint8 cast keeps) with the labels of the pick table's windows copied in -- ~21 000 pixels.
+        The label map still goes to the device when the scorer itself reads it (oracle_acc / oracle_ripu).
+      mask_staging="device": the reference's data flow -- both maps are DMA'd from the loader's (pinned) tensors into the slot's
+        device buffers (37.7 MB, 0.69 ms per image), the selection kernel writes the windows, the mask returns as uint8.
+    Same files either way (tests/test_gpu_parity.py runs both against the reference's PNGs)."""
     import time
     rec = _InFlight()
     rec.slot, rec.b = slot, int(origin_mask.shape[0])
     H, W = int(origin_mask.shape[-2]), int(origin_mask.shape[-1])
     buf = rec.buf = slot.buffers(rec.b, H, W, dev)
     stream = slot.stream
-    t0 = time.perf_counter()
-    scorer_reads_gt = prm.unc == "oracle_acc" or prm.pur == "oracle_ripu"
-    narrow_mask = narrow_masks and (not origin_mask.is_cuda) and origin_mask.dtype != torch.uint8 and not origin_mask.dtype.is_floating_point
-    narrow_gt = narrow_masks and (not origin_label.is_cuda) and origin_label.dtype != torch.uint8 \
-        and not origin_label.dtype.is_floating_point and not scorer_reads_gt
-    if narrow_mask or narrow_gt:
-        in_mask, in_gt, d_u8 = buf.narrow_inputs()
-        if narrow_mask:
-            _low_byte_into(in_mask, origin_mask)
-        if narrow_gt:
-            _low_byte_into(in_gt, origin_label)
     t1 = time.perf_counter()
+    scorer_reads_gt = prm.unc == "oracle_acc" or prm.pur == "oracle_ripu"
+    # masks that already live on the device are composed there
+    rec.table = mask_staging == "table" and not origin_mask.is_cuda and not origin_label.is_cuda
+    n_regions = prm.regions(size[0] * size[1])
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))             # the head outputs are complete from here on
     with torch.cuda.stream(stream):
         stream.wait_event(ready)
-        if narrow_mask:
-            d_u8[0].copy_(in_mask, non_blocking=True)
-            buf.d_amask.copy_(d_u8[0])                       # widen on the device
-        else:
+        if not rec.table:
             buf.d_amask.copy_(origin_mask, non_blocking=True)
-        if narrow_gt:
-            d_u8[1].copy_(in_gt, non_blocking=True)
-            buf.d_gt.copy_(d_u8[1])
-        else:
+        if not rec.table or scorer_reads_gt:
             buf.d_gt.copy_(origin_label, non_blocking=True)
         buf.d_active.copy_(active_in, non_blocking=True)
         buf.d_selected.copy_(selected_in, non_blocking=True)
+        # table staging: the selection kernel still writes its windows (active_mask[window] = ground_truth[window]) -- into the
+        # slot's scratch mask, from itself when no label map is resident: nobody reads that buffer
+        gt_dev = buf.d_gt if (not rec.table or scorer_reads_gt) else buf.d_amask
         # the two F.interpolate(align_corners=True) calls of build.py:122-135 are fused into the scorer:
         # the C x H x W float64 embedding (4.3 GB at C=256) is never written or read
         rec.picks, rec.npk = acquire_batch_lowres(
-                             logits_lr, embed_lr, size, buf.d_gt, buf.d_active, buf.d_selected, buf.d_amask,
+                             logits_lr, embed_lr, size, gt_dev, buf.d_active, buf.d_selected, buf.d_amask,
                              unc_type=prm.unc, pur_type=prm.pur, normalize=prm.normalize,
-                             n_regions=prm.regions(size[0] * size[1]), active_radius=prm.radius,
+                             n_regions=n_regions, active_radius=prm.radius,
                              mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
                              K=prm.K, c=prm.scorer.mapper.c, lowres_mode=lowres_mode)
-        # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
-        # reference's cast-after-copy, build.py:67-68,162)
-        buf.d_mask8.copy_(buf.d_amask)
-        buf.out_mask.copy_(buf.d_mask8, non_blocking=True)
+        if rec.table:
+            buf.picks_out(rec.picks.shape[1]).copy_(rec.picks, non_blocking=True)
+        else:
+            # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
+            # reference's cast-after-copy, build.py:67-68,162)
+            buf.d_mask8.copy_(buf.d_amask)
+            buf.out_mask.copy_(buf.d_mask8, non_blocking=True)
         buf.out_active.copy_(buf.d_active, non_blocking=True)
         buf.out_selected.copy_(buf.d_selected, non_blocking=True)
         buf.out_npk.copy_(rec.npk, non_blocking=True)       # (a .item() in the writer thread would queue behind the backbone's kernels)
         rec.done = torch.cuda.Event(blocking=True)           # the writer threads sleep on it instead of spinning
         rec.done.record(stream)
-    # what the side stream still reads: the head outputs and the loader's (pinned) tensors, kept alive until the batch is retired
+    # what the side stream and the writer threads still read: the head outputs and the loader's tensors, kept alive until the
+    # batch is retired
     rec.keep = (logits_lr, embed_lr, origin_mask, origin_label, active_in, selected_in)
+    rec.radius = prm.radius
     if stats is not None:
-        stats["main_stage_s"] += t1 - t0
         stats["main_launch_s"] += time.perf_counter() - t1
     return rec
+
+
+def compose_mask(origin_mask, origin_label, picks, active_radius):
+    """The uint8 mask file of one image from host data and the pick table (mask_staging="table"): the low byte of every
+    `origin_mask` value -- what the reference's uint8 cast keeps (to_np_array, build.py:67-68) -- with
+    `ground_truth[h-r : h+r+1, w-r : w+r+1]` copied in around every pick (h, w) of the round, windows clipped at the image
+    borders as the reference's slices are (build.py:52-62).  numpy throughout: the big copies release the GIL.
+    origin_mask, origin_label: (H, W) integer arrays; picks: (k, >=2) rows (h, w, ...)."""
+    H, W = origin_mask.shape
+    mask = np.empty((H, W), dtype=np.uint8)
+    np.copyto(mask, origin_mask, casting="unsafe")               # int64 -> uint8 wraps modulo 256, like numpy's astype
+    k = picks.shape[0]
+    if k:
+        r = int(active_radius)
+        d = np.arange(-r, r + 1, dtype=np.int64)
+        rows = picks[:, 0].astype(np.int64)[:, None, None] + d[None, :, None]
+        cols = picks[:, 1].astype(np.int64)[:, None, None] + d[None, None, :]
+        rows, cols = np.broadcast_arrays(rows, cols)
+        ok = (rows >= 0) & (rows < H) & (cols >= 0) & (cols < W)
+        rr, cc = rows[ok], cols[ok]
+        mask[rr, cc] = origin_label[rr, cc].astype(np.uint8)     # the same wrap for the labels
+    return mask
 
 
 _PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
@@ -372,6 +381,106 @@ def write_png_gray8(path, arr):
         _write_png_gray8_zlib(path, arr)
 
 
+class _IndicatorTemplate:
+    """The bytes torch.save writes for {'active': bool (H, W), 'selected': bool (H, W)} (build.py:165-166), produced ONCE per
+    shape by torch.save itself: the zip archive stores the two tensor payloads uncompressed, so an image's file is the template
+    with the two payloads and their CRC-32 fields (data descriptor or local header, and central directory) replaced -- which
+    libhalo_host.so does without the interpreter lock (halo_write_indicator).  The format is whatever the installed torch
+    writes; the parsed template is checked once by torch.load on a rendered random pair, and any surprise (compressed payloads,
+    a layout this parser does not know) disables it: the writer then calls torch.save."""
+
+    _cache = {}
+    _lock = None
+
+    @classmethod
+    def get(cls, shape):
+        import threading
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        key = tuple(int(v) for v in shape)
+        tpl = cls._cache.get(key)
+        if tpl is None:
+            with cls._lock:
+                tpl = cls._cache.get(key)
+                if tpl is None:
+                    if len(cls._cache) >= 8:
+                        cls._cache.pop(next(iter(cls._cache)))
+                    tpl = cls._cache[key] = cls(key)
+        return tpl
+
+    def __init__(self, shape):
+        self.ok, self.shape = False, shape
+        try:
+            self._build(shape)
+            self.ok = self._self_check()
+        except Exception:
+            self.ok = False
+
+    def _build(self, shape):
+        import io
+        import zipfile
+        n = int(np.prod(shape))
+        a = torch.zeros(shape, dtype=torch.bool)
+        b = torch.zeros(shape, dtype=torch.bool)
+        a.view(-1)[0] = True                                     # two different payloads: two different CRCs to tell apart
+        buf = io.BytesIO()
+        torch.save({"active": a, "selected": b}, buf)
+        raw = buf.getvalue()
+        self.raw = np.frombuffer(raw, dtype=np.uint8).copy()
+        zf = zipfile.ZipFile(io.BytesIO(raw))
+        want = {a.numpy().tobytes(): "active", b.numpy().tobytes(): "selected"}
+        self.off, self.crc = {}, {}                               # name -> payload offset, the two CRC field offsets
+        central, pos = {}, zf.start_dir
+        for _ in zf.infolist():                                   # central directory: signature, ..., crc at +16, lengths at +28..
+            if raw[pos:pos + 4] != b"PK\x01\x02":
+                raise ValueError("central directory entry expected")
+            fl, el, cl = struct.unpack_from("<HHH", raw, pos + 28)
+            central[raw[pos + 46:pos + 46 + fl].decode("utf-8")] = pos + 16
+            pos += 46 + fl + el + cl
+        for info in zf.infolist():
+            if info.file_size != n or "/data/" not in "/" + info.filename:
+                continue
+            name = want.get(zf.read(info.filename))
+            if name is None:
+                continue
+            if info.compress_type != zipfile.ZIP_STORED or info.file_size >= 0xffffffff:
+                raise ValueError("stored 32-bit zip entries expected")
+            sig, _, flag, _, _, _, _, _, _, fl, el = struct.unpack_from("<IHHHHHIIIHH", raw, info.header_offset)
+            if sig != 0x04034b50:
+                raise ValueError("local header expected")
+            off = info.header_offset + 30 + fl + el
+            if flag & 8:                                          # data descriptor behind the payload: [signature] crc sizes
+                d = off + n
+                second = d + 4 if raw[d:d + 4] == b"PK\x07\x08" else d
+            else:
+                second = info.header_offset + 14
+            fields = [central[info.filename], second]
+            for c in fields:
+                if struct.unpack_from("<I", raw, c)[0] != info.CRC:
+                    raise ValueError("CRC field not where expected")
+            self.off[name], self.crc[name] = off, np.array(fields, dtype=np.uint64)
+        if set(self.off) != {"active", "selected"}:
+            raise ValueError("payload records not found")
+
+    def _self_check(self):
+        import io
+        import tempfile
+        from ... import _hostlib
+        rng = np.random.default_rng(7)
+        a, b = np.ascontiguousarray(rng.random(self.shape) < 0.3), np.ascontiguousarray(rng.random(self.shape) < 0.6)
+        with tempfile.TemporaryDirectory(prefix="halo_tpl_") as tmp:
+            p = os.path.join(tmp, "i.pth")
+            rc = _hostlib.lib().halo_write_indicator(os.fsencode(p), self.raw.ctypes.data, self.raw.size, a.ctypes.data, b.ctypes.data, a.size,
+                                                     self.off["active"], self.off["selected"], self.crc["active"].ctypes.data,
+                                                     self.crc["selected"].ctypes.data)
+            if rc != 0:
+                return False
+            got = torch.load(p)
+        return (set(got) == {"active", "selected"} and got["active"].dtype == torch.bool and got["selected"].dtype == torch.bool
+                and tuple(got["active"].shape) == tuple(self.shape) and np.array_equal(got["active"].numpy(), a)
+                and np.array_equal(got["selected"].numpy(), b))
+
+
 def _persist(mask_np, active, selected, path_mask, path_indicator, stats=None):
     """build.py:162-166: uint8 mode-L PNG + torch.save'd indicator dict (what cityscapes.py:234-251 reads back)."""
     import time
@@ -388,51 +497,92 @@ def _persist(mask_np, active, selected, path_mask, path_indicator, stats=None):
             stats["writer_save_s"] += time.perf_counter() - t1
 
 
+def _native_retire():
+    """the one-call native writer (libhalo_host.so), or None: HALO_RETIRE_PYTHON=1 (A/B switch) or no host library"""
+    if os.environ.get("HALO_RETIRE_PYTHON"):
+        return None
+    try:
+        from ... import _hostlib
+        _hostlib.lib()
+        return _hostlib.retire_image
+    except Exception:
+        return None
+
+
 def _finish(rec, i, paths, slots, stats=None):
-    """Writer-thread half of image i of a batch: wait for the batch's copies, encode the mask straight out of the slot's pinned
-    buffer, take the two indicator maps out of theirs (the slot goes back when the last image of the batch has been taken),
-    write the indicator."""
+    """Writer-thread half of image i of a batch: wait for the batch's copies, turn the image's results in the slot's pinned
+    buffers into its two files (the slot goes back when the last image of the batch is done with the buffers)."""
     import time
     t0 = time.perf_counter()
+    native = False
+    t_png = t_copy = t_save = 0.0
     try:
         rec.done.synchronize()
         t1 = time.perf_counter()
         buf = rec.buf
-        # the PNG encoder makes ONE pass over the mask: it reads the pinned buffer directly.  The indicator must hold plain
-        # tensors as from `.cpu()`: one streaming copy each (numpy on purpose: a torch CPU op here would wake an intra-op
-        # thread pool as wide as the host)
-        mask = buf.out_mask[i].numpy()
-        direct = mask.size and str(paths[0]).lower().endswith(".png")
-        if direct:
-            write_png_gray8(paths[0], mask)
-        else:
-            mask = mask.copy()
-        t2 = time.perf_counter()
-        active, selected = torch.from_numpy(buf.out_active[i].numpy().copy()), torch.from_numpy(buf.out_selected[i].numpy().copy())
-        out = (rec.picks[i], int(buf.out_npk[i]))
+        k = int(buf.out_npk[i])
+        is_png = bool(buf.out_mask[i].numel()) and str(paths[0]).lower().endswith(".png")
+        mask = active = selected = None
+        retire = _native_retire() if (rec.table and is_png) else None
+        if retire is not None:
+            # mask_staging="table": ONE call without the interpreter lock composes the mask from the loader's maps and the pick
+            # table, encodes it, and writes the indicator from the pinned maps through the shape's template
+            om, gt = rec.keep[2][i].numpy(), rec.keep[3][i].numpy()
+            if om.flags["C_CONTIGUOUS"] and gt.flags["C_CONTIGUOUS"] and om.dtype.kind in "iub" and gt.dtype.kind in "iub":
+                tpl = _IndicatorTemplate.get(om.shape)
+                retire(paths[0], paths[1], om, gt, buf.out_picks[i].numpy(), k, rec.radius, buf.out_active[i].numpy(),
+                       buf.out_selected[i].numpy(), tpl if tpl.ok else None)
+                native = True
+                if not tpl.ok:
+                    active, selected = torch.from_numpy(buf.out_active[i].numpy().copy()), torch.from_numpy(buf.out_selected[i].numpy().copy())
+                t_png = time.perf_counter() - t1
+        if not native:
+            if rec.table:
+                table = buf.out_picks[i, :k].numpy().copy()
+                origin_mask, origin_label = rec.keep[2][i].numpy(), rec.keep[3][i].numpy()
+            elif is_png:
+                # the PNG encoder makes ONE pass over the mask: it reads the pinned buffer directly
+                write_png_gray8(paths[0], buf.out_mask[i].numpy())
+            else:
+                mask = buf.out_mask[i].numpy().copy()
+            t2 = time.perf_counter()
+            t_png = t2 - t1
+            # the indicator must hold plain tensors as from `.cpu()`: one streaming copy each (numpy on purpose: a torch CPU op
+            # here would wake an intra-op thread pool as wide as the host)
+            active, selected = torch.from_numpy(buf.out_active[i].numpy().copy()), torch.from_numpy(buf.out_selected[i].numpy().copy())
+            t_copy = time.perf_counter() - t2
+        out = (rec.picks[i], k)
     finally:
         with rec.lock:
             rec.left -= 1
             last = rec.left == 0
         if last:
-            rec.keep = rec.buf = None
+            rec.keep = rec.buf = None                         # (numpy views taken above keep the loader's tensors alive)
             slots.put(rec.slot)
     t3 = time.perf_counter()
-    if not direct:
-        Image.fromarray(mask).save(paths[0])
+    if not native:
+        if rec.table:
+            mask = compose_mask(origin_mask, origin_label, table, rec.radius)
+            if is_png:
+                write_png_gray8(paths[0], mask)
+        if mask is not None and not is_png:
+            Image.fromarray(mask).save(paths[0])
+        t_png += time.perf_counter() - t3
     t4 = time.perf_counter()
-    torch.save({"active": active, "selected": selected}, paths[1])
+    if active is not None:
+        torch.save({"active": active, "selected": selected}, paths[1])
+        t_save = time.perf_counter() - t4
     if stats is not None:
         with stats["lock"]:
             stats["writer_event_wait_s"] += t1 - t0
-            stats["writer_png_s"] += (t2 - t1) + (t4 - t3)
-            stats["writer_copy_s"] += t3 - t2
-            stats["writer_save_s"] += time.perf_counter() - t4
+            stats["writer_png_s"] += t_png
+            stats["writer_copy_s"] += t_copy
+            stats["writer_save_s"] += t_save
     return out
 
 
 def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=8, writer_threads=None,
-                    streams=4, return_tables=False, lowres_mode=None, stats=None, narrow_masks=False):
+                    streams=4, return_tables=False, lowres_mode=None, stats=None, mask_staging=None):
     """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
     at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
     every file on disk when the call returns.  Returns None like the reference, or -- keyword-only
@@ -452,13 +602,17 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     per-cell Gram terms (floating_region.score_maps_lowres: bit-identical to its oracle twin, squared norms within 1.3e-10 of
     the exact order, the reference's files on every test vector -- but not the reference's evaluation order).
     `stats`: an optional dict that receives where the host time went (seconds per phase, main thread and writers);
-    `narrow_masks`: see _launch (default False: the loader's int64 masks are DMA'd as they are)."""
+    `mask_staging`: "table" (default; environment HALO_MASK_STAGING) or "device" -- whether the int64 mask / label maps travel to
+    the GPU at all (see _launch): same files either way."""
     import queue
     import threading
     import time
     from concurrent.futures import ThreadPoolExecutor
     prm = AcquisitionParams(cfg)
     dev = torch.device("cuda", torch.cuda.current_device())
+    mask_staging = os.environ.get("HALO_MASK_STAGING", "table") if mask_staging is None else mask_staging
+    if mask_staging not in ("table", "device"):
+        raise ValueError("mask_staging must be 'table' or 'device', got %r" % (mask_staging,))
     if writer_threads is None:
         # this rank's share of the usable host cores (8 ranks on a 16-core quota: 2 writers each, not 8 x 8 threads)
         from ..._host import host_threads_per_rank
@@ -507,7 +661,7 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
                     try:
                         rec = _launch(prm, logits_lr[lo:hi], embed_lr[lo:hi], sizes[lo], batch["origin_mask"][lo:hi],
                                       batch["origin_label"][lo:hi], batch["active"][lo:hi], batch["selected"][lo:hi], dev, slot,
-                                      lowres_mode, stats, narrow_masks)
+                                      lowres_mode, stats, mask_staging)
                     except BaseException:
                         slots.put(slot)
                         raise

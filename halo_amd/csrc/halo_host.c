@@ -11,35 +11,134 @@
  * sent as its first byte + distance-1 matches of up to 258 bytes.  Runs are found 8 bytes at a time and the Adler-32 of a
  * run is a closed form, so the cost is proportional to the number of runs, not pixels: ~0.3 ms per mask.  Any decoder
  * (libpng, PIL) reads the result; an image without runs still encodes correctly (9 bits per pixel at worst).
+ *
+ * halo_retire_image: everything the round writes for one image, in ONE call that holds no interpreter lock -- the mask composed
+ * from host data and the pick table (the low byte of origin_mask with the labels of the picks' windows, build.py:52-62,67-68),
+ * its PNG, and the indicator file as a per-shape template of torch.save's own bytes with the two payloads and their CRC-32
+ * fields replaced (halo_amd/core/active/build.py:_IndicatorTemplate).  Eight Python writer threads doing the same through
+ * numpy / zlib / torch.save spend ~1 ms per image holding the GIL (torch.save's record writes), which bounded RegionSelection
+ * at ~1 ms per image whatever else was improved (profiles/r04_region_selection_timing.txt).
  */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
-#define HALO_HOST_ABI 1
+#define HALO_HOST_ABI 2
 
 int halo_host_version(void) { return HALO_HOST_ABI; }
 
-/* ---- CRC-32 (IEEE 802.3, as PNG chunks use it), byte-wise table ---- */
-static uint32_t crc_table[256];
+/* ---- CRC-32 (IEEE 802.3: PNG chunks, zip entries).  Slicing-by-8 tables; on x86-64 with PCLMULQDQ the bulk of a long buffer
+ * goes through the carry-less-multiplication folding of Gopal et al., "Fast CRC Computation for Generic Polynomials Using
+ * PCLMULQDQ" (64 bytes per iteration, ~10 bytes per cycle), which tests/test_abi.py checks against zlib on random lengths. ---- */
+static uint32_t crc_table[8][256];
 static int crc_ready = 0;
 static void crc_init(void)
 {
     for (uint32_t n = 0; n < 256; ++n) {
         uint32_t c = n;
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-        crc_table[n] = c;
+        crc_table[0][n] = c;
     }
+    for (uint32_t n = 0; n < 256; ++n)
+        for (int t = 1; t < 8; ++t) crc_table[t][n] = crc_table[0][crc_table[t - 1][n] & 0xffu] ^ (crc_table[t - 1][n] >> 8);
     crc_ready = 1;
 }
-static uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n)
+/* raw register update (no pre/post inversion) */
+static uint32_t crc_tables_raw(uint32_t crc, const uint8_t *p, size_t n)
 {
     if (!crc_ready) crc_init();                     /* idempotent: a race between threads writes the same values */
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        v ^= crc;
+        crc = crc_table[7][v & 0xff] ^ crc_table[6][(v >> 8) & 0xff] ^ crc_table[5][(v >> 16) & 0xff] ^ crc_table[4][(v >> 24) & 0xff] ^
+              crc_table[3][(v >> 32) & 0xff] ^ crc_table[2][(v >> 40) & 0xff] ^ crc_table[1][(v >> 48) & 0xff] ^ crc_table[0][v >> 56];
+        p += 8; n -= 8;
+    }
+    while (n--) crc = crc_table[0][(crc ^ *p++) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+#if defined(__x86_64__)
+/* len >= 64 and a multiple of 16 */
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc_clmul_raw(uint32_t crc, const uint8_t *buf, size_t len)
+{
+    static const uint64_t __attribute__((aligned(16))) k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+    static const uint64_t __attribute__((aligned(16))) k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+    static const uint64_t __attribute__((aligned(16))) k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+    static const uint64_t __attribute__((aligned(16))) poly[2] = {0x01db710641ull, 0x01f7011641ull};
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00));
+    x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20));
+    x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i *)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64) {                              /* fold four 128-bit lanes over the next 64 bytes */
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i *)k3k4);      /* fold the four lanes into one */
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {                              /* remaining 16-byte blocks */
+        x2 = _mm_loadu_si128((const __m128i *)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);         /* 128 -> 64 bits */
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i *)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i *)poly);      /* Barrett reduction to 32 bits */
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+static int have_clmul(void)
+{
+    static int state = -1;
+    if (state < 0) state = (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) ? 1 : 0;
+    return state;
+}
+#endif
+static int crc_force_tables = 0;                     /* test switch: halo_crc32_mode(1) */
+void halo_crc32_mode(int tables_only) { crc_force_tables = tables_only; }
+static uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n)
+{
     crc = ~crc;
-    for (size_t i = 0; i < n; ++i) crc = crc_table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+#if defined(__x86_64__)
+    if (n >= 256 && !crc_force_tables && have_clmul()) {
+        const size_t bulk = n & ~(size_t)15;
+        crc = crc_clmul_raw(crc, p, bulk);
+        p += bulk; n -= bulk;
+    }
+#endif
+    crc = crc_tables_raw(crc, p, n);
     return ~crc;
 }
+/* zlib.crc32(buf, crc) */
+uint32_t halo_crc32(uint32_t crc, const uint8_t *buf, size_t len) { return buf ? crc32_update(crc, buf, len) : crc; }
 
 static void put_be32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
 
@@ -222,5 +321,93 @@ int halo_png_gray8_write(const char *path, const uint8_t *img, int64_t H, int64_
         }
     }
     free(buf);
+    return rc;
+}
+
+/* ---- one image's files from host data, the pick table and the device's indicator maps ---- */
+static inline uint8_t low_byte_at(const void *src, int itemsize, size_t i)
+{
+    return ((const uint8_t *)src)[i * (size_t)itemsize];           /* little-endian hosts (x86-64, the GPU boxes) */
+}
+static void low_bytes(uint8_t *dst, const void *src, int itemsize, size_t n)
+{
+    if (itemsize == 1) { memcpy(dst, src, n); return; }
+    if (itemsize == 8) { const uint64_t *s = (const uint64_t *)src; for (size_t i = 0; i < n; ++i) dst[i] = (uint8_t)s[i]; return; }
+    if (itemsize == 4) { const uint32_t *s = (const uint32_t *)src; for (size_t i = 0; i < n; ++i) dst[i] = (uint8_t)s[i]; return; }
+    if (itemsize == 2) { const uint16_t *s = (const uint16_t *)src; for (size_t i = 0; i < n; ++i) dst[i] = (uint8_t)s[i]; return; }
+    for (size_t i = 0; i < n; ++i) dst[i] = low_byte_at(src, itemsize, i);
+}
+
+/* mask (H, W) uint8 <- the low byte of every origin_mask element, then origin_label's low bytes over the
+ * (2 radius + 1)^2 window of every pick (rows of `picks`: h, w, score as float64), windows clipped at the borders */
+int halo_compose_mask(uint8_t *mask, const void *origin_mask, int mask_itemsize, const void *origin_label, int label_itemsize,
+                      int64_t H, int64_t W, const double *picks, int64_t k, int64_t radius)
+{
+    if (!mask || !origin_mask || H <= 0 || W <= 0 || k < 0 || radius < 0 || (k > 0 && (!picks || !origin_label))) return -1;
+    if ((mask_itemsize != 1 && mask_itemsize != 2 && mask_itemsize != 4 && mask_itemsize != 8) ||
+        (k > 0 && label_itemsize != 1 && label_itemsize != 2 && label_itemsize != 4 && label_itemsize != 8)) return -1;
+    low_bytes(mask, origin_mask, mask_itemsize, (size_t)H * (size_t)W);
+    for (int64_t p = 0; p < k; ++p) {
+        const int64_t h = (int64_t)picks[3 * p], w = (int64_t)picks[3 * p + 1];
+        const int64_t y0 = h - radius < 0 ? 0 : h - radius, y1 = h + radius >= H ? H - 1 : h + radius;
+        const int64_t x0 = w - radius < 0 ? 0 : w - radius, x1 = w + radius >= W ? W - 1 : w + radius;
+        for (int64_t y = y0; y <= y1; ++y)
+            for (int64_t x = x0; x <= x1; ++x) mask[y * W + x] = low_byte_at(origin_label, label_itemsize, (size_t)(y * W + x));
+    }
+    return 0;
+}
+
+static int write_file(const char *path, const uint8_t *buf, size_t n)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -2;
+    const size_t wr = fwrite(buf, 1, n, f);
+    return (fclose(f) == 0 && wr == n) ? 0 : -2;
+}
+
+/* The indicator file: `tpl` (tpl_len bytes: what torch.save wrote for two bool tensors of this shape) with the n payload bytes
+ * of `active` at off_a and of `selected` at off_s, and each payload's CRC-32 stored (little-endian) at its two field offsets
+ * (zip data descriptor / local header, and central directory). */
+int halo_write_indicator(const char *path, const uint8_t *tpl, size_t tpl_len, const uint8_t *active, const uint8_t *selected, size_t n,
+                         size_t off_a, size_t off_s, const uint64_t *crc_fields_a, const uint64_t *crc_fields_s)
+{
+    if (!path || !tpl || !active || !selected || !crc_fields_a || !crc_fields_s || off_a + n > tpl_len || off_s + n > tpl_len) return -1;
+    uint8_t *buf = (uint8_t *)malloc(tpl_len);
+    if (!buf) return -1;
+    memcpy(buf, tpl, tpl_len);
+    memcpy(buf + off_a, active, n);
+    memcpy(buf + off_s, selected, n);
+    const uint32_t ca = crc32_update(0, active, n), cs = crc32_update(0, selected, n);
+    for (int i = 0; i < 2; ++i) {
+        if (crc_fields_a[i] + 4 > tpl_len || crc_fields_s[i] + 4 > tpl_len) { free(buf); return -1; }
+        for (int b = 0; b < 4; ++b) { buf[crc_fields_a[i] + b] = (uint8_t)(ca >> (8 * b)); buf[crc_fields_s[i] + b] = (uint8_t)(cs >> (8 * b)); }
+    }
+    const int rc = write_file(path, buf, tpl_len);
+    free(buf);
+    return rc;
+}
+
+/* mask PNG (composed as halo_compose_mask) + indicator file (halo_write_indicator; skipped when tpl is NULL) of one image.
+ * 0 on success, -1 bad argument / out of memory, -2 I/O error on the mask, -3 I/O error on the indicator. */
+int halo_retire_image(const char *path_png, const char *path_indicator, const void *origin_mask, int mask_itemsize,
+                      const void *origin_label, int label_itemsize, int64_t H, int64_t W, const double *picks, int64_t k, int64_t radius,
+                      const uint8_t *active, const uint8_t *selected, const uint8_t *tpl, size_t tpl_len, size_t off_a, size_t off_s,
+                      const uint64_t *crc_fields_a, const uint64_t *crc_fields_s)
+{
+    if (!path_png || H <= 0 || W <= 0) return -1;
+    const size_t n = (size_t)H * (size_t)W, cap = halo_png_gray8_bound(H, W);
+    uint8_t *mask = (uint8_t *)malloc(n + cap);
+    if (!mask) return -1;
+    int rc = halo_compose_mask(mask, origin_mask, mask_itemsize, origin_label, label_itemsize, H, W, picks, k, radius);
+    if (rc == 0) {
+        const size_t m = halo_png_gray8_encode(mask, H, W, W, mask + n, cap);
+        rc = m ? write_file(path_png, mask + n, m) : -1;
+    }
+    free(mask);
+    if (rc != 0) return rc;
+    if (tpl && path_indicator) {
+        rc = halo_write_indicator(path_indicator, tpl, tpl_len, active, selected, n, off_a, off_s, crc_fields_a, crc_fields_s);
+        if (rc == -2) rc = -3;
+    }
     return rc;
 }

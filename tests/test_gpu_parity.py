@@ -1203,18 +1203,20 @@ def test_region_selection_pipelined_pool_vs_oracle(dev):
         assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
 
 
-@pytest.mark.parametrize("variant", ["loader_batch_3", "narrow_masks", "uint8_loader", "oracle_branch_narrow"])
-def test_region_selection_batched_and_narrow_staging_vs_oracle(dev, variant):
+@pytest.mark.parametrize("staging", ["table", "device"])
+@pytest.mark.parametrize("variant", ["loader_batch_3", "wide_labels", "uint8_loader", "oracle_branch"])
+def test_region_selection_batched_and_mask_staging_vs_oracle(dev, variant, staging):
     """Round 4 host side: a loader batch > 1 goes through as ONE launch group when its images share a label size (and one by
-    one when they do not), the masks may travel as low bytes (narrow_masks=True: the label map keeps its width when the scorer
-    reads it, oracle_acc / oracle_ripu), and a loader that already hands uint8 masks is taken as it is.  Label values above 255
-    are included on purpose: only their low byte can reach the uint8 PNG in the reference either (build.py:67-68).  Every
-    file equals the oracle driver's result."""
+    one when they do not); with mask_staging="table" (default) the int64 mask / label maps never travel -- the writer thread
+    composes the uint8 mask from the pick table -- while "device" DMAs them and lets the selection kernel write the windows (the
+    label map also travels when the scorer reads it: oracle_acc / oracle_ripu); a loader that hands uint8 masks is taken as it
+    is.  Label values above 255 are included on purpose: only their low byte can reach the uint8 PNG in the reference either
+    (build.py:67-68).  Every file equals the oracle driver's result."""
     from PIL import Image
     from halo_amd.core.active.build import RegionSelection
     from oracle import halo_oracle as ho
     rng = np.random.default_rng(77)
-    oracle_branch = variant == "oracle_branch_narrow"
+    oracle_branch = variant == "oracle_branch"
     cfg = types.SimpleNamespace(
         MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
         ACTIVE=types.SimpleNamespace(UNCERTAINTY="oracle_acc" if oracle_branch else "entropy", PURITY="oracle_ripu" if oracle_branch else "radius",
@@ -1231,12 +1233,13 @@ def test_region_selection_batched_and_narrow_staging_vs_oracle(dev, variant):
         om = np.full((H, W), 255, np.int64)
         prior = rng.random((H, W)) < 0.01
         om[prior] = gt[prior]
-        if variant == "narrow_masks":
+        if variant == "wide_labels":
             gt[rng.random((H, W)) < 0.02] += 256                       # only the low byte reaches the file (reference: uint8 cast)
+            om[rng.random((H, W)) < 0.02] += 512
         act = rng.random((H, W)) < 0.02
         per.append(dict(om=om, gt=gt, act=act, H=H, W=W, emb=emb_lr, lg=logit_lr))
         oracle_in.append(dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act, selected=np.zeros((H, W), bool), origin_mask=om))
-    nb = 3 if variant in ("loader_batch_3", "narrow_masks", "oracle_branch_narrow") else 1
+    nb = 3 if variant in ("loader_batch_3", "wide_labels", "oracle_branch") else 1
     items = []
     for k in range(0, len(per), nb):
         grp = per[k:k + nb]
@@ -1258,8 +1261,7 @@ def test_region_selection_batched_and_narrow_staging_vs_oracle(dev, variant):
                        "selected": torch.zeros(len(idxs), H, W, dtype=torch.bool), "name": [f"img{i}" for i in idxs]})
         head_outs.append((t(np.concatenate([per[i]["lg"] for i in idxs]), dev), t(np.concatenate([per[i]["emb"] for i in idxs]), dev)))
     st = {}
-    RegionSelection(cfg, _Fake(), _Fake(head_outs), loader, 1, in_flight=2, writer_threads=3, stats=st,
-                    narrow_masks=variant in ("narrow_masks", "oracle_branch_narrow"))
+    RegionSelection(cfg, _Fake(), _Fake(head_outs), loader, 1, in_flight=2, writer_threads=3, stats=st, mask_staging=staging)
     assert st["images"] == len(sizes) and st["batches"] == len(items) and st["main_launch_s"] > 0
     want = ho.region_selection(cfg, oracle_in, lowres_mode=_lr_mode())
     for i, (mask, act, sel, _) in enumerate(want):

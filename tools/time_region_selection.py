@@ -75,7 +75,7 @@ def batched(items, nb):
     return out
 
 
-NARROW = bool(int(os.environ.get("HALO_RS_NARROW", "0")))
+STAGING = os.environ.get("HALO_RS_STAGING", "table")
 for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
     for (infl, wr, nb, tag) in ((0, 1, 1, "serial (in_flight=0, 1 writer)"), (8, 8, 1, "pipelined (in_flight=8, 4 streams, 8 writers)"),
                                 (8, 12, 1, "pipelined (in_flight=8, 4 streams, 12 writers)"), (8, None, 1, "pipelined (defaults)"),
@@ -84,11 +84,11 @@ for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
             continue
         tmp = tempfile.mkdtemp(prefix="halo_rs_t_")
         items = batched(pool(tmp), nb) if nb > 1 else pool(tmp)
-        RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, in_flight=infl, writer_threads=wr, narrow_masks=NARROW)
+        RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, in_flight=infl, writer_threads=wr, mask_staging=STAGING)
         torch.cuda.synchronize()
         st = {}
         t0 = time.perf_counter()
-        RegionSelection(cfg, Ident(), Head(busy), items, 1, in_flight=infl, writer_threads=wr, stats=st, narrow_masks=NARROW)
+        RegionSelection(cfg, Ident(), Head(busy), items, 1, in_flight=infl, writer_threads=wr, stats=st, mask_staging=STAGING)
         dt = time.perf_counter() - t0
         print(f"backbone stand-in {MODE:5s} {busy:4.0f} ms: {tag:48s} {dt / N * 1e3:7.2f} ms/image  ({N / dt:6.1f} images/s)")
         print(fmt(st), flush=True)
