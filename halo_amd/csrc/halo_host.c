@@ -372,18 +372,38 @@ int halo_write_indicator(const char *path, const uint8_t *tpl, size_t tpl_len, c
                          size_t off_a, size_t off_s, const uint64_t *crc_fields_a, const uint64_t *crc_fields_s)
 {
     if (!path || !tpl || !active || !selected || !crc_fields_a || !crc_fields_s || off_a + n > tpl_len || off_s + n > tpl_len) return -1;
-    uint8_t *buf = (uint8_t *)malloc(tpl_len);
-    if (!buf) return -1;
-    memcpy(buf, tpl, tpl_len);
-    memcpy(buf + off_a, active, n);
-    memcpy(buf + off_s, selected, n);
+    if (!(off_a + n <= off_s || off_s + n <= off_a)) return -1;           /* the two payloads must not overlap */
+    /* the file = template with two holes: only the ~1.5 KB around the payloads is copied (and patched), the payloads are
+     * written straight from the caller's buffers */
+    const int a_first = off_a < off_s;
+    const size_t o1 = a_first ? off_a : off_s, o2 = a_first ? off_s : off_a;
+    const uint8_t *p1 = a_first ? active : selected, *p2 = a_first ? selected : active;
+    const size_t small_len = tpl_len - 2 * n;
+    uint8_t *small = (uint8_t *)malloc(small_len ? small_len : 1);
+    if (!small) return -1;
+    memcpy(small, tpl, o1);                                               /* [0, o1) */
+    memcpy(small + o1, tpl + o1 + n, o2 - (o1 + n));                      /* [o1 + n, o2) */
+    memcpy(small + (o2 - n), tpl + o2 + n, tpl_len - (o2 + n));           /* [o2 + n, end) */
     const uint32_t ca = crc32_update(0, active, n), cs = crc32_update(0, selected, n);
-    for (int i = 0; i < 2; ++i) {
-        if (crc_fields_a[i] + 4 > tpl_len || crc_fields_s[i] + 4 > tpl_len) { free(buf); return -1; }
-        for (int b = 0; b < 4; ++b) { buf[crc_fields_a[i] + b] = (uint8_t)(ca >> (8 * b)); buf[crc_fields_s[i] + b] = (uint8_t)(cs >> (8 * b)); }
+    for (int i = 0; i < 2; ++i)
+        for (int which = 0; which < 2; ++which) {
+            const uint64_t f = which ? crc_fields_s[i] : crc_fields_a[i];
+            const uint32_t c = which ? cs : ca;
+            if (f + 4 > tpl_len || (f + 4 > o1 && f < o1 + n) || (f + 4 > o2 && f < o2 + n)) { free(small); return -1; }   /* inside a payload?! */
+            const size_t g = f < o1 ? f : (f < o2 ? f - n : f - 2 * n);   /* template offset -> offset in `small` */
+            for (int b = 0; b < 4; ++b) small[g + b] = (uint8_t)(c >> (8 * b));
+        }
+    int rc = -2;
+    FILE *f = fopen(path, "wb");
+    if (f) {
+        size_t wr = fwrite(small, 1, o1, f);
+        wr += fwrite(p1, 1, n, f);
+        wr += fwrite(small + o1, 1, o2 - (o1 + n), f);
+        wr += fwrite(p2, 1, n, f);
+        wr += fwrite(small + (o2 - n), 1, tpl_len - (o2 + n), f);
+        if (fclose(f) == 0 && wr == tpl_len) rc = 0;
     }
-    const int rc = write_file(path, buf, tpl_len);
-    free(buf);
+    free(small);
     return rc;
 }
 
