@@ -722,7 +722,7 @@ def main():
                                 float(np.mean(lr_ms["tail"])), HBM_PEAK_GBPS, "GB/s",
                                 "radius + entropy read (entropy twice: min/max pass and combine), active read, three maps written"))
             out["roofline_kernels"] = ks
-        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if out["roofline"] is None or lowres or not os.path.exists(pmc):
                 continue

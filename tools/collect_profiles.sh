@@ -2,7 +2,7 @@
 # Measurement pass on one MI355X box: every number quoted in DESIGN.md / README.md / profiles/README.md for the current round.
 # Run through gpurun from the repository root; raw output lands in gpurun_out/<round>_profiles/, tools/distill_profiles.py
 # (run afterwards in the build container) turns it into the tracked files under profiles/.
-RND=${1:-r03}
+RND=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${RND}_profiles
 rm -rf $OUT; mkdir -p $OUT
@@ -17,7 +17,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 python3 $R/tools/tail_timeline.py $OUT/trace > $OUT/tail_timeline.txt 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --ring 16 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --ring 16 > /dev/null 2>&1
-for v in "f32:--feat-dtype f32" "lowres_exact:--source lowres --lr-mode exact" "lowres_gram:--source lowres --lr-mode gram" "c512:--channels 512 --ring 16" "ripu:--branch ripu" "hyper:--branch hyper" "pool2975:--pool-images 2975" "resets_kernel:--resets kernel" "resets_fills:--resets fills"; do
+for v in "f32:--feat-dtype f32" "lowres_exact:--source lowres --lr-mode exact" "lowres_gram:--source lowres --lr-mode gram" "c512:--channels 512 --ring 16" "ripu:--branch ripu" "hyper:--branch hyper" "pool2975:--pool-images 2975" "resets_kernel:--resets kernel" "resets_fills:--resets fills" "r02_equivalent:--resets fills --settle 0"; do
   name=${v%%:*}; args=${v#*:}
   pause
   python3 $R/bench.py --cpu-images 0 $args > $OUT/bench_$name.json 2> /dev/null
@@ -33,6 +33,21 @@ done
 python3 $R/tools/ab_feat_map.py 2> /dev/null > $OUT/ab_feat_map.txt
 METHODS=auto,serial python3 $R/tools/time_select.py > $OUT/select_timing.txt 2>&1
 python3 $R/tools/time_region_selection.py > $OUT/region_selection_timing.txt 2>&1
+HALO_RS_STAGING=device python3 $R/tools/time_region_selection.py 2>&1 | head -14 > $OUT/region_selection_timing_device_staging.txt
+HALO_RETIRE_PYTHON=1 python3 $R/tools/time_region_selection.py 2>&1 | head -14 > $OUT/region_selection_timing_python_writer.txt
+python3 $R/tools/time_persist.py > $OUT/host_pieces.txt 2>&1
+# hardware queues, with the settled bench: two runs per value
+for q in 1 2 4 8; do for rep in 1 2; do
+  HALO_BENCH_HW_QUEUES=$q python3 $R/bench.py --cpu-images 0 2> /dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('GPU_MAX_HW_QUEUES=$q run $rep: %.1f images/s  ms_per_step %.3f  k_feat_reduce %.3f ms  tail %.3f ms' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], d['ms_per_step'] - r['avg_launch_ms']))" >> $OUT/hw_queues.txt
+done; done
+for q in 2 4; do
+  HALO_BENCH_HW_QUEUES=$q python3 $R/bench.py --cpu-images 0 --source lowres 2> /dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('GPU_MAX_HW_QUEUES=$q --source lowres (exact): %.1f images/s  ms_per_step %.3f' % (d['value'], d['ms_per_step']))" >> $OUT/hw_queues.txt
+done
+# the world-8 code on the one GPU (tests/test_gpu_pool.py runs the same): eight gloo ranks share the device, 2975-image pool, tiny shape
+HALO_BENCH_BACKEND=gloo HALO_BENCH_SHARE_GPU=1 python3 $R/bench.py --gpus 8 --height 64 --width 128 --channels 8 --batch 8 --ring 16 --warmup 2 --pool-images 2975 --cpu-images 0 > $OUT/bench_world8_one_gpu_tiny.json 2> /dev/null
+KSTATS_TOP=14 $R/tools/kstats.sh gram_ab python3 $R/tools/ab_gram.py > $OUT/gram_ab.txt 2>&1
 python3 $R/tools/time_secondary.py > $OUT/secondary_kernels.txt 2>&1
 python3 $R/tools/time_branches.py > $OUT/branches.txt 2>&1
 python3 $R/tools/time_feat.py > $OUT/feat_alone.txt 2>&1

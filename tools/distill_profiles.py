@@ -3,7 +3,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", RND + "_profiles")
 DST = os.path.join(ROOT, "profiles")
 
@@ -66,7 +66,7 @@ def main():
     d = copy_json("bench_default.json", RND + "_bench_default.json")
     copy_json("bench_under_rocprof.json", RND + "_bench_under_rocprof.json")
     for v in ("f32", "lowres", "lowres_exact", "lowres_gram", "c512", "ripu", "hyper", "pool2975", "resets_kernel", "resets_fills",
-              "pool96_one_rank", "pool96_two_ranks_one_gpu"):
+              "pool96_one_rank", "pool96_two_ranks_one_gpu", "r02_equivalent", "world8_one_gpu_tiny"):
         copy_json("bench_%s.json" % v, RND + "_bench_%s.json" % v)
     stats_csv("trace/*/*_kernel_stats.csv", RND + "_kernel_stats.csv")
     stats_csv("trace_ripu/*/*_kernel_stats.csv", RND + "_kernel_stats_ripu.csv", 25)
@@ -104,7 +104,8 @@ def main():
                    "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all waves; GRBM_GUI_ACTIVE / 8 = shader cycles",
                    "per_kernel_avg_per_launch": per}, open(os.path.join(DST, RND + "_pmc_lowres.json"), "w"), indent=1)
     for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt", "tail_timeline.txt", "ab_lowres_dma.txt", "two_ranks_one_gpu.txt", "select_timing_ranged.txt",
-              "select16_breakdown.txt", "bench_repeats.txt", "ab_feat_map.txt"):
+              "select16_breakdown.txt", "bench_repeats.txt", "ab_feat_map.txt", "region_selection_timing_device_staging.txt",
+              "region_selection_timing_python_writer.txt", "host_pieces.txt", "hw_queues.txt", "gram_ab.txt"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]
