@@ -704,9 +704,9 @@ def main():
                         "avg_launch_ms": round(t_ms, 4), "work_per_launch": work, "what": what}
             ks = []
             if lr_ms["logit"]:
-                # 1331 VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/r03_pmc_lowres.json: 697 M per
-                # 16 images): interpolation 4 + lean softmax / entropy ~66 per class; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops
-                ks.append(entry("k_logit_maps_lr<%d>" % O, "valu", 1331.0 / 19 * O * B * Hh * Ww, float(np.mean(lr_ms["logit"])), 78.6, "T lane-ops/s",
+                # 1162 VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/r04_pmc_lowres.json: 609 M per
+                # 16 images): interpolation 4 + lean softmax / entropy ~57 per class; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops
+                ks.append(entry("k_logit_maps_lr<%d>" % O, "valu", 1162.0 / 19 * O * B * Hh * Ww, float(np.mean(lr_ms["logit"])), 78.6, "T lane-ops/s",
                                 "f32 VALU instruction issue (no flops convention: compares, selects and conversions count)"))
             if lr_ms["gram"]:
                 ks.append(entry("k_gram_lr2", "hbm", B * (C * h4 * w4 * 8 + 5 * h4 * w4 * 8), float(np.mean(lr_ms["gram"])), HBM_PEAK_GBPS, "GB/s",
