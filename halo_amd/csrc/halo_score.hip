@@ -1674,82 +1674,93 @@ __global__ void __launch_bounds__(TPB) k_gram_lr(const double *__restrict__ feat
 // column the next lane's first (full-wave DPP shift); only lane 63 loads its right neighbour itself (8 bytes per row and
 // channel, clamped at the row's end).  Half the load instructions per byte of k_gram_lr, no idle 64th lane, and 512-column rows
 // split into four full waves.  Same fma chains, same bits.
-template <int UCH, bool NT>
+template <int UCH, bool NT, int R>
 __global__ void __launch_bounds__(TPB) k_gram_lr2(const double *__restrict__ feat, long long bstride, int C, int h, int w,
                                                   double *__restrict__ gram)
 {
+    // R rows per wave (+ the lower neighbour of the last one): every source row is loaded (R + 1) / R times
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const unsigned per = gridDim.x / 8;                       // the host pads the grid's x extent to a multiple of 8
     const unsigned wid = ((blockIdx.x % 8) * per + blockIdx.x / 8) * (TPB / 64) + (threadIdx.x >> 6);
     const unsigned nwx = (unsigned)((w + 127) / 128);
-    const int y = 2 * (int)(wid / nwx);
+    const int y = R * (int)(wid / nwx);
     if (y >= h) return;                                       // wave-uniform
     const int xu = (int)(wid % nwx) * 128 + 2 * lane;         // this lane's first column (even)
     const int x = xu < w - 2 ? xu : w - 2;                    // lanes past the row re-read its last pair (never stored)
     const int xr = xu + 2 < w - 1 ? xu + 2 : w - 1;           // right neighbour of the second column, clamped (lane 63 loads it)
-    const int y1 = y + 1 < h - 1 ? y + 1 : h - 1, y2 = y + 2 < h - 1 ? y + 2 : h - 1;
-    const unsigned a0 = (unsigned)(y * w + x), a1 = (unsigned)(y1 * w + x), a2 = (unsigned)(y2 * w + x);
-    const unsigned e0 = (unsigned)(y * w + xr), e1 = (unsigned)(y1 * w + xr), e2 = (unsigned)(y2 * w + xr);
+    unsigned a[R + 1], e[R + 1];
+#pragma unroll
+    for (int r = 0; r <= R; ++r) {
+        const int yr = y + r < h - 1 ? y + r : h - 1;
+        a[r] = (unsigned)(yr * w + x);
+        e[r] = (unsigned)(yr * w + xr);
+    }
     const int hwl = h * w;
     const double *p = feat + (size_t)b * bstride;             // plane base: scalar, advanced by scalar adds
-    double g[2][2][GRAM_MAPS];                                // [row][column of the pair][map]
+    double g[R][2][GRAM_MAPS];                                // [row][column of the pair][map]
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int k = 0; k < GRAM_MAPS; ++k) g[r][q][k] = 0.0;
     const bool last = lane == 63, edge = xu + 2 >= w;         // edge: the pair ends the row, its right neighbour is clamped to itself
-    auto accumulate = [&](const d2_t &v0, const d2_t &v1, const d2_t &v2, double x0, double x1, double x2) {
+    auto accumulate = [&](const d2_t (&v)[R + 1], const double (&xx)[R + 1]) {
         // right neighbours of the pair's second column: the next lane's first column, (lane 63) the value it loaded itself, or
         // (last pair of the row) the column itself
-        const double s0 = next_lane(v0.x), s1 = next_lane(v1.x), s2 = next_lane(v2.x);
-        const double n0 = edge ? v0.y : (last ? x0 : s0), n1 = edge ? v1.y : (last ? x1 : s1), n2 = edge ? v2.y : (last ? x2 : s2);
-        const double c0[2] = {v0.x, v0.y}, c1[2] = {v1.x, v1.y}, c2[2] = {v2.x, v2.y};
-        const double r0[2] = {v0.y, n0}, r1[2] = {v1.y, n1}, r2[2] = {v2.y, n2};
+        double cc[R + 1][2], rr[R + 1][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            g[0][q][0] = __builtin_fma(c0[q], c0[q], g[0][q][0]); g[0][q][1] = __builtin_fma(c0[q], r0[q], g[0][q][1]);
-            g[0][q][2] = __builtin_fma(c0[q], c1[q], g[0][q][2]); g[0][q][3] = __builtin_fma(c0[q], r1[q], g[0][q][3]);
-            g[0][q][4] = __builtin_fma(r0[q], c1[q], g[0][q][4]);
-            g[1][q][0] = __builtin_fma(c1[q], c1[q], g[1][q][0]); g[1][q][1] = __builtin_fma(c1[q], r1[q], g[1][q][1]);
-            g[1][q][2] = __builtin_fma(c1[q], c2[q], g[1][q][2]); g[1][q][3] = __builtin_fma(c1[q], r2[q], g[1][q][3]);
-            g[1][q][4] = __builtin_fma(r1[q], c2[q], g[1][q][4]);
+        for (int r = 0; r <= R; ++r) {
+            const double sh = next_lane(v[r].x);
+            const double nb = edge ? v[r].y : (last ? xx[r] : sh);
+            cc[r][0] = v[r].x; cc[r][1] = v[r].y; rr[r][0] = v[r].y; rr[r][1] = nb;
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                g[r][q][0] = __builtin_fma(cc[r][q], cc[r][q], g[r][q][0]); g[r][q][1] = __builtin_fma(cc[r][q], rr[r][q], g[r][q][1]);
+                g[r][q][2] = __builtin_fma(cc[r][q], cc[r + 1][q], g[r][q][2]); g[r][q][3] = __builtin_fma(cc[r][q], rr[r + 1][q], g[r][q][3]);
+                g[r][q][4] = __builtin_fma(rr[r][q], cc[r + 1][q], g[r][q][4]);
+            }
     };
-    // UCH channels (3 x 16 bytes each) in flight per lane; NT: the tensor is streamed once (each row a second time, right away,
-    // by the wave of the row pair above it) -- non-temporal loads keep it from displacing the Gram maps in the L2
+    // UCH channels ((R + 1) x 16 bytes each) in flight per lane.  NT (non-temporal loads) measured 20 % SLOWER: every row is read
+    // a second time, right away, as the neighbour row of the wave above -- an L2 hit that `nt` gives up (profiles/r04_gram_ab.txt)
     auto ld2 = [](const double *q) -> d2_t {
         if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(q));
         else return *reinterpret_cast<const d2_t *>(q);
     };
     int c = 0;
     for (; c + UCH <= C; c += UCH) {
-        d2_t v[UCH][3];
-        double xe[UCH][3];
+        d2_t v[UCH][R + 1];
+        double xe[UCH][R + 1];
 #pragma unroll
         for (int u = 0; u < UCH; ++u, p += hwl) {
-            v[u][0] = ld2(p + a0); v[u][1] = ld2(p + a1); v[u][2] = ld2(p + a2);
-            xe[u][0] = xe[u][1] = xe[u][2] = 0.0;
-            if (last) { xe[u][0] = p[e0]; xe[u][1] = p[e1]; xe[u][2] = p[e2]; }
+#pragma unroll
+            for (int r = 0; r <= R; ++r) { v[u][r] = ld2(p + a[r]); xe[u][r] = 0.0; }
+            if (last) {
+#pragma unroll
+                for (int r = 0; r <= R; ++r) xe[u][r] = p[e[r]];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < UCH; ++u) accumulate(v[u][0], v[u][1], v[u][2], xe[u][0], xe[u][1], xe[u][2]);
+        for (int u = 0; u < UCH; ++u) accumulate(v[u], xe[u]);
     }
     for (; c < C; ++c, p += hwl) {
-        const d2_t v0 = *reinterpret_cast<const d2_t *>(p + a0), v1 = *reinterpret_cast<const d2_t *>(p + a1), v2 = *reinterpret_cast<const d2_t *>(p + a2);
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-        if (last) { x0 = p[e0]; x1 = p[e1]; x2 = p[e2]; }
-        accumulate(v0, v1, v2, x0, x1, x2);
+        d2_t v[R + 1];
+        double xx[R + 1];
+#pragma unroll
+        for (int r = 0; r <= R; ++r) { v[r] = *reinterpret_cast<const d2_t *>(p + a[r]); xx[r] = last ? p[e[r]] : 0.0; }
+        accumulate(v, xx);
     }
     if (xu < w) {                                             // w even: both columns of the pair exist
         double *gb = gram + (size_t)b * GRAM_MAPS * hwl;
 #pragma unroll
-        for (int k = 0; k < GRAM_MAPS; ++k) *reinterpret_cast<d2_t *>(gb + (size_t)k * hwl + a0) = (d2_t){g[0][0][k], g[0][1][k]};
-        if (y + 1 < h) {
+        for (int r = 0; r < R; ++r)
+            if (y + r < h) {
 #pragma unroll
-            for (int k = 0; k < GRAM_MAPS; ++k) *reinterpret_cast<d2_t *>(gb + (size_t)k * hwl + a1) = (d2_t){g[1][0][k], g[1][1][k]};
-        }
+                for (int k = 0; k < GRAM_MAPS; ++k) *reinterpret_cast<d2_t *>(gb + (size_t)k * hwl + a[r]) = (d2_t){g[r][0][k], g[r][1][k]};
+            }
     }
 }
 
@@ -2140,14 +2151,25 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
             // 16 bytes per lane where the planes allow it (even width, 16-byte aligned); HALO_GRAM_8B=1: the 8-byte kernel (A/B)
             const bool wide = lr->wf >= 2 && lr->wf % 2 == 0 && feat_bstride % 2 == 0 && aligned16(feat) && aligned16(gram) && getenv("HALO_GRAM_8B") == nullptr;
             if (wide) {
-                const long long nwaves = cdiv(lr->wf, 128) * cdiv(lr->hf, 2);
+                // rows per wave: every source row is loaded (R + 1) / R times (its own strip + as lower neighbour of the strip above),
+                // and that redundancy, not the bytes in flight, is what the kernel's time follows (profiles/r04_gram_ab.txt: R = 2 / 4 /
+                // 8 -> 788 / 745 / 705 us per 16 images; 2, 3 or 4 channels in flight: equal; non-temporal loads: 20 % slower).  The
+                // widest strip that still gives every SIMD of the chip a wave; HALO_GRAM_ROWS / _UCH / _NT are A/B switches (same bits)
+                const char *eu = getenv("HALO_GRAM_UCH"), *en = getenv("HALO_GRAM_NT"), *er = getenv("HALO_GRAM_ROWS");
+                const long long nwx = cdiv(lr->wf, 128);
+                int rows = 2;
+                for (int cand = 8; cand > 2; cand >>= 1)
+                    if (B * nwx * cdiv(lr->hf, cand) >= 1024) { rows = cand; break; }
+                if (er) rows = atoi(er);
+                rows = rows >= 8 ? 8 : (rows >= 4 ? 4 : 2);
+                const int uch = eu ? atoi(eu) : (rows == 8 ? 1 : 2), nt = en ? atoi(en) : 0;
+                const long long nwaves = nwx * cdiv(lr->hf, rows);
                 const dim3 gg((unsigned)(cdiv(cdiv(nwaves, TPB / 64), 8) * 8), (unsigned)B);
-                const char *eu = getenv("HALO_GRAM_UCH"), *en = getenv("HALO_GRAM_NT");           // A/B switches, same bits
-                const int uch = eu ? atoi(eu) : 2, nt = en ? atoi(en) : 0;
-#define HALO_GRAM2(U_, N_) hipLaunchKernelGGL((k_gram_lr2<U_, N_>), gg, block, 0, st, (const double *)feat, (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram)
-                if (uch >= 4) { if (nt) HALO_GRAM2(4, true); else HALO_GRAM2(4, false); }
-                else if (uch == 3) { if (nt) HALO_GRAM2(3, true); else HALO_GRAM2(3, false); }
-                else { if (nt) HALO_GRAM2(2, true); else HALO_GRAM2(2, false); }
+#define HALO_GRAM2(U_, N_, R_) hipLaunchKernelGGL((k_gram_lr2<U_, N_, R_>), gg, block, 0, st, (const double *)feat, (long long)feat_bstride, (int)C, lr->hf, lr->wf, gram)
+                if (rows == 8) HALO_GRAM2(1, false, 8);
+                else if (rows == 4) { if (uch >= 3) HALO_GRAM2(3, false, 4); else if (uch == 2) HALO_GRAM2(2, false, 4); else HALO_GRAM2(1, false, 4); }
+                else if (uch >= 4) { if (nt) HALO_GRAM2(4, true, 2); else HALO_GRAM2(4, false, 2); }
+                else { if (nt) HALO_GRAM2(2, true, 2); else HALO_GRAM2(2, false, 2); }
 #undef HALO_GRAM2
             } else {
                 const long long nwaves = cdiv(lr->wf, GRAM_COLS) * cdiv(lr->hf, 2);

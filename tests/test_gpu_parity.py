@@ -1026,6 +1026,24 @@ def test_padding_modes_vs_reference_and_oracle(golden, dev, mode):
         score_maps(tiny, None, "entropy", "ripu", False, None, size=3, padding_mode="mirror")
 
 
+@pytest.mark.parametrize("rows", ["2", "4", "8"])
+def test_gram_kernel_strip_heights_are_invisible(dev, monkeypatch, rows):
+    """k_gram_lr2 lets a wave own 2, 4 or 8 source rows (chosen by the size of the launch; HALO_GRAM_ROWS forces one): same fma
+    chains per low-res pixel whatever the strip, so the maps are bit-identical to the oracle twin for every strip height --
+    source heights that are no multiple of the strip, shorter than it, a single row, odd widths (the 8-byte kernel) included."""
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from oracle import halo_oracle as ho
+    monkeypatch.setenv("HALO_GRAM_ROWS", rows)
+    rng = np.random.default_rng(int(rows))
+    for (C, hf, wf, H, W) in ((24, 16, 32, 64, 128), (7, 9, 130, 30, 300), (5, 1, 64, 4, 200), (12, 3, 6, 17, 23), (9, 21, 258, 40, 500),
+                              (6, 7, 5, 20, 16), (256, 32, 64, 64, 128)):
+        emb_lr = ho.expmap((rng.standard_normal((2, C, hf, wf)) * 0.3).astype(np.float32), 1.0, dim=1)
+        logit_lr = rng.standard_normal((2, 19, 8, 8)).astype(np.float32)
+        g = score_maps_lowres(t(logit_lr, dev), t(emb_lr, dev), (H, W), "none", "radius", False, None, ksize=3, mode="gram")[1].cpu().numpy()
+        for b in range(2):
+            assert bits_equal(g[b], ho.gram_radius(emb_lr[b], (H, W), "radius", 1.0)), (rows, C, hf, wf, b)
+
+
 def test_lowres_gram_mode_on_degenerate_grids(dev):
     """single-row / single-column / single-pixel embeddings, odd sizes around the 63-column wave width"""
     from halo_amd.core.active.floating_region import score_maps_lowres

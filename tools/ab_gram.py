@@ -12,13 +12,13 @@ logit = torch.randn((B, O, h, w), generator=g, device=dev)
 feat = torch.randn((B, C, h, w), generator=g, device=dev, dtype=torch.float64) * 0.05
 ref = None
 for rep in range(3):
-    for uch in (2, 3, 4):
-        for nt in (0, 1):
-            os.environ["HALO_GRAM_UCH"], os.environ["HALO_GRAM_NT"] = str(uch), str(nt)
+    for uch, nt, rows in ((2, 0, 2), (4, 0, 2), (2, 1, 2), (1, 0, 4), (2, 0, 4), (3, 0, 4), (1, 0, 8)):
+        if True:
+            os.environ["HALO_GRAM_UCH"], os.environ["HALO_GRAM_NT"], os.environ["HALO_GRAM_ROWS"] = str(uch), str(nt), str(rows)
             out = score_maps_lowres(logit, feat, (H, W), "entropy", "radius", True, None, ksize=3, mode="gram")
             if ref is None:
                 ref = [o.clone() for o in out]
             else:
-                assert all(torch.equal(a, b) for a, b in zip(ref, out)), (uch, nt)
+                assert all(torch.equal(a, b) for a, b in zip(ref, out)), (uch, nt, rows)
 torch.cuda.synchronize()
 print("all variants bit-identical")
