@@ -46,7 +46,7 @@ def host_is_stale():
     if not os.path.exists(HOST_SO):
         return True
     t = os.path.getmtime(HOST_SO)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in HOST_SOURCES)
+    return any(os.path.getmtime(p) > t for p in [os.path.join(CSRC, f) for f in HOST_SOURCES] + [os.path.join(HERE, "..", "include", "halo_host.h")])
 
 
 def build_host(force=False):

@@ -27,9 +27,9 @@
 #include <immintrin.h>
 #endif
 
-#define HALO_HOST_ABI 2
+#include "../../include/halo_host.h"
 
-int halo_host_version(void) { return HALO_HOST_ABI; }
+int halo_host_version(void) { return HALO_HOST_ABI_VERSION; }
 
 /* ---- CRC-32 (IEEE 802.3: PNG chunks, zip entries).  Slicing-by-8 tables; on x86-64 with PCLMULQDQ the bulk of a long buffer
  * goes through the carry-less-multiplication folding of Gopal et al., "Fast CRC Computation for Generic Polynomials Using

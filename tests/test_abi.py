@@ -35,6 +35,23 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert "#define HALO_ABI_VERSION %d" % _lib.ABI_VERSION in text
 
 
+def test_host_library_exports_every_symbol_its_header_declares():
+    """include/halo_host.h: the plain-C helpers of the persistence step (libhalo_host.so, no HIP) -- every declared entry point is
+    exported, the header's version is the binding's, and the compiler checked the definitions against the declarations (the .c
+    file includes the header)."""
+    from halo_amd import _build, _hostlib
+    text = open(os.path.join(ROOT, "include", "halo_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(halo_[a-z0-9_]+)\s*\(", text)))
+    assert {"halo_retire_image", "halo_compose_mask", "halo_write_indicator", "halo_png_gray8_write", "halo_crc32", "halo_host_version"} <= set(syms)
+    h = ctypes.CDLL(_build.build_host())
+    for s in syms:
+        assert hasattr(h, s), "libhalo_host.so does not export %s" % s
+    assert "#define HALO_HOST_ABI_VERSION %d" % _hostlib.ABI_VERSION in open(os.path.join(ROOT, "include", "halo_host.h")).read()
+    assert _hostlib.lib().halo_host_version() == _hostlib.ABI_VERSION
+    assert '#include "../../include/halo_host.h"' in open(os.path.join(ROOT, "halo_amd", "csrc", "halo_host.c")).read()
+
+
 def test_workspace_queries_are_pure_host_functions():
     from halo_amd import _lib
     L = _lib.lib()
