@@ -528,7 +528,8 @@ def _finish(rec, i, paths, slots, stats=None):
             # mask_staging="table": ONE call without the interpreter lock composes the mask from the loader's maps and the pick
             # table, encodes it, and writes the indicator from the pinned maps through the shape's template
             om, gt = rec.keep[2][i].numpy(), rec.keep[3][i].numpy()
-            if om.flags["C_CONTIGUOUS"] and gt.flags["C_CONTIGUOUS"] and om.dtype.kind in "iub" and gt.dtype.kind in "iub":
+            if om.flags["C_CONTIGUOUS"] and gt.flags["C_CONTIGUOUS"] and om.dtype.kind in "iub" and gt.dtype.kind in "iub" \
+                    and om.ctypes.data % om.dtype.itemsize == 0 and gt.ctypes.data % gt.dtype.itemsize == 0:      # (naturally aligned elements)
                 tpl = _IndicatorTemplate.get(om.shape)
                 retire(paths[0], paths[1], om, gt, buf.out_picks[i].numpy(), k, rec.radius, buf.out_active[i].numpy(),
                        buf.out_selected[i].numpy(), tpl if tpl.ok else None)
