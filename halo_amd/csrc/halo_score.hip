@@ -787,9 +787,14 @@ constexpr int BM_RPT = 4, BM_TW = 256, BM_TH = BM_RPT * (TPB / 64);
 __device__ __forceinline__ float nan_minf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
 __device__ __forceinline__ float nan_maxf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
 
-__global__ void __launch_bounds__(TPB) k_box3_minmax(const float *__restrict__ ent, int H, int W, int pk, double *__restrict__ partials)
+__global__ void __launch_bounds__(TPB) k_box3_minmax(const float *__restrict__ ent, int H, int W, int pk, double *__restrict__ partials,
+                                                     unsigned *__restrict__ hist_zero)
 {
     const int b = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (hist_zero) {        // the coarse histogram k_combine_box3 fills behind this kernel: cleared here (NB1 counters per image)
+        const unsigned nb = gridDim.x * gridDim.y;
+        for (unsigned l = blockIdx.y * gridDim.x + blockIdx.x; l < NB1 / TPB; l += nb) hist_zero[(size_t)b * NB1 + l * TPB + threadIdx.x] = 0u;
+    }
     const int x = blockIdx.x * BM_TW + lane * 4, y0 = blockIdx.y * BM_TH + wv * BM_RPT;
     const float *ep = ent + (size_t)b * H * W;
     const bool xin = x < W;
@@ -915,74 +920,116 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
 // normalised score is the product of two values in [0, 1] -- (x - min) / (max - min) of finite maps -- or -inf where masked, so
 // [0, 1] bounds it without a pass over the map; the only other possibility is a NaN map, and that is a property of the
 // min / max themselves (a constant or NaN-carrying map makes max - min zero or NaN): no per-pixel reporting is needed.
+// CB_ROWS consecutive rows per workgroup (round 4): the per-row work is what it was -- box3_row4 per row, so the sums are the bits
+// k_box3_minmax reduced -- but a workgroup now lives long enough to privatise the selector's coarse histogram of the score it
+// writes (NB1 counters in LDS, flushed once: with one row per workgroup the flush would be an atomic per pixel).  For a normalised
+// map the score is a product of two values in [0, 1] (or -inf where masked), so the bins are those of the range record this kernel
+// writes: lo = 0, scale = NB1 -- exactly what k_sel_hist1 would count from the stored map (same coarse_bin, same exclusions).
+constexpr int CB_ROWS = 16;
+
 template <typename TI>
 __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp_raw, const float *__restrict__ ent,
                                                       const double *__restrict__ stats, const unsigned char *__restrict__ active,
                                                       int H, int W, int pk, int normalize, TI *__restrict__ score,
-                                                      TI *__restrict__ imp_out, float *__restrict__ unc_out, SelHdr *__restrict__ rng)
+                                                      TI *__restrict__ imp_out, float *__restrict__ unc_out, SelHdr *__restrict__ rng,
+                                                      unsigned *__restrict__ hist)
 {
-    // grid (row segments of TPB * 4 pixels, rows, images): no index division (a 64-bit i / W was a fifth of the kernel's
-    // instructions); lanes past the end of a row idle
-    const int b = blockIdx.z, y = blockIdx.y;
+    // grid (row segments of TPB * 4 pixels, groups of CB_ROWS rows, images): no index division (a 64-bit i / W was a fifth of the
+    // kernel's instructions); lanes past the end of a row idle
+    __shared__ unsigned hl[NB1];
+    const int b = blockIdx.z;
     const long long hw = (long long)H * W;
     const int x = (blockIdx.x * TPB + threadIdx.x) * 4;
     const bool live = x < W;
-    float un[4];
-    box3_row4(ent + (size_t)b * hw, H, W, y, live ? x : 0, live, pk, un);
-    if (!live) return;
-    const size_t o = (size_t)b * hw + (size_t)y * W + x;
-    TI im[4];
-    if constexpr (sizeof(TI) == 8) {
-        const double2 q0 = *reinterpret_cast<const double2 *>(imp_raw + o), q1 = *reinterpret_cast<const double2 *>(imp_raw + o + 2);
-        im[0] = q0.x; im[1] = q0.y; im[2] = q1.x; im[3] = q1.y;
-    } else {
-        const float4 q = *reinterpret_cast<const float4 *>(imp_raw + o);
-        im[0] = q.x; im[1] = q.y; im[2] = q.z; im[3] = q.w;
-    }
+    float umn = 0.0f, uden = 1.0f;
+    TI imn = (TI)0, iden = (TI)1;
+    bool fin = false;
     if (normalize) {
-        const float umn = (float)stats[b * 4 + 2], umx = (float)stats[b * 4 + 3];
-        const float uden = (float)((double)umx - (double)umn);
-        const TI imn = (TI)stats[b * 4 + 0], imx = (TI)stats[b * 4 + 1];
-        TI iden;
+        umn = (float)stats[b * 4 + 2];
+        const float umx = (float)stats[b * 4 + 3];
+        uden = (float)((double)umx - (double)umn);
+        imn = (TI)stats[b * 4 + 0];
+        const TI imx = (TI)stats[b * 4 + 1];
         if constexpr (sizeof(TI) == 8) iden = imx - imn;
         else iden = (float)((double)imx - (double)imn);
+        // zero, NaN or infinite range: the map holds NaN (0/0, inf/inf); a finite positive range with finite extrema
+        // leaves every quotient in [0, 1]
+        fin = uden > 0.0f && uden < __builtin_inff() && iden > (TI)0 && iden < (TI)__builtin_inf();
         if (rng && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
             SelHdr h;
             memset(&h, 0, sizeof(h));
             h.kmin_inv = ~order_key(0.0);
             h.kmax = order_key(1.0);
             h.nvalid = 1u;                     // "something may be pickable": a fully masked map simply yields no candidates
-            // zero, NaN or infinite range: the map holds NaN (0/0, inf/inf); a finite positive range with finite extrema
-            // leaves every quotient in [0, 1]
-            const bool fin = uden > 0.0f && uden < __builtin_inff() && iden > (TI)0 && iden < (TI)__builtin_inf();
-            h.flags = fin ? 0u : (unsigned)SEL_F_BAD;
+            h.flags = fin ? (hist ? (unsigned)SEL_F_HIST : 0u) : (unsigned)SEL_F_BAD;
             rng[b] = h;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { un[j] = (un[j] - umn) / uden; im[j] = (im[j] - imn) / iden; }
     }
-    const unsigned am = active ? *reinterpret_cast<const unsigned *>(active + o) : 0u;
-    TI sc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        sc[j] = im[j] * (TI)un[j];
-        if ((am >> (8 * j)) & 0xffu) {
-            if constexpr (sizeof(TI) == 8) sc[j] = __longlong_as_double(0xfff0000000000000ll);
-            else sc[j] = __uint_as_float(0xff800000u);
+    const bool count = hist != nullptr && fin;               // kernel-uniform per image
+    if (count) {
+        for (int j = threadIdx.x; j < NB1; j += TPB) hl[j] = 0u;
+        __syncthreads();
+    }
+    ValRange vr;
+    vr.lo = 0.0; vr.scale = (double)NB1; vr.ok = true;       // = sel_range of the record above
+    const int yend = (blockIdx.y + 1) * CB_ROWS < H ? (blockIdx.y + 1) * CB_ROWS : H;
+    for (int y = blockIdx.y * CB_ROWS; y < yend; ++y) {
+        float un[4];
+        box3_row4(ent + (size_t)b * hw, H, W, y, live ? x : 0, live, pk, un);
+        if (!live) continue;                                  // (the lane shifts of box3_row4 are done: idle lanes may skip the rest)
+        const size_t o = (size_t)b * hw + (size_t)y * W + x;
+        TI im[4];
+        if constexpr (sizeof(TI) == 8) {
+            const double2 q0 = *reinterpret_cast<const double2 *>(imp_raw + o), q1 = *reinterpret_cast<const double2 *>(imp_raw + o + 2);
+            im[0] = q0.x; im[1] = q0.y; im[2] = q1.x; im[3] = q1.y;
+        } else {
+            const float4 q = *reinterpret_cast<const float4 *>(imp_raw + o);
+            im[0] = q.x; im[1] = q.y; im[2] = q.z; im[3] = q.w;
         }
-    }
-    if constexpr (sizeof(TI) == 8) {
-        *reinterpret_cast<double2 *>(score + o) = make_double2(sc[0], sc[1]);
-        *reinterpret_cast<double2 *>(score + o + 2) = make_double2(sc[2], sc[3]);
-        if (imp_out) {
-            *reinterpret_cast<double2 *>(imp_out + o) = make_double2(im[0], im[1]);
-            *reinterpret_cast<double2 *>(imp_out + o + 2) = make_double2(im[2], im[3]);
+        if (normalize) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { un[j] = (un[j] - umn) / uden; im[j] = (im[j] - imn) / iden; }
         }
-    } else {
-        *reinterpret_cast<float4 *>(score + o) = make_float4(sc[0], sc[1], sc[2], sc[3]);
-        if (imp_out) *reinterpret_cast<float4 *>(imp_out + o) = make_float4(im[0], im[1], im[2], im[3]);
+        const unsigned am = active ? *reinterpret_cast<const unsigned *>(active + o) : 0u;
+        TI sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = im[j] * (TI)un[j];
+            if ((am >> (8 * j)) & 0xffu) {
+                if constexpr (sizeof(TI) == 8) sc[j] = __longlong_as_double(0xfff0000000000000ll);
+                else sc[j] = __uint_as_float(0xff800000u);
+            }
+        }
+        if (count) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double v = (double)sc[j];
+                const unsigned long long k = order_key(v);
+                if (k < KEY_POS_INF && k != KEY_NEG_INF) {
+                    double t;
+                    atomicAdd(&hl[coarse_bin(v, vr, t)], 1u);
+                }
+            }
+        }
+        if constexpr (sizeof(TI) == 8) {
+            *reinterpret_cast<double2 *>(score + o) = make_double2(sc[0], sc[1]);
+            *reinterpret_cast<double2 *>(score + o + 2) = make_double2(sc[2], sc[3]);
+            if (imp_out) {
+                *reinterpret_cast<double2 *>(imp_out + o) = make_double2(im[0], im[1]);
+                *reinterpret_cast<double2 *>(imp_out + o + 2) = make_double2(im[2], im[3]);
+            }
+        } else {
+            *reinterpret_cast<float4 *>(score + o) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+            if (imp_out) *reinterpret_cast<float4 *>(imp_out + o) = make_float4(im[0], im[1], im[2], im[3]);
+        }
+        if (unc_out) *reinterpret_cast<float4 *>(unc_out + o) = make_float4(un[0], un[1], un[2], un[3]);
     }
-    if (unc_out) *reinterpret_cast<float4 *>(unc_out + o) = make_float4(un[0], un[1], un[2], un[3]);
+    if (count) {
+        __syncthreads();
+        unsigned *g = hist + (size_t)b * NB1;
+        for (int j = threadIdx.x; j < NB1; j += TPB)
+            if (hl[j]) atomicAdd(&g[j], hl[j]);
+    }
 }
 
 
@@ -2235,11 +2282,15 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
                            (!uncertainty || aligned16(uncertainty)) && (!active || ((uintptr_t)active & 3) == 0) &&
                            getenv("HALO_NO_FUSE_TAIL") == nullptr;
     const int nblk_c3 = (int)cdiv(hw, TPB * 4);
+    // the selector's coarse histogram of a normalised score map, counted by the combine kernel while it writes the map and handed
+    // over behind the range records (HALO_NO_FUSE_HIST=1: A/B switch, the selector then counts it itself -- same picks)
+    unsigned *rng_hist = (score_range && normalize && fuse_tail && getenv("HALO_NO_FUSE_HIST") == nullptr)
+                             ? (unsigned *)((char *)score_range + range_hist_offset(B)) : nullptr;
     if (fuse_tail) {
         if (normalize) {            // only the min / max are needed before the combine kernel
             const dim3 gridm((unsigned)cdiv(W, BM_TW), (unsigned)cdiv(H, BM_TH), (unsigned)B);
             nblk_unc = (int)(gridm.x * gridm.y);
-            hipLaunchKernelGGL(k_box3_minmax, gridm, block, 0, st, (const float *)ent, (int)H, (int)W, hist ? pksize : 0, part_unc);
+            hipLaunchKernelGGL(k_box3_minmax, gridm, block, 0, st, (const float *)ent, (int)H, (int)W, hist ? pksize : 0, part_unc, rng_hist);
         }
     } else if (box3) {
         nblk_unc = nblk_c3;
@@ -2258,9 +2309,9 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
         hipLaunchKernelGGL(k_minmax_finalize2, dim3((unsigned)B, 2u), dim3(FIN_TPB), 0, st, (const double *)part_imp, nblk_imp,
                            (const double *)part_unc, nblk_unc, stats);
     if (fuse_tail) {
-        dim3 gridc((unsigned)cdiv(W, TPB * 4), (unsigned)H, (unsigned)B);
-        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty, rng_free);
-        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty, rng_free);
+        dim3 gridc((unsigned)cdiv(W, TPB * 4), (unsigned)cdiv(H, CB_ROWS), (unsigned)B);
+        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty, rng_free, rng_hist);
+        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty, rng_free, rng_hist);
     } else if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
     if (score_range && !rng_free) {

@@ -317,7 +317,7 @@ extern "C" int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, 
                                      picks, n_picked, workspace, workspace_bytes, method, nullptr, stream);
 }
 
-extern "C" size_t halo_score_range_bytes(int64_t B) { return B > 0 ? (size_t)B * sizeof(SelHdr) : 0; }
+extern "C" size_t halo_score_range_bytes(int64_t B) { return B > 0 ? range_hist_offset(B) + (size_t)B * NB1 * sizeof(unsigned) : 0; }
 
 extern "C" int halo_score_range(const void *score, int dtype, int64_t B, int64_t H, int64_t W, void *score_range, void *stream)
 {

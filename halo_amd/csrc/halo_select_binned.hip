@@ -40,7 +40,6 @@
 
 namespace halo {
 
-constexpr int NB1 = 2048;        // coarse bins
 constexpr int SW_TPB = 256;      // sweep workgroup: 4 waves, one per SIMD
 constexpr int SW_SURV = 256;     // survivor capacity of one bin (4 per lane of the resolving wave)
 constexpr int FWIN = 1024;       // fine-bin offsets staged in LDS at a time
@@ -53,7 +52,8 @@ constexpr int SW_MB = 4;         // the sweep filters up to SW_MB consecutive bi
 
 struct BinWs {
     SelHdr *hdr;
-    const SelHdr *rng;                       // where the value range lives: hdr, or the scorer's range record (halo_score_range_t)
+    SelHdr *rng;                             // where the value range lives: hdr, or the scorer's range record (halo_score_range_t)
+    const unsigned *rng_hist;                // the scorer's coarse histograms behind its records (valid per image: SEL_F_HIST), or NULL
     unsigned *hist1, *cbase, *cm;            // NB1 each
     unsigned *fcur;                          // nfmax: candidates placed in each fine bin
     unsigned long long *ckey;                // nfmax * BIN_CAP: bin f owns slots [f * BIN_CAP, (f + 1) * BIN_CAP)
@@ -69,30 +69,6 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
         v = t > v ? t : v;
     }
     return v;
-}
-
-struct ValRange { double lo, scale; bool ok; };
-
-__device__ __forceinline__ ValRange sel_range(const SelHdr &h)
-{
-    ValRange r;
-    const double lo = key_value(~h.kmin_inv), hi = key_value(h.kmax);
-    r.lo = lo;
-    r.scale = (double)NB1 / (hi - lo);
-    r.ok = !(h.flags & SEL_F_BAD) && h.nvalid > 0 && hi > lo && r.scale > 0.0 && r.scale < 1.0e300;
-    return r;
-}
-
-// coarse bin of a finite value v; t = position in bin units (monotone, non-decreasing in v).  The range record only has to bound
-// the values for the bins to be well filled, NOT for correctness: a value below `lo` is clamped into the lowest bin explicitly
-// (t >= 0: nothing relies on how a negative double converts), one above `hi` into the highest, and the sub-bin of such a value
-// is clamped by its caller -- binning stays monotone, so the picks do not depend on the record.
-__device__ __forceinline__ int coarse_bin(double v, const ValRange &r, double &t)
-{
-    t = (v - r.lo) * r.scale;
-    t = t > 0.0 ? t : 0.0;
-    const int j = t < (double)(NB1 - 1) ? (int)t : NB1 - 1;
-    return j;
 }
 
 // ------------------------------------------------------------------ counters to zero
@@ -154,6 +130,7 @@ __global__ void __launch_bounds__(256) k_sel_hist1(const T *__restrict__ score, 
     const int b = blockIdx.y;
     const ValRange r = sel_range(ws.rng[b]);
     if (!r.ok) return;
+    if (ws.rng_hist && (ws.rng[b].flags & SEL_F_HIST)) return;      // the scorer counted this map while it wrote it
     for (int j = threadIdx.x; j < NB1; j += 256) h[j] = 0;
     __syncthreads();
     const T *sc = score + (size_t)b * hw;
@@ -189,7 +166,11 @@ __global__ void __launch_bounds__(256) k_sel_scan1(BinWs ws, BinGeom g)
     const int b = blockIdx.x, tid = threadIdx.x;
     SelHdr *hdr = ws.hdr + b;
     const ValRange r = sel_range(ws.rng[b]);
-    const unsigned *hist = ws.hist1 + (size_t)b * NB1;
+    // the scorer's histogram describes the map as it was when it was scored: used once (the flag is cleared below), and should the
+    // map have changed since (fewer candidates above the threshold than the counts promise) an exhausted sweep hands the image over
+    // instead of concluding that nothing is left (`truncated`)
+    const bool ext = ws.rng_hist && (ws.rng[b].flags & SEL_F_HIST);
+    const unsigned *hist = (ext ? ws.rng_hist : ws.hist1) + (size_t)b * NB1;
     unsigned c[8], m[8], tc = 0, tm = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -240,10 +221,13 @@ __global__ void __launch_bounds__(256) k_sel_scan1(BinWs ws, BinGeom g)
         if (!r.ok) { t1 = NB1; trunc = 1; nf = 0; }
         else if (s_here > g.captot) { t1 += 1; trunc = 1; nf = M_here; }
         else nf = M_here + m_here;
+        if (ext && t1 > 0) trunc = 1;
         hdr->t1 = t1;
         hdr->truncated = trunc;
         hdr->nf = nf;
     }
+    __syncthreads();
+    if (ext && tid == 0) ws.rng[b].flags &= ~(unsigned)SEL_F_HIST;      // consumed
 }
 
 // ------------------------------------------------------------------ candidates -> their fine bins, in one pass
@@ -742,7 +726,8 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     if ((size_t)(base - (char *)workspace) + p.total_bytes - 256 > workspace_bytes) return fail(HALO_E_WORKSPACE, "halo_greedy_select: workspace too small");
     BinWs ws;
     ws.hdr = (SelHdr *)(base + p.off_hdr);
-    ws.rng = score_range ? (const SelHdr *)score_range : ws.hdr;      // the scorer already knows the range: no pass over the map
+    ws.rng = score_range ? (SelHdr *)score_range : ws.hdr;            // the scorer already knows the range: no pass over the map
+    ws.rng_hist = score_range ? (const unsigned *)((const char *)score_range + range_hist_offset(B)) : nullptr;
     ws.hist1 = (unsigned *)(base + p.off_hist1);
     ws.fcur = (unsigned *)(base + p.off_fcur);
     ws.cbase = (unsigned *)(base + p.off_cbase);

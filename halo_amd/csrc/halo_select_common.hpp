@@ -90,6 +90,39 @@ struct SelHdr {
 static_assert(sizeof(SelHdr) == 64, "SelHdr is 64 bytes");
 enum { SEL_RUN = 0, SEL_DONE = 1, SEL_BAIL = 2 };
 enum { SEL_F_BAD = 1,              // NaN or +inf present: the value range cannot be binned
-       SEL_F_OVERFLOW = 2 };       // a fine bin received more candidates than it has slots (a plateau of ties)
+       SEL_F_OVERFLOW = 2,         // a fine bin received more candidates than it has slots (a plateau of ties)
+       SEL_F_HIST = 4 };           // (range records of the scorer) the coarse histogram behind the records is valid for this image
+
+constexpr int NB1 = 2048;          // coarse bins of the value-binned selector
+
+// A range record buffer (halo_score_range_bytes): B records, then -- 256-byte aligned -- B coarse histograms of NB1 counters.  The
+// scorer's fused tail fills a histogram while it writes a normalised score map (k_combine_box3) and sets SEL_F_HIST; the selector
+// then skips its own pass over the map (k_sel_hist1) and CONSUMES the flag (k_sel_scan1 clears it: the counts describe the map as
+// it was when it was scored).
+__host__ __device__ inline size_t range_hist_offset(long long B) { return ((size_t)B * sizeof(SelHdr) + 255) / 256 * 256; }
+
+struct ValRange { double lo, scale; bool ok; };
+
+__device__ __forceinline__ ValRange sel_range(const SelHdr &h)
+{
+    ValRange r;
+    const double lo = key_value(~h.kmin_inv), hi = key_value(h.kmax);
+    r.lo = lo;
+    r.scale = (double)NB1 / (hi - lo);
+    r.ok = !(h.flags & SEL_F_BAD) && h.nvalid > 0 && hi > lo && r.scale > 0.0 && r.scale < 1.0e300;
+    return r;
+}
+
+// coarse bin of a finite value v; t = position in bin units (monotone, non-decreasing in v).  The range record only has to bound
+// the values for the bins to be well filled, NOT for correctness: a value below `lo` is clamped into the lowest bin explicitly
+// (t >= 0: nothing relies on how a negative double converts), one above `hi` into the highest, and the sub-bin of such a value
+// is clamped by its caller -- binning stays monotone, so the picks do not depend on the record.
+__device__ __forceinline__ int coarse_bin(double v, const ValRange &r, double &t)
+{
+    t = (v - r.lo) * r.scale;
+    t = t > 0.0 ? t : 0.0;
+    const int j = t < (double)(NB1 - 1) ? (int)t : NB1 - 1;
+    return j;
+}
 
 }  // namespace halo

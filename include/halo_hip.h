@@ -224,9 +224,14 @@ int halo_greedy_select(void *score, int dtype, int64_t B, int64_t H, int64_t W, 
                        int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                        void *workspace, size_t workspace_bytes, int method, void *stream);
 
-/* halo_greedy_select given the value range of each score map (`score_range`: B records from halo_score_maps_timed /
- * halo_score_maps_lr_timed or halo_score_range; NULL = find it here).  The range only has to BOUND the finite values: the
- * binning is monotone, so the picks do not depend on it.  halo_score_range computes the exact records of existing maps. */
+/* halo_greedy_select given the value range of each score map (`score_range`: a buffer of halo_score_range_bytes(B) bytes filled
+ * by halo_score_maps_timed / halo_score_maps_lr_timed or halo_score_range for the same B maps; NULL = find it here).  The range
+ * only has to BOUND the finite values: the binning is monotone, so the picks do not depend on it.  The buffer also holds room
+ * for the selector's coarse histogram of each map (2048 counters): for normalised maps the scorer counts it while it writes the
+ * score and marks the record; the selector then skips its pass over the map and CLEARS the mark (the buffer is written through
+ * the const pointer's storage: the counts describe the map as it was scored and are used once; should the caller have changed
+ * the map in between, the sweep hands an exhausted image over to the serial kernel instead of trusting them -- results never
+ * depend on the histogram).  halo_score_range computes the exact range records of existing maps (no histogram). */
 size_t halo_score_range_bytes(int64_t B);
 int halo_score_range(const void *score, int dtype, int64_t B, int64_t H, int64_t W, void *score_range, void *stream);
 int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,

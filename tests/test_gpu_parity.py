@@ -850,6 +850,64 @@ def test_selection_with_the_scorers_range_records(dev):
     assert bits_equal(outs[0], outs[1])
 
 
+def test_fused_selector_histogram_is_consumed_once_and_survives_a_changed_map(dev, monkeypatch):
+    """Round 4: for normalised maps the combine kernel counts the selector's 2048-bin coarse histogram while it
+    writes the score and hands it over behind the range records; the selector skips its own pass over the map.  (1) same picks,
+    tables and masks as with HALO_NO_FUSE_HIST=1 (the selector counts) and as without any record; (2) the counts describe the
+    map as it was scored: a SECOND selection with the same records (windows now -inf) must not trust them -- the flag is consumed
+    by the first; (3) a map the caller changed between scoring and selection (a large region masked by hand, so that fewer
+    candidates exist above the threshold than the counts promise) still selects exactly what the unranged path selects: the sweep
+    hands an exhausted image over instead of concluding that nothing is left."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import new_score_range, score_maps
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(13)
+    B, C, O, H, W = 3, 8, 19, 96, 160
+    emb = ho.bilinear(ho.expmap((rng.standard_normal((B, C, H // 4, W // 4)) * 0.2).astype(np.float32), 1.0, dim=1), (H, W))
+    logit = ho.bilinear(rng.standard_normal((B, O, H // 4, W // 4)).astype(np.float32), (H, W))
+    gt = t(rng.integers(0, O, (B, H, W)).astype(np.int64), dev)
+    act0 = rng.random((B, H, W)) < 0.02
+    lg, em = t(logit, dev), t(emb, dev)
+
+    def run(ranged, n, premask=None, twice=False):
+        rec = new_score_range(B, dev) if ranged else None
+        act = t(act0, dev).clone()
+        sc = score_maps(lg, em, "entropy", "radius", True, None, size=3, active=act, want_maps=False, score_range=rec)[0]
+        if premask is not None:
+            sc[premask] = -float("inf")
+        sel = torch.zeros_like(act)
+        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+        outs = []
+        for _ in range(2 if twice else 1):
+            pk, nk = greedy_select(sc, n, 1, 5, act, sel, am, gt, score_range=rec)
+            outs.append((pk.cpu().numpy().copy(), nk.cpu().numpy().copy()))
+        return outs, act.cpu().numpy(), sel.cpu().numpy(), am.cpu().numpy(), sc.cpu().numpy()
+
+    n = 40
+    base = run(False, n)
+    fused = run(True, n)
+    monkeypatch.setenv("HALO_NO_FUSE_HIST", "1")
+    unfused = run(True, n)
+    monkeypatch.delenv("HALO_NO_FUSE_HIST")
+    for other in (fused, unfused):
+        assert bits_equal(base[0][0][0], other[0][0][0]) and np.array_equal(base[0][0][1], other[0][0][1])
+        assert all(np.array_equal(x, y) for x, y in zip(base[1:4], other[1:4])) and bits_equal(base[4], other[4])
+    assert int(base[0][0][1].min()) == n
+    # (2) two selections in a row with the same records
+    b2, f2 = run(False, n, twice=True), run(True, n, twice=True)
+    for k in range(2):
+        assert bits_equal(b2[0][k][0], f2[0][k][0]) and np.array_equal(b2[0][k][1], f2[0][k][1])
+    assert all(np.array_equal(x, y) for x, y in zip(b2[1:4], f2[1:4]))
+    assert int(b2[0][1][1].min()) > 0                                              # the second round still found regions
+    # (3) the caller masks the top 60 % of the rows after scoring: the counts are stale
+    pm = torch.zeros((B, H, W), dtype=torch.bool, device=dev)
+    pm[:, : int(H * 0.6)] = True
+    n3 = 60
+    b3, f3 = run(False, n3, premask=pm), run(True, n3, premask=pm)
+    assert bits_equal(b3[0][0][0], f3[0][0][0]) and np.array_equal(b3[0][0][1], f3[0][0][1])
+    assert all(np.array_equal(x, y) for x, y in zip(b3[1:4], f3[1:4])) and int(b3[0][0][1].min()) > 0
+
+
 def test_score_and_select_replay_from_a_hip_graph(dev):
     """include/halo_hip.h promises that every call is an asynchronous enqueue with no allocation, no host sync and no global
     state, hence hipGraph-capturable.  Capture one acquisition (score -> range record -> mask -> select, ~12 launches incl. the
