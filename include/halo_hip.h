@@ -122,9 +122,10 @@ int halo_score_maps(const float *logit, int64_t logit_bstride, const void *feat,
 /* Same call with two optional hipEvent_t (as void*, from halo_event_create) recorded on `stream`
  * immediately before and after the feature-reduction kernel (k_feat_reduce, the HBM-roofline
  * kernel) -- used by bench.py to time that kernel live inside the pipelined run -- and an optional
- * `score_range` output (B records of halo_score_range_bytes(1) bytes, NULL = none): the value range of each
- * score map in the form halo_greedy_select_ranged accepts, so that the selector need not read the map once more
- * to find it.  Free when the maps are normalised (a product of two values in [0, 1]); otherwise reduced exactly. */
+ * `score_range` output (a buffer of halo_score_range_bytes(B) bytes for these B maps, NULL = none): the value range of each
+ * score map -- and, for normalised maps, the selector's coarse histogram of it -- in the form halo_greedy_select_ranged
+ * accepts, so that the selector need not read the map once or twice more to find them.  Free when the maps are normalised
+ * (a product of two values in [0, 1]); otherwise the range is reduced exactly and no histogram is handed over. */
 int halo_score_maps_timed(const float *logit, int64_t logit_bstride, const void *feat, int feat_dtype,
                           int64_t feat_bstride, const int64_t *gt, const uint8_t *active, int64_t B, int64_t O,
                           int64_t C, int64_t H, int64_t W, int unc_type, int pur_type, int normalize, int ksize,
