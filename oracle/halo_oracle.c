@@ -721,7 +721,7 @@ i64 halo_o_select(void *score, int dtype, i64 H, i64 W, i64 n_regions, i64 activ
             for (i64 x = as_w; x < ae_w; ++x) { selected[y * W + x] = 1; active_mask[y * W + x] = gt[y * W + x]; }
         /* the table's value column holds the score's class under the selection order (-0 ties with +0, every NaN is one value):
          * +0 for either zero, the canonical quiet NaN for any NaN -- what halo_greedy_select reports (the reference keeps no
-         * table; found by tools/fuzz_parity.py on an all -0.0 map) */
+         * table; found by tests/fuzz_parity.py on an all -0.0 map) */
         double rv = mv == 0.0 ? 0.0 : mv;
         if (mv != mv) { const unsigned long long qn = 0x7ff8000000000000ull; memcpy(&rv, &qn, 8); }
         picks[np_ * 3 + 0] = (double)h; picks[np_ * 3 + 1] = (double)w; picks[np_ * 3 + 2] = rv;

@@ -1,7 +1,7 @@
 """Randomised differential test of the head-side entry points on one MI355X against the CPU oracle: expmap / logmap / dist0 / pdist
 (bit for bit where the two share one written sequence of operations, a stated tolerance where the device uses the matrix cores or
 the library's tanh), HyperMLR logits (float64 and float32 output, class counts on both sides of the MFMA path's limit of 32),
-bilinear resize (float32 / float64, up- and down-sampling, degenerate sizes).  `python tools/fuzz_head.py [n_cases] [seed]`."""
+bilinear resize (float32 / float64, up- and down-sampling, degenerate sizes).  `python tests/fuzz_head.py [n_cases] [seed]`."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,6 @@
 """Randomised differential test on one MI355X: HIP path vs the CPU oracle, bit for bit, over random shapes / branches / window
 sizes / padding modes / dtypes / low-res geometries and modes / selection parameters -- the configurations the fixed parity tests
-do not enumerate.  Not a pytest (minutes): `python tools/fuzz_parity.py [n_cases] [seed]`, one line per case, a summary at the end;
+do not enumerate.  Test infrastructure (it drives the CPU oracle, so it lives under tests/); not collected by pytest (minutes): `python tests/fuzz_parity.py [n_cases] [seed]`, one line per case, a summary at the end;
 exit code 1 on the first mismatch (the case's parameters are printed so that it can be replayed with the same seed)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

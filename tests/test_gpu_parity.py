@@ -2193,12 +2193,12 @@ def test_binned_selection_repeats_identically(dev):
 
 
 def test_randomised_differential_run_vs_oracle(dev):
-    """tools/fuzz_parity.py as a regression: 200 random configurations (shapes, branches, window sizes, padding modes, dtypes,
+    """tests/fuzz_parity.py as a regression: 200 random configurations (shapes, branches, window sizes, padding modes, dtypes,
     low-res geometries and modes, selection parameters, NaN / inf logits) -- HIP == oracle bit for bit in maps, picks, masks.
     (Round 4: the first run found that the pick table reports +0 for a -0.0 score and the canonical NaN for any NaN while the
     oracle kept the raw bits; the table's convention is now written down and the oracle follows it.)"""
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "200", "11"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "200", "11"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "HIP == oracle bit for bit" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
