@@ -973,10 +973,42 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
     ValRange vr;
     vr.lo = 0.0; vr.scale = (double)NB1; vr.ok = true;       // = sel_range of the record above
     const int yend = (blockIdx.y + 1) * CB_ROWS < H ? (blockIdx.y + 1) * CB_ROWS : H;
+    // the three-row window slides down the workgroup's rows: CB_ROWS + 2 row loads instead of 3 per row, the same taps added in the
+    // same (row-major) order as box3_row4 / k_box3_minmax
+    const float *ep = ent + (size_t)b * hw;
+    const int lane = threadIdx.x & 63;
+    auto load_row = [&](int yy, float (&r)[6]) {
+        const bool in = live && yy >= 0 && yy < H;
+        const float *row = ep + (size_t)(in ? yy : 0) * W;
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (in) q = *reinterpret_cast<const float4 *>(row + x);
+        float left = lane_prev(q.w), right = lane_next(q.x);
+        if (lane == 0) left = (in && x > 0) ? row[x - 1] : 0.0f;
+        if (lane == 63) right = (in && x + 4 < W) ? row[x + 4] : 0.0f;
+        r[0] = (in && x > 0) ? left : 0.0f;
+        r[1] = q.x; r[2] = q.y; r[3] = q.z; r[4] = q.w;
+        r[5] = (in && x + 4 < W) ? right : 0.0f;
+    };
+    float r0[6], r1[6], r2[6];
+    load_row(blockIdx.y * CB_ROWS - 1, r0);
+    load_row(blockIdx.y * CB_ROWS, r1);
     for (int y = blockIdx.y * CB_ROWS; y < yend; ++y) {
+        load_row(y + 1, r2);                                  // every lane of the wave: the lane shifts are wave-wide
         float un[4];
-        box3_row4(ent + (size_t)b * hw, H, W, y, live ? x : 0, live, pk, un);
-        if (!live) continue;                                  // (the lane shifts of box3_row4 are done: idle lanes may skip the rest)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.0f;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a = a + r0[j + dx];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a = a + r1[j + dx];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a = a + r2[j + dx];
+            un[j] = box3_over_count(a, H, W, y, x + j, pk);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { r0[q] = r1[q]; r1[q] = r2[q]; }
+        if (!live) continue;
         const size_t o = (size_t)b * hw + (size_t)y * W + x;
         TI im[4];
         if constexpr (sizeof(TI) == 8) {
