@@ -925,14 +925,14 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
 // writes (NB1 counters in LDS, flushed once: with one row per workgroup the flush would be an atomic per pixel).  For a normalised
 // map the score is a product of two values in [0, 1] (or -inf where masked), so the bins are those of the range record this kernel
 // writes: lo = 0, scale = NB1 -- exactly what k_sel_hist1 would count from the stored map (same coarse_bin, same exclusions).
-constexpr int CB_ROWS = 16;
+constexpr int CB_ROWS = 16;        // at most; fewer when the launch would otherwise not fill the chip (one image at a time)
 
 template <typename TI>
 __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp_raw, const float *__restrict__ ent,
                                                       const double *__restrict__ stats, const unsigned char *__restrict__ active,
                                                       int H, int W, int pk, int normalize, TI *__restrict__ score,
                                                       TI *__restrict__ imp_out, float *__restrict__ unc_out, SelHdr *__restrict__ rng,
-                                                      unsigned *__restrict__ hist)
+                                                      unsigned *__restrict__ hist, int rows)
 {
     // grid (row segments of TPB * 4 pixels, groups of CB_ROWS rows, images): no index division (a 64-bit i / W was a fifth of the
     // kernel's instructions); lanes past the end of a row idle
@@ -972,7 +972,7 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
     }
     ValRange vr;
     vr.lo = 0.0; vr.scale = (double)NB1; vr.ok = true;       // = sel_range of the record above
-    const int yend = (blockIdx.y + 1) * CB_ROWS < H ? (blockIdx.y + 1) * CB_ROWS : H;
+    const int ybeg = blockIdx.y * rows, yend = ybeg + rows < H ? ybeg + rows : H;
     // the three-row window slides down the workgroup's rows: CB_ROWS + 2 row loads instead of 3 per row, the same taps added in the
     // same (row-major) order as box3_row4 / k_box3_minmax
     const float *ep = ent + (size_t)b * hw;
@@ -990,9 +990,9 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
         r[5] = (in && x + 4 < W) ? right : 0.0f;
     };
     float r0[6], r1[6], r2[6];
-    load_row(blockIdx.y * CB_ROWS - 1, r0);
-    load_row(blockIdx.y * CB_ROWS, r1);
-    for (int y = blockIdx.y * CB_ROWS; y < yend; ++y) {
+    load_row(ybeg - 1, r0);
+    load_row(ybeg, r1);
+    for (int y = ybeg; y < yend; ++y) {
         load_row(y + 1, r2);                                  // every lane of the wave: the lane shifts are wave-wide
         float un[4];
 #pragma unroll
@@ -2341,9 +2341,11 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
         hipLaunchKernelGGL(k_minmax_finalize2, dim3((unsigned)B, 2u), dim3(FIN_TPB), 0, st, (const double *)part_imp, nblk_imp,
                            (const double *)part_unc, nblk_unc, stats);
     if (fuse_tail) {
-        dim3 gridc((unsigned)cdiv(W, TPB * 4), (unsigned)cdiv(H, CB_ROWS), (unsigned)B);
-        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty, rng_free, rng_hist);
-        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty, rng_free, rng_hist);
+        int crows = CB_ROWS;                 // rows per workgroup: as many as leave >= 1024 workgroups in the launch
+        while (crows > 1 && cdiv(W, TPB * 4) * cdiv(H, crows) * B < 1024) crows >>= 1;
+        dim3 gridc((unsigned)cdiv(W, TPB * 4), (unsigned)cdiv(H, crows), (unsigned)B);
+        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty, rng_free, rng_hist, crows);
+        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty, rng_free, rng_hist, crows);
     } else if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
     if (score_range && !rng_free) {
