@@ -229,4 +229,15 @@ __device__ __forceinline__ float dist0_from_ssq(float ssq, double ks, double rks
     return 2.0f * ((float)rks * a);
 }
 
+// Bilinear combination of the four taps of one output element, F.interpolate(mode='bilinear', align_corners=True)
+// (build.py:123-135; classifier.py:375-377,556-557) in ATen's order -- columns first, rows second, each p*q + r*s as
+// fma(p, q, r*s): bit for bit torch's CPU kernel at the shapes the path runs (oracle/halo_oracle.c, halo_o_bilinear_*).
+__device__ __forceinline__ double col_lerp(double lx0, double lx1, double v0, double v1) { return __builtin_fma(lx0, v0, lx1 * v1); }
+__device__ __forceinline__ float col_lerp(float lx0, float lx1, float v0, float v1) { return __builtin_fmaf(lx0, v0, lx1 * v1); }
+template <typename T>
+__device__ __forceinline__ T bilerp(T v00, T v01, T v10, T v11, T lx0, T lx1, T ly0, T ly1)
+{
+    return col_lerp(ly0, ly1, col_lerp(lx0, lx1, v00, v01), col_lerp(lx0, lx1, v10, v11));
+}
+
 }  // namespace halo

@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
 }
 
 // ---------------------------------------------------------------- bilinear, align_corners=True
-// out = fma(v11,w11, fma(v10,w10, fma(v00,w00, v01*w01))), w_ij = ly_i*lx_j, weights in the tensor's dtype
+// out = bilerp (halo_devmath.hpp): columns first, rows second, fma(l0, a, l1*b) -- ATen's order; weights in the tensor's dtype
 template <typename T>
 __global__ void __launch_bounds__(HTPB) k_bilinear(const T *__restrict__ src, T *__restrict__ dst, long long planes, int h, int w,
                                                    int H, int W, T sh, T sw)
@@ -633,17 +633,7 @@ __global__ void __launch_bounds__(HTPB) k_bilinear(const T *__restrict__ src, T 
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
     const T ly1 = fy - (T)y0, ly0 = (T)1 - ly1, lx1 = fx - (T)x0, lx0 = (T)1 - lx1;
     const T *r0 = src + ((size_t)p * h + y0) * w, *r1 = src + ((size_t)p * h + y1) * w;
-    T a = r0[x1] * (ly0 * lx1);
-    if constexpr (sizeof(T) == 8) {
-        a = __builtin_fma(r0[x0], ly0 * lx0, a);
-        a = __builtin_fma(r1[x0], ly1 * lx0, a);
-        a = __builtin_fma(r1[x1], ly1 * lx1, a);
-    } else {
-        a = __builtin_fmaf(r0[x0], ly0 * lx0, a);
-        a = __builtin_fmaf(r1[x0], ly1 * lx0, a);
-        a = __builtin_fmaf(r1[x1], ly1 * lx1, a);
-    }
-    dst[idx] = a;
+    dst[idx] = bilerp<T>(r0[x0], r0[x1], r1[x0], r1[x1], lx0, lx1, ly0, ly1);
 }
 
 
@@ -662,7 +652,7 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_rows(const T *__restrict__ sr
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
     const T ly1 = fy - (T)y0, ly0 = (T)1 - ly1;
     int x0[VEC], x1[VEC];
-    T w00[VEC], w01[VEC], w10[VEC], w11[VEC];
+    T lx0[VEC], lx1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const T fx = sw * (T)(xb + j);
@@ -670,25 +660,15 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_rows(const T *__restrict__ sr
         a = a > w - 1 ? w - 1 : a;
         x0[j] = a;
         x1[j] = a + (a < w - 1 ? 1 : 0);
-        const T lx1 = fx - (T)a, lx0 = (T)1 - lx1;
-        w00[j] = ly0 * lx0; w01[j] = ly0 * lx1; w10[j] = ly1 * lx0; w11[j] = ly1 * lx1;
+        lx1[j] = fx - (T)a;
+        lx0[j] = (T)1 - lx1[j];
     }
     for (int p = blockIdx.z; p < planes; p += gridDim.z) {
         const T *r0 = src + ((size_t)p * h + y0) * w, *r1 = src + ((size_t)p * h + y1) * w;
         T o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            T a = r0[x1[j]] * w01[j];
-            if constexpr (sizeof(T) == 8) {
-                a = __builtin_fma(r0[x0[j]], w00[j], a);
-                a = __builtin_fma(r1[x0[j]], w10[j], a);
-                a = __builtin_fma(r1[x1[j]], w11[j], a);
-            } else {
-                a = __builtin_fmaf(r0[x0[j]], w00[j], a);
-                a = __builtin_fmaf(r1[x0[j]], w10[j], a);
-                a = __builtin_fmaf(r1[x1[j]], w11[j], a);
-            }
-            o[j] = a;
+            o[j] = bilerp<T>(r0[x0[j]], r0[x1[j]], r1[x0[j]], r1[x1[j]], lx0[j], lx1[j], ly0, ly1);
         }
         T *q = dst + ((size_t)p * H + y) * W + xb;
         if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));
@@ -1011,7 +991,7 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
     sx1 += sx1 < w - 1 ? 1 : 0;
     const int ncol = sx1 - sx0 + 1;                                // <= span (host bound)
     int x0[VEC], x1[VEC];
-    T w00[VEC], w01[VEC], w10[VEC], w11[VEC];
+    T lx0[VEC], lx1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int x = xb + j < W ? xb + j : W - 1;
@@ -1020,8 +1000,8 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
         a = a > w - 1 ? w - 1 : a;
         x0[j] = a - sx0;
         x1[j] = a + (a < w - 1 ? 1 : 0) - sx0;
-        const T lx1 = fx - (T)a, lx0 = (T)1 - lx1;
-        w00[j] = ly0 * lx0; w01[j] = ly0 * lx1; w10[j] = ly1 * lx0; w11[j] = ly1 * lx1;
+        lx1[j] = fx - (T)a;
+        lx0[j] = (T)1 - lx1[j];
     }
     for (int p0 = blockIdx.z * BL_PC; p0 < planes; p0 += gridDim.z * BL_PC) {
         __syncthreads();                                           // the previous chunk's taps have been read
@@ -1043,17 +1023,7 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
                 T o[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    T a = r0[x1[j]] * w01[j];
-                    if constexpr (sizeof(T) == 8) {
-                        a = __builtin_fma(r0[x0[j]], w00[j], a);
-                        a = __builtin_fma(r1[x0[j]], w10[j], a);
-                        a = __builtin_fma(r1[x1[j]], w11[j], a);
-                    } else {
-                        a = __builtin_fmaf(r0[x0[j]], w00[j], a);
-                        a = __builtin_fmaf(r1[x0[j]], w10[j], a);
-                        a = __builtin_fmaf(r1[x1[j]], w11[j], a);
-                    }
-                    o[j] = a;
+                    o[j] = bilerp<T>(r0[x0[j]], r0[x1[j]], r1[x0[j]], r1[x1[j]], lx0[j], lx1[j], ly0, ly1);
                 }
                 T *q = dst + ((size_t)(p0 + pl) * H + y) * W + xb;
                 if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));
@@ -1070,8 +1040,7 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
 // Round 3: BL_RO output rows per block.  Up-sampling by f reuses every source row for f output rows, so a block that owns
 // one output row (above) stages two source rows and synchronises twice for every 16 bytes it stores per lane and plane; here
 // a block owns BL_RO consecutive output rows: the <= BL_SR source rows they touch are staged once per plane chunk, and a
-// thread has BL_PC * BL_RO 16-byte stores in flight per pair of barriers instead of BL_PC.  Weights are formed from the row
-// and column fractions where they are used (w = ly * lx, the same rounded product as the precomputed ones: same bits).
+// thread has BL_PC * BL_RO 16-byte stores in flight per pair of barriers instead of BL_PC.  Same arithmetic (bilerp), same bits.
 constexpr int BL_RO = 4, BL_SR = 6, BL_PCR = 4;     // output rows per block, source rows staged at most, planes per chunk
 
 template <typename T, int VEC>
@@ -1143,24 +1112,13 @@ __global__ void __launch_bounds__(HTPB, 4) k_bilinear_lds_rows(const T *__restri
                 for (int r = 0; r < BL_RO; ++r) {
                     if (yb + r >= H) break;
                     const T *r0 = tp + ry0[r], *r1 = tp + ry1[r];
-                    // the 4 * VEC weight products of a row are formed here, per plane: hoisted out of the plane loop they would
-                    // be BL_RO * VEC * 4 live values (64 registers) and the kernel would spill; the empty asm keeps them here
+                    // (the empty asm keeps the row's fractions from being hoisted and duplicated per plane)
                     T l0 = ly0[r], l1 = ly1[r];
                     asm volatile("" : "+v"(l0), "+v"(l1));
                     T o[VEC];
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
-                        T a = r0[x1[j]] * (l0 * lx1[j]);
-                        if constexpr (sizeof(T) == 8) {
-                            a = __builtin_fma(r0[x0[j]], l0 * lx0[j], a);
-                            a = __builtin_fma(r1[x0[j]], l1 * lx0[j], a);
-                            a = __builtin_fma(r1[x1[j]], l1 * lx1[j], a);
-                        } else {
-                            a = __builtin_fmaf(r0[x0[j]], l0 * lx0[j], a);
-                            a = __builtin_fmaf(r1[x0[j]], l1 * lx0[j], a);
-                            a = __builtin_fmaf(r1[x1[j]], l1 * lx1[j], a);
-                        }
-                        o[j] = a;
+                        o[j] = bilerp<T>(r0[x0[j]], r0[x1[j]], r1[x0[j]], r1[x1[j]], lx0[j], lx1[j], l0, l1);
                     }
                     T *q = dst + ((size_t)(p0 + pl) * H + yb + r) * W + xb;
                     if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));

@@ -1087,23 +1087,19 @@ __device__ __forceinline__ Taps<T> make_taps(int o, T scale, int in_size)
     t.l0 = (T)1 - t.l1;
     return t;
 }
-template <typename T>
-__device__ __forceinline__ T lerp4(T v00, T v01, T v10, T v11, T w00, T w01, T w10, T w11)
-{
-    T a = v01 * w01;
-    a = fma_t(v00, w00, a);
-    a = fma_t(v10, w10, a);
-    return fma_t(v11, w11, a);
-}
-
 constexpr int LR_STAGE_IT = 3, LR_STAGE_G = 4;      // window elements per lane with precomputed offsets (<= 192 taps), channels per group
 constexpr int LR_TW = 64, LR_TH = 16, LR_PPT = 4;   // 64 x 16 output pixels per 256-thread block; a wave owns 4 consecutive rows x 64 columns
+
+// bilinear weights of a lane's LR_PPT vertically adjacent output pixels (one column: lx shared, one ly pair per pixel).
+// The four taps are combined by bilerp (halo_devmath.hpp): columns first, rows second -- ATen's order.
+template <typename T> struct LrW { T lx0, lx1, ly0[LR_PPT], ly1[LR_PPT]; };
+
 
 // One channel chunk of the window for a lane's LR_PPT vertically adjacent pixels, when their upper tap rows are
 // R + {0, PAT bit 0, PAT bit 1, PAT bit 2} (wave-uniform, compile-time): the lane reads the 2 or 3 source rows once per
 // channel -- 4 or 6 LDS words instead of the 16 of four independent pixels -- and every pixel picks its rows by register
 // name.  The LDS pipe (128 bytes per clock and CU, shared by the four SIMDs) is what bounds this kernel, not the 5 float64
-// operations per pixel and channel.  Same lerp4 per pixel as the generic loop, so the same bits.
+// operations per pixel and channel.  Same bilerp per pixel as the generic loop (the column interpolation of a row is one expression, shared), so the same bits.
 // The six LDS words of a lane (rows R..R+2, columns q and q + 1).  For 8-byte elements they are read by hand-written
 // ds_read_b64 (2 LDS cycles each, 256 bytes per clock): the compiler fuses each (q, q + 1) pair into one ds_read2_b64,
 // which moves the same 16 bytes per lane in 16 LDS cycles and leaves the kernel bound by the LDS pipe at 2.4x its float64
@@ -1136,26 +1132,30 @@ template <typename T, int PAT> struct LrRows {
             if constexpr (PAT != 0) { v[2][0] = tp[2 * stride]; v[2][1] = tp[2 * stride + 1]; }
         }
     }
-    __device__ __forceinline__ void accumulate(const T (&w00)[LR_PPT], const T (&w01)[LR_PPT], const T (&w10)[LR_PPT],
-                                               const T (&w11)[LR_PPT], T (&acc)[LR_PPT]) const
+    __device__ __forceinline__ void accumulate(const LrW<T> &wt, T (&acc)[LR_PPT]) const
     {
+        // the column interpolation of each source row once, shared by the lane's pixels that read the row (2 or 3 rows for 4
+        // pixels: 16-18 float64 operations per channel where four independent pixels take 28)
+        T t[3];
+        t[0] = col_lerp(wt.lx0, wt.lx1, v[0][0], v[0][1]);
+        t[1] = col_lerp(wt.lx0, wt.lx1, v[1][0], v[1][1]);
+        if constexpr (PAT != 0) t[2] = col_lerp(wt.lx0, wt.lx1, v[2][0], v[2][1]);
 #pragma unroll
         for (int j = 0; j < LR_PPT; ++j) {
             const int a = j == 0 ? 0 : (PAT >> (j - 1)) & 1;      // 0 or 1; a + 1 == 2 only when PAT != 0
-            const T x = lerp4<T>(v[a][0], v[a][1], v[a + 1][0], v[a + 1][1], w00[j], w01[j], w10[j], w11[j]);
+            const T x = col_lerp(wt.ly0[j], wt.ly1[j], t[a], t[a + 1]);
             acc[j] = fma_t(x, x, acc[j]);
         }
     }
 };
 template <typename T, int PAT>
-__device__ __forceinline__ void lr_rows_chunk(const T *__restrict__ tp, int cc, int plane, int stride, const T (&w00)[LR_PPT],
-                                              const T (&w01)[LR_PPT], const T (&w10)[LR_PPT], const T (&w11)[LR_PPT], T (&acc)[LR_PPT])
+__device__ __forceinline__ void lr_rows_chunk(const T *__restrict__ tp, int cc, int plane, int stride, const LrW<T> &wt, T (&acc)[LR_PPT])
 {
 #pragma unroll 1
     for (int ch = 0; ch < cc; ++ch, tp += plane) {
         LrRows<T, PAT> A;
         A.load(tp, stride);
-        A.accumulate(w00, w01, w10, w11, acc);
+        A.accumulate(wt, acc);
     }
 }
 
@@ -1191,7 +1191,9 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
     const int rows = ty_hi - ty_lo + 2, cols = tx_hi - tx_lo + 2;            // with the extra row / column; <= max_rows / max_cols
     const bool xin = x < W;
     const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
-    T acc[LR_PPT], w00[LR_PPT], w01[LR_PPT], w10[LR_PPT], w11[LR_PPT];
+    T acc[LR_PPT];
+    LrW<T> wt;
+    wt.lx0 = tx.l0; wt.lx1 = tx.l1;
     int o00[LR_PPT], o10[LR_PPT];
     bool live[LR_PPT];
     int a0 = 0, pat = 0;
@@ -1201,7 +1203,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
         const int y = Y0 + ly * LR_PPT + j;
         live[j] = xin && y < H;
         const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
-        w00[j] = ty.l0 * tx.l0; w01[j] = ty.l0 * tx.l1; w10[j] = ty.l1 * tx.l0; w11[j] = ty.l1 * tx.l1;
+        wt.ly0[j] = ty.l0; wt.ly1[j] = ty.l1;
         o00[j] = (ty.i0 - ty_lo) * max_cols + (tx.i0 - tx_lo);
         o10[j] = (ty.i1 - ty_lo) * max_cols + (tx.i0 - tx_lo);
         acc[j] = (T)0;
@@ -1261,10 +1263,10 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
         }
         __syncthreads();
         const T *t0 = tile + o00[0];
-        if (upat == 0) lr_rows_chunk<T, 0>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
-        else if (upat == 4) lr_rows_chunk<T, 4>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
-        else if (upat == 6) lr_rows_chunk<T, 6>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
-        else if (upat == 7) lr_rows_chunk<T, 7>(t0, cc, plane, max_cols, w00, w01, w10, w11, acc);
+        if (upat == 0) lr_rows_chunk<T, 0>(t0, cc, plane, max_cols, wt, acc);
+        else if (upat == 4) lr_rows_chunk<T, 4>(t0, cc, plane, max_cols, wt, acc);
+        else if (upat == 6) lr_rows_chunk<T, 6>(t0, cc, plane, max_cols, wt, acc);
+        else if (upat == 7) lr_rows_chunk<T, 7>(t0, cc, plane, max_cols, wt, acc);
         else {
             // any other geometry (factors below 3, rows clamped past the image): four independent pixels
 #pragma unroll 1
@@ -1272,7 +1274,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
                 const T *tp = tile + ch * plane;
 #pragma unroll
                 for (int j = 0; j < LR_PPT; ++j) {
-                    const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
+                    const T v = bilerp<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], wt.lx0, wt.lx1, wt.ly0[j], wt.ly1[j]);
                     acc[j] = fma_t(v, v, acc[j]);
                 }
             }
@@ -1314,7 +1316,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr(const T *__restrict__ fe
 //   * a pair that would start past the row's last column (only the clamped extra column of a right-edge tile) is loaded from
 //     (w - 2, w - 1) and its first half overwritten with the second after the data has landed: both halves then hold the
 //     clamped tap v[w - 1] the arithmetic expects there.
-// Same lerp4 / fma chains per pixel, so the same bits as k_feat_reduce_lr and as upsample-then-reduce.
+// Same bilerp / fma chains per pixel, so the same bits as k_feat_reduce_lr and as upsample-then-reduce.
 constexpr int DMA_PER_WAVE = 4, DMA_UNITS = DMA_PER_WAVE * TPB;      // 1024 units = 16 KiB per image
 
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
@@ -1353,7 +1355,9 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dma(const double *__rest
     const int per = rows * U, stride = 2 * U, plane = 2 * per;   // units per channel; row / channel strides in doubles
     const bool xin = x < W;
     const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
-    T acc[LR_PPT], w00[LR_PPT], w01[LR_PPT], w10[LR_PPT], w11[LR_PPT];
+    T acc[LR_PPT];
+    LrW<T> wt;
+    wt.lx0 = tx.l0; wt.lx1 = tx.l1;
     int o00[LR_PPT], o10[LR_PPT];
     bool live[LR_PPT];
     int a0 = 0, pat = 0;
@@ -1363,7 +1367,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dma(const double *__rest
         const int y = Y0 + ly * LR_PPT + j;
         live[j] = xin && y < H;
         const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
-        w00[j] = ty.l0 * tx.l0; w01[j] = ty.l0 * tx.l1; w10[j] = ty.l1 * tx.l0; w11[j] = ty.l1 * tx.l1;
+        wt.ly0[j] = ty.l0; wt.ly1[j] = ty.l1;
         o00[j] = (ty.i0 - ty_lo) * stride + (tx.i0 - tx_lo);
         o10[j] = (ty.i1 - ty_lo) * stride + (tx.i0 - tx_lo);
         acc[j] = (T)0;
@@ -1421,17 +1425,17 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dma(const double *__rest
             __builtin_amdgcn_s_barrier();
         }
         const T *t0 = tile + o00[0];
-        if (upat == 0) lr_rows_chunk<T, 0>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
-        else if (upat == 4) lr_rows_chunk<T, 4>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
-        else if (upat == 6) lr_rows_chunk<T, 6>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
-        else if (upat == 7) lr_rows_chunk<T, 7>(t0, cc, plane, stride, w00, w01, w10, w11, acc);
+        if (upat == 0) lr_rows_chunk<T, 0>(t0, cc, plane, stride, wt, acc);
+        else if (upat == 4) lr_rows_chunk<T, 4>(t0, cc, plane, stride, wt, acc);
+        else if (upat == 6) lr_rows_chunk<T, 6>(t0, cc, plane, stride, wt, acc);
+        else if (upat == 7) lr_rows_chunk<T, 7>(t0, cc, plane, stride, wt, acc);
         else {
 #pragma unroll 1
             for (int ch = 0; ch < cc; ++ch) {
                 const T *tp = tile + (size_t)ch * plane;
 #pragma unroll
                 for (int j = 0; j < LR_PPT; ++j) {
-                    const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
+                    const T v = bilerp<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], wt.lx0, wt.lx1, wt.ly0[j], wt.ly1[j]);
                     acc[j] = fma_t(v, v, acc[j]);
                 }
             }
@@ -1492,13 +1496,18 @@ template <int PAT, int OFF, int STRIDE_B> struct LrRowsImm {
         else
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]) : "n"(N) : "memory");
     }
-    __device__ __forceinline__ void accumulate(const double (&w00)[LR_PPT], const double (&w01)[LR_PPT], const double (&w10)[LR_PPT],
-                                               const double (&w11)[LR_PPT], double (&acc)[LR_PPT]) const
+    __device__ __forceinline__ void accumulate(const LrW<double> &wt, double (&acc)[LR_PPT]) const
     {
+        // the column interpolation of each source row once, shared by the lane's pixels that read the row (2 or 3 rows for 4
+        // pixels: 16-18 float64 operations per channel where four independent pixels take 28)
+        double t[3];
+        t[0] = col_lerp(wt.lx0, wt.lx1, v[0][0], v[0][1]);
+        t[1] = col_lerp(wt.lx0, wt.lx1, v[1][0], v[1][1]);
+        if constexpr (PAT != 0) t[2] = col_lerp(wt.lx0, wt.lx1, v[2][0], v[2][1]);
 #pragma unroll
         for (int j = 0; j < LR_PPT; ++j) {
             const int a = j == 0 ? 0 : (PAT >> (j - 1)) & 1;
-            const double x = lerp4<double>(v[a][0], v[a][1], v[a + 1][0], v[a + 1][1], w00[j], w01[j], w10[j], w11[j]);
+            const double x = col_lerp(wt.ly0[j], wt.ly1[j], t[a], t[a + 1]);
             acc[j] = fma_t(x, x, acc[j]);
         }
     }
@@ -1506,29 +1515,27 @@ template <int PAT, int OFF, int STRIDE_B> struct LrRowsImm {
 
 template <int PAT, int ROWS, int UU, int CH, int CCF>
 __device__ __forceinline__ void lr_imm_steps(unsigned base, int cc, LrRowsImm<PAT, (CH % CCF) * ROWS * UU * 16, UU * 16> &cur,
-                                             const double (&w00)[LR_PPT], const double (&w01)[LR_PPT], const double (&w10)[LR_PPT],
-                                             const double (&w11)[LR_PPT], double (&acc)[LR_PPT])
+                                             const LrW<double> &wt, double (&acc)[LR_PPT])
 {
     constexpr int NREAD = PAT != 0 ? 6 : 4;
     if constexpr (CH + 1 < CCF) {
         LrRowsImm<PAT, ((CH + 1) % CCF) * ROWS * UU * 16, UU * 16> nxt;
         nxt.issue(base);                                   // channel CH + 1 on its way ...
         cur.template wait<NREAD>();                        // ... channel CH has landed
-        if (CH < cc) cur.accumulate(w00, w01, w10, w11, acc);
-        lr_imm_steps<PAT, ROWS, UU, CH + 1, CCF>(base, cc, nxt, w00, w01, w10, w11, acc);
+        if (CH < cc) cur.accumulate(wt, acc);
+        lr_imm_steps<PAT, ROWS, UU, CH + 1, CCF>(base, cc, nxt, wt, acc);
     } else {
         cur.template wait<0>();
-        if (CH < cc) cur.accumulate(w00, w01, w10, w11, acc);
+        if (CH < cc) cur.accumulate(wt, acc);
     }
 }
 
 template <int PAT, int ROWS, int UU, int CCF>
-__device__ __forceinline__ void lr_imm_chunk(unsigned base, int cc, const double (&w00)[LR_PPT], const double (&w01)[LR_PPT],
-                                             const double (&w10)[LR_PPT], const double (&w11)[LR_PPT], double (&acc)[LR_PPT])
+__device__ __forceinline__ void lr_imm_chunk(unsigned base, int cc, const LrW<double> &wt, double (&acc)[LR_PPT])
 {
     LrRowsImm<PAT, 0, UU * 16> first;
     first.issue(base);
-    lr_imm_steps<PAT, ROWS, UU, 0, CCF>(base, cc, first, w00, w01, w10, w11, acc);
+    lr_imm_steps<PAT, ROWS, UU, 0, CCF>(base, cc, first, wt, acc);
 }
 
 template <int MODE, int ROWS, int UU>
@@ -1557,7 +1564,9 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
     const int tx_lo = make_taps<T>(X0, sw, w).i0 & ~1, tx_hi = make_taps<T>(xlast, sw, w).i1;
     const bool xin = x < W;
     const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
-    T acc[LR_PPT], w00[LR_PPT], w01[LR_PPT], w10[LR_PPT], w11[LR_PPT];
+    T acc[LR_PPT];
+    LrW<T> wt;
+    wt.lx0 = tx.l0; wt.lx1 = tx.l1;
     int o00[LR_PPT], o10[LR_PPT];
     bool live[LR_PPT];
     int a0 = 0, pat = 0;
@@ -1567,7 +1576,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
         const int y = Y0 + ly * LR_PPT + j;
         live[j] = xin && y < H;
         const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
-        w00[j] = ty.l0 * tx.l0; w01[j] = ty.l0 * tx.l1; w10[j] = ty.l1 * tx.l0; w11[j] = ty.l1 * tx.l1;
+        wt.ly0[j] = ty.l0; wt.ly1[j] = ty.l1;
         o00[j] = (ty.i0 - ty_lo) * STRIDE + (tx.i0 - tx_lo);
         o10[j] = (ty.i1 - ty_lo) * STRIDE + (tx.i0 - tx_lo);
         acc[j] = (T)0;
@@ -1639,17 +1648,17 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
             __builtin_amdgcn_s_barrier();
         }
         const unsigned base = lds0 + (unsigned)(n & 1) * (DMA_UNITS * 16) + (unsigned)o00[0] * 8u;
-        if (upat == 0) lr_imm_chunk<0, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
-        else if (upat == 4) lr_imm_chunk<4, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
-        else if (upat == 6) lr_imm_chunk<6, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
-        else if (upat == 7) lr_imm_chunk<7, ROWS, UU, CCF>(base, cc, w00, w01, w10, w11, acc);
+        if (upat == 0) lr_imm_chunk<0, ROWS, UU, CCF>(base, cc, wt, acc);
+        else if (upat == 4) lr_imm_chunk<4, ROWS, UU, CCF>(base, cc, wt, acc);
+        else if (upat == 6) lr_imm_chunk<6, ROWS, UU, CCF>(base, cc, wt, acc);
+        else if (upat == 7) lr_imm_chunk<7, ROWS, UU, CCF>(base, cc, wt, acc);
         else {
 #pragma unroll 1
             for (int ch = 0; ch < cc; ++ch) {
                 const T *tp = tile + (size_t)ch * PLANE;
 #pragma unroll
                 for (int j = 0; j < LR_PPT; ++j) {
-                    const T v = lerp4<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], w00[j], w01[j], w10[j], w11[j]);
+                    const T v = bilerp<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], wt.lx0, wt.lx1, wt.ly0[j], wt.ly1[j]);
                     acc[j] = fma_t(v, v, acc[j]);
                 }
             }
@@ -1867,7 +1876,7 @@ __global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ 
         if (hw <= 0x7fffffffll) { const unsigned iu = (unsigned)i; y = (int)(iu / (unsigned)W); x = (int)(iu - (unsigned)y * (unsigned)W); }
         else { y = (int)(i / W); x = (int)(i % W); }
         const Taps<double> ty = make_taps<double>(y, sh, h), tx = make_taps<double>(x, sw, w);
-        const double wt[4] = {ty.l0 * tx.l0, ty.l0 * tx.l1, ty.l1 * tx.l0, ty.l1 * tx.l1};      // the weights of lerp4
+        const double wt[4] = {ty.l0 * tx.l0, ty.l0 * tx.l1, ty.l1 * tx.l0, ty.l1 * tx.l1};      // the weights of the four corner vectors
         const size_t hwl = (size_t)h * w;
         const double *S = gram + (size_t)b * GRAM_MAPS * hwl, *Hh = S + hwl, *Vv = Hh + hwl, *D1 = Vv + hwl, *D2 = D1 + hwl;
         const unsigned c00 = (unsigned)(ty.i0 * w + tx.i0), c01 = (unsigned)(ty.i0 * w + tx.i1), c10 = (unsigned)(ty.i1 * w + tx.i0),
@@ -1889,7 +1898,7 @@ __global__ void __launch_bounds__(TPB) k_radius_gram(const double *__restrict__ 
             const double *pl = feat + (size_t)b * bstride;
             double acc = 0.0;
             for (int ch = 0; ch < C; ++ch, pl += hwl) {
-                const double v = lerp4<double>(pl[c00], pl[c01], pl[c10], pl[c11], wt[0], wt[1], wt[2], wt[3]);
+                const double v = bilerp<double>(pl[c00], pl[c01], pl[c10], pl[c11], tx.l0, tx.l1, ty.l0, ty.l1);
                 acc = __builtin_fma(v, v, acc);
             }
             s = acc;
@@ -1919,7 +1928,6 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__
     if (i >= hw) return;
     const int y = (int)(i / W), x = (int)(i % W);
     const Taps<float> ty = make_taps<float>(y, sh, h), tx = make_taps<float>(x, sw, w);
-    const float w00 = ty.l0 * tx.l0, w01 = ty.l0 * tx.l1, w10 = ty.l1 * tx.l0, w11 = ty.l1 * tx.l1;
     // plane base in SGPRs (advanced by scalar adds) + four 32-bit tap offsets: no 64-bit address arithmetic per load
     // (byte offsets in 32 bits: a low-res class plane is far below 4 GiB)
     const char *pl = reinterpret_cast<const char *>(logit + (size_t)b * bstride);
@@ -1930,7 +1938,7 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__
     float p[1][O_T];
 #pragma unroll
     for (int c = 0; c < O_T; ++c, pl += plane_bytes)
-        p[0][c] = lerp4<float>(at(pl, a00), at(pl, a01), at(pl, a10), at(pl, a11), w00, w01, w10, w11);
+        p[0][c] = bilerp<float>(at(pl, a00), at(pl, a01), at(pl, a10), at(pl, a11), tx.l0, tx.l1, ty.l0, ty.l1);
     const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
     const long long g[1] = {need_gt ? gt[(size_t)b * hw + i] : 0};
     float e[1];
@@ -1955,12 +1963,11 @@ __global__ void __launch_bounds__(TPB) k_logit_interp_lr(const float *__restrict
     if (i >= hw) return;
     const int y = (int)(i / W), x = (int)(i % W);
     const Taps<float> ty = make_taps<float>(y, sh, h), tx = make_taps<float>(x, sw, w);
-    const float w00 = ty.l0 * tx.l0, w01 = ty.l0 * tx.l1, w10 = ty.l1 * tx.l0, w11 = ty.l1 * tx.l1;
     const float *lb = logit + (size_t)b * bstride;
     for (int c = 0; c < O; ++c) {
         const float *pl = lb + (size_t)c * h * w;
-        dst[((size_t)b * O + c) * hw + i] = lerp4<float>(pl[(size_t)ty.i0 * w + tx.i0], pl[(size_t)ty.i0 * w + tx.i1],
-                                                         pl[(size_t)ty.i1 * w + tx.i0], pl[(size_t)ty.i1 * w + tx.i1], w00, w01, w10, w11);
+        dst[((size_t)b * O + c) * hw + i] = bilerp<float>(pl[(size_t)ty.i0 * w + tx.i0], pl[(size_t)ty.i0 * w + tx.i1],
+                                                          pl[(size_t)ty.i1 * w + tx.i0], pl[(size_t)ty.i1 * w + tx.i1], tx.l0, tx.l1, ty.l0, ty.l1);
     }
 }
 

@@ -246,12 +246,17 @@ void halo_o_hypermlr(const double *x, const double *P, const double *A, double *
 /* ------------------------------------------------------------------------- *
  * F.interpolate(mode="bilinear", align_corners=True)  (build.py:123-125,133-135;
  * classifier.py:375-377,556-557).  planes x (h,w) -> planes x (H,W).
- * Source index = dst * (in-1)/(out-1) evaluated in the tensor's own dtype; the four
- * taps are combined as  fma(v11,w11, fma(v10,w10, fma(v00,w00, v01*w01))),  w_ij = ly_i*lx_j.
- * That is bit-for-bit what ATen's generic CPU kernel produces for some shapes/thread
- * counts (e.g. C<=3, one thread) -- ATen itself rounds differently from shape to shape
- * and thread count to thread count (DESIGN.md "What 'exact' can mean"), so 1-ulp
- * agreement is the only well-defined target here.
+ * Source index = dst * (in-1)/(out-1) evaluated in the tensor's own dtype; the four taps are
+ * combined the way ATen writes it (UpSampleKernel.cpp / UpSampleBilinear2d.cu:
+ * h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)), columns first, rows second, every
+ * "p*q + r*s" contracted as fma(p, q, r*s):
+ *     top = fma(lx0, v00, lx1*v01)   bot = fma(lx0, v10, lx1*v11)   out = fma(ly0, top, ly1*bot)
+ * That is bit for bit what torch's CPU kernel returns on an FMA host at the shapes the path runs
+ * (160x320 -> 1024x2048 float64, 640x1280 -> 1024x2048 float32, the fixture shapes; 1 or 8 threads:
+ * tests/test_oracle_golden.py::test_bilinear_is_torchs_cpu_kernel_bit_for_bit).  ATen has other code
+ * paths (tiny outputs with power-of-two scales were seen 1 ulp away), so 1 ulp stays the bar in general.
+ * (Rounds 1-3 used product weights w_ij = ly_i*lx_j and one 4-term fma chain: 1 ulp from ATen nearly
+ * everywhere.)
  * ------------------------------------------------------------------------- */
 void halo_o_bilinear_f64(const double *src, double *dst, i64 planes, i64 h, i64 w, i64 H, i64 W)
 {
@@ -270,10 +275,8 @@ void halo_o_bilinear_f64(const double *src, double *dst, i64 planes, i64 h, i64 
                 i64 x0 = (i64)fx; if (x0 > w - 1) x0 = w - 1;
                 const i64 x1 = x0 + (x0 < w - 1 ? 1 : 0);
                 const double lx1 = fx - (double)x0, lx0 = 1.0 - lx1;
-                double a = r0[x1] * (ly0 * lx1);
-                a = fma(r0[x0], ly0 * lx0, a);
-                a = fma(r1[x0], ly1 * lx0, a);
-                dst[(p * H + y) * W + x] = fma(r1[x1], ly1 * lx1, a);
+                const double top = fma(lx0, r0[x0], lx1 * r0[x1]), bot = fma(lx0, r1[x0], lx1 * r1[x1]);
+                dst[(p * H + y) * W + x] = fma(ly0, top, ly1 * bot);
             }
         }
 }
@@ -294,10 +297,8 @@ void halo_o_bilinear_f32(const float *src, float *dst, i64 planes, i64 h, i64 w,
                 i64 x0 = (i64)fx; if (x0 > w - 1) x0 = w - 1;
                 const i64 x1 = x0 + (x0 < w - 1 ? 1 : 0);
                 const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
-                float a = r0[x1] * (ly0 * lx1);
-                a = fmaf(r0[x0], ly0 * lx0, a);
-                a = fmaf(r1[x0], ly1 * lx0, a);
-                dst[(p * H + y) * W + x] = fmaf(r1[x1], ly1 * lx1, a);
+                const float top = fmaf(lx0, r0[x0], lx1 * r0[x1]), bot = fmaf(lx0, r1[x0], lx1 * r1[x1]);
+                dst[(p * H + y) * W + x] = fmaf(ly0, top, ly1 * bot);
             }
         }
 }
@@ -372,10 +373,8 @@ void halo_o_gram_radius(const double *feat, i64 C, i64 h, i64 w, i64 H, i64 W, i
                 double acc = 0.0;
                 for (i64 ch = 0; ch < C; ++ch) {
                     const double *pl = feat + ch * hwl;
-                    double a = pl[c01] * wt[1];
-                    a = fma(pl[c00], wt[0], a);
-                    a = fma(pl[c10], wt[2], a);
-                    a = fma(pl[c11], wt[3], a);
+                    const double top = fma(lx0, pl[c00], lx1 * pl[c01]), bot = fma(lx0, pl[c10], lx1 * pl[c11]);
+                    const double a = fma(ly0, top, ly1 * bot);
                     acc = fma(a, a, acc);
                 }
                 s = acc;

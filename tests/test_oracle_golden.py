@@ -251,3 +251,29 @@ def test_padding_modes_vs_reference(golden, mode):
     assert max_abs_diff(ho.uncertainty_from_probs(p, "entropy", None, 5, True, padding_mode=mode), d[f"{mode}__region_unc_k5"]) < 2.5e-5    # 25-tap float32 sums up to ~20: a few ulps of 16 (1.9e-6)
     imp, cnt = ho.region_impurity(p.argmax(0), O, 5, padding_mode=mode)
     assert max_abs_diff(imp, d[f"{mode}__imp_k5"]) < 1e-6 and np.array_equal(cnt, d[f"{mode}__cnt_k5"]) and float(cnt.min()) == 25.0
+
+
+@pytest.mark.parametrize("threads", [1, 8])
+@pytest.mark.parametrize("dtype,shape", [("float64", (1, 6, 160, 320, 1024, 2048)), ("float64", (2, 5, 23, 37, 147, 231)),
+                                         ("float64", (1, 64, 40, 80, 256, 512)), ("float32", (1, 19, 640, 1280, 1024, 2048)),
+                                         ("float32", (2, 19, 37, 53, 101, 203)), ("float64", (1, 3, 8, 8, 1, 1)),
+                                         ("float32", (1, 3, 1, 1, 7, 5)), ("float64", (1, 3, 7, 9, 7, 9))])
+def test_bilinear_is_torchs_cpu_kernel_bit_for_bit(dtype, shape, threads):
+    """The contract's bilinear (columns first, rows second, each p*q + r*s as fma(p, q, r*s); round 4) against the call the
+    reference makes, F.interpolate(mode='bilinear', align_corners=True) (build.py:123-135), on this host's CPU: the same bits at
+    the shapes the path runs (low-res head outputs -> label size) and the fixture shapes.  Needs an FMA host (ATen's
+    vectorised kernel contracts; the oracle is built with -mfma when /proc/cpuinfo has it)."""
+    import torch
+    import torch.nn.functional as F
+    if " fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("no FMA on this host: ATen's kernel rounds every product")
+    B, C, h, w, H, W = shape
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        x = torch.randn((B, C, h, w), dtype=getattr(torch, dtype), generator=torch.Generator().manual_seed(3))
+        want = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=True).numpy()
+    finally:
+        torch.set_num_threads(old)
+    got = ho.bilinear(x.numpy(), (H, W))
+    assert got.dtype == want.dtype and np.array_equal(got, want)
