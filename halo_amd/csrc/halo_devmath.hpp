@@ -48,11 +48,19 @@ __device__ __forceinline__ float det_expf_core(float x)
 }
 
 // expf for x in [-87, 0.35] (the lean softmax hands in x - max, in [-64, 0]): det_expf_core with its last step -- the scaling
-// by 2^k in two exact halves, needed where y 2^k leaves the normal range -- as ONE exact scaling (v_ldexp_f32).  Here y is in
-// [0.5, 2) and k in [-126, 0], so y 2^k is a normal float either way: the same bits in 2 instead of 7 instructions.
+// by 2^k in two exact halves, needed where y 2^k leaves the normal range -- as ONE exact scaling.  Here y is in [0.5, 2) and k in
+// [-126, 0], so y 2^k is a normal float either way: the same bits.
+// Device form (round 4, after tools/micro/op_rate.hip: on gfx950 v_fma / v_mul / v_add_f32 and v_add_u32 issue in 2 cycles per
+// wave, every other VALU instruction -- v_rndne, v_cvt, v_ldexp, v_frexp, v_cmp, v_cndmask, v_max -- in 4, v_rcp / v_exp in 8):
+// the rounding to an integer is two additions with 1.5 * 2^23 (t + M rounds t to the nearest integer, ties to even, exactly like
+// rintf for |t| < 2^22; t lies in [-127, 1]) and the scaling adds k to y's exponent field -- k sits in the low mantissa bits of
+// t + M in two's complement, so (bits(t + M) << 23) is k << 23 modulo 2^32 (the constant's own bits shift out): ONE
+// v_lshl_add_u32 where v_rndne + v_cvt_i32 + v_ldexp were three 4-cycle instructions.  Same values at every step.
 __device__ __forceinline__ float det_expf_core_small(float x)
 {
-    float k = __builtin_rintf(x * 1.44269502162933349609375f);
+    const float t = x * 1.44269502162933349609375f;
+    const float tm = t + 12582912.0f;
+    float k = tm - 12582912.0f;                      // == rintf(t)
     float r = __builtin_fmaf(k, -0.693359375f, x);
     r = __builtin_fmaf(k, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
@@ -62,7 +70,7 @@ __device__ __forceinline__ float det_expf_core_small(float x)
     p = __builtin_fmaf(p, r, 1.6666665459e-1f);
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
     float y = __builtin_fmaf(p, r * r, r) + 1.0f;
-    return __builtin_ldexpf(y, (int)k);
+    return __uint_as_float(__float_as_uint(y) + (__float_as_uint(tm) << 23));      // == ldexpf(y, (int)k)
 }
 
 __device__ __forceinline__ float det_expf(float x)
@@ -101,19 +109,19 @@ __device__ __forceinline__ float logf_core_(uint32_t u, int e0)
     return __builtin_fmaf(fe, 0.693359375f, r);
 }
 
-// logf for positive normal finite x.  Exponent and mantissa come from v_frexp_exp_i32_f32 / v_frexp_mant_f32 (for a positive normal
-// float exactly the fields logf_core_ cuts out of the bits: mantissa in [0.5, 1), exponent = biased exponent - 126): two
-// instructions fewer per call, the same operations on the same values afterwards.
+// logf for positive normal finite x: logf_core_ with its normalisation -- mantissa m0 in [0.5, 1) and exponent, then "m0 <
+// sqrt(1/2): double it and lower the exponent" (a compare, two selects, an integer subtract) -- written on the bits: with
+// v = bits(x) - bits(sqrt(1/2)) (0x3f3504f3, the constant of the comparison), k = v >> 23 (arithmetic) is the adjusted exponent
+// and bits(x) - (v & 0xff800000) the adjusted mantissa in [sqrt(1/2), sqrt(2)) -- the mantissa field is below the constant's
+// exactly when m0 < sqrt(1/2), and then the subtraction borrows one from the exponent.  Two 2-cycle integer subtractions and two
+// 4-cycle bit operations where the frexp pair, the compare and the selects were seven 4-cycle instructions; the same m, the same
+// exponent, the same operations afterwards.
 __device__ __forceinline__ float det_logf_core(float x)
 {
-#ifdef HALO_DEVMATH_HOST_CHECK
-    return logf_core_(__float_as_uint(x), 0);
-#else
-    int e = __builtin_amdgcn_frexp_expf(x);
-    float m = __builtin_amdgcn_frexp_mantf(x);
-    const bool low = m < 0.707106769084930419921875f;
-    e -= low ? 1 : 0;
-    m = (low ? m + m : m) - 1.0f;
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t v = u - 0x3f3504f3u;
+    const int e = (int)v >> 23;
+    float m = __uint_as_float(u - (v & 0xff800000u)) - 1.0f;
     float z = m * m;
     float p = 7.0376836292e-2f;
     p = __builtin_fmaf(p, m, -1.1514610310e-1f);
@@ -130,7 +138,6 @@ __device__ __forceinline__ float det_logf_core(float x)
     y = __builtin_fmaf(z, -0.5f, y);
     float r = m + y;
     return __builtin_fmaf(fe, 0.693359375f, r);
-#endif
 }
 
 __device__ __forceinline__ float det_logf(float x)
