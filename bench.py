@@ -46,6 +46,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+LOGIT_LR_VALU_PER_PX = 1030.0      # updated from the PMC pass of tools/collect_profiles.sh
 HBM_PEAK_GBPS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 H, W, O = 1024, 2048, 19
 
@@ -686,16 +687,20 @@ def main():
                                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": nbytes,
                                    "avg_launch_ms": round(t_feat, 4), "launches_timed": len(lr_feat_ms)}
             else:
-                # k_feat_reduce_lr: per output pixel and channel one 4-tap interpolation (1 mul + 3 fma) and one fma into the sum
-                # of squares = 9 flops in 5 VALU slots, in the embedding's dtype; peak = the FP64 / FP32 vector rate (an all-fma
-                # stream; this mix can reach 9/10 of it)
-                flops = 9.0 * B * Hh * Ww * C
+                # k_feat_reduce_lr*: per output pixel and channel ATen's bilinear (3 mul + 3 fma: columns first, rows second) and one
+                # fma into the sum of squares = 11 flops in 7 VALU slots as upsample-then-reduce executes them.  The kernel shares
+                # a source row's column interpolation between the 4 vertically adjacent pixels of a lane: 16 (two source rows) or
+                # 18 (three) slots per channel and 4 pixels, ~4.4 per pixel at this geometry -- `valu_slot_frac` prices the slots
+                # it actually issues against the FP64 (FP32) vector issue rate, `frac` the reference-formula flops against the spec.
+                flops = 11.0 * B * Hh * Ww * C
+                slots = 4.4 * B * Hh * Ww * C
                 peak = 78.6 if fdtype == torch.float64 else 157.3
                 ach = flops / (t_feat * 1e-3) / 1e12
                 out["roofline"] = {"bound": "valu", "kernel": "k_feat_reduce_lr_dmaf" if fdtype == torch.float64 else "k_feat_reduce_lr", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": None, "flops_per_launch": flops,
                                    "avg_launch_ms": round(t_feat, 4), "launches_timed": len(lr_feat_ms),
-                                   "valu_slot_frac": round(ach / peak * 10.0 / 9.0, 4)}
+                                   "valu_slot_frac": round(slots / (t_feat * 1e-3) / 1e12 / (peak / 2.0), 4),
+                                   "flops_convention": "the reference's formula (ATen bilinear + square-accumulate), 11 per pixel and channel; the kernel issues ~4.4 of its 7 instructions"}
             out["lowres_passes_ms"] = {"logit_pass(k_logit_maps_lr, f32 VALU-bound)": round(t_logit, 4), "embedding_pass": round(t_feat, 4)}
             # one roofline entry per kernel of the low-res step; `roofline` above stays the embedding pass
             def entry(kernel, bound, work, t_ms, peak, unit, what):
@@ -704,9 +709,10 @@ def main():
                         "avg_launch_ms": round(t_ms, 4), "work_per_launch": work, "what": what}
             ks = []
             if lr_ms["logit"]:
-                # 1162 VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/r04_pmc_lowres.json: 609 M per
-                # 16 images): interpolation 4 + lean softmax / entropy ~57 per class; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops
-                ks.append(entry("k_logit_maps_lr<%d>" % O, "valu", 1162.0 / 19 * O * B * Hh * Ww, float(np.mean(lr_ms["logit"])), 78.6, "T lane-ops/s",
+                # VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/r04_pmc_lowres.json; 1162 before the
+                # integer forms of the exp / log cores): interpolation 6 + lean softmax / entropy ~48 per class; peak = 256 CUs x 4
+                # SIMDs x 32 lanes x 2.4 GHz (fma / mul / add issue in 2 cycles per wave, everything else in 4: tools/micro/op_rate.hip)
+                ks.append(entry("k_logit_maps_lr<%d>" % O, "valu", LOGIT_LR_VALU_PER_PX / 19 * O * B * Hh * Ww, float(np.mean(lr_ms["logit"])), 78.6, "T lane-ops/s",
                                 "f32 VALU instruction issue (no flops convention: compares, selects and conversions count)"))
             if lr_ms["gram"]:
                 ks.append(entry("k_gram_lr2", "hbm", B * (C * h4 * w4 * 8 + 5 * h4 * w4 * 8), float(np.mean(lr_ms["gram"])), HBM_PEAK_GBPS, "GB/s",

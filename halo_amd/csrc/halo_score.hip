@@ -1528,7 +1528,7 @@ template <int PAT, int OFF, int STRIDE_B> struct LrRowsImm {
     }
 };
 
-template <int PAT, int ROWS, int UU, int CH, int CCF>
+template <int PAT, int ROWS, int UU, int CH, int CCF, bool FULL>
 __device__ __forceinline__ void lr_imm_steps(unsigned base, int cc, LrRowsImm<PAT, (CH % CCF) * ROWS * UU * 16, UU * 16> &cur,
                                              const LrW<double> &wt, double (&acc)[LR_PPT])
 {
@@ -1537,20 +1537,22 @@ __device__ __forceinline__ void lr_imm_steps(unsigned base, int cc, LrRowsImm<PA
         LrRowsImm<PAT, ((CH + 1) % CCF) * ROWS * UU * 16, UU * 16> nxt;
         nxt.issue(base);                                   // channel CH + 1 on its way ...
         cur.template wait<NREAD>();                        // ... channel CH has landed
-        if (CH < cc) cur.accumulate(wt, acc);
-        lr_imm_steps<PAT, ROWS, UU, CH + 1, CCF>(base, cc, nxt, wt, acc);
+        if (FULL || CH < cc) cur.accumulate(wt, acc);
+        lr_imm_steps<PAT, ROWS, UU, CH + 1, CCF, FULL>(base, cc, nxt, wt, acc);
     } else {
         cur.template wait<0>();
-        if (CH < cc) cur.accumulate(wt, acc);
+        if (FULL || CH < cc) cur.accumulate(wt, acc);
     }
 }
 
+// FULL: the chunk holds CCF channels (every chunk but possibly the last): no per-channel test of the channel count
 template <int PAT, int ROWS, int UU, int CCF>
 __device__ __forceinline__ void lr_imm_chunk(unsigned base, int cc, const LrW<double> &wt, double (&acc)[LR_PPT])
 {
     LrRowsImm<PAT, 0, UU * 16> first;
     first.issue(base);
-    lr_imm_steps<PAT, ROWS, UU, 0, CCF>(base, cc, first, wt, acc);
+    if (cc == CCF) lr_imm_steps<PAT, ROWS, UU, 0, CCF, true>(base, cc, first, wt, acc);
+    else lr_imm_steps<PAT, ROWS, UU, 0, CCF, false>(base, cc, first, wt, acc);
 }
 
 template <int MODE, int ROWS, int UU>
