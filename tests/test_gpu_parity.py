@@ -2202,3 +2202,21 @@ def test_randomised_differential_run_vs_oracle(dev):
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "200", "11"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "HIP == oracle bit for bit" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype,shape", [("float64", (1, 12, 160, 320, 1024, 2048)), ("float32", (1, 19, 640, 1280, 1024, 2048)),
+                                         ("float64", (2, 5, 23, 37, 147, 231)), ("float32", (2, 19, 37, 53, 101, 203))])
+def test_device_resize_is_torchs_cpu_interpolate_bit_for_bit(dev, dtype, shape):
+    """The HIP resize against the reference's own call (build.py:123-135), F.interpolate(mode='bilinear', align_corners=True)
+    evaluated by torch on this box's CPU: the same bits, at the head-output -> label-size shapes of the path and at ragged
+    ones.  (Round 4: the contract's bilinear is ATen's order; the CPU oracle carries the same statement,
+    tests/test_oracle_golden.py::test_bilinear_is_torchs_cpu_kernel_bit_for_bit.)"""
+    import torch.nn.functional as F
+    from halo_amd.core.utils.hyperbolic import bilinear_align_corners
+    if " fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("no FMA on this host: ATen's CPU kernel rounds every product")
+    B, C, h, w, H, W = shape
+    x = torch.randn((B, C, h, w), dtype=getattr(torch, dtype), generator=torch.Generator().manual_seed(11))
+    want = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
+    got = bilinear_align_corners(x.to(dev), (H, W)).cpu()
+    assert got.dtype == want.dtype and torch.equal(got, want)
