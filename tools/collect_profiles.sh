@@ -82,6 +82,10 @@ print("  exchange:", d["exchange"], " sharding:", d["config"]["sharding"])
 PY
 rm -f $OUT/pool96_one.npz $OUT/pool96_two.npz
 METHODS=auto RANGED=1 python3 $R/tools/time_select.py > $OUT/select_timing_ranged.txt 2>&1
+# issue-rate probe of the VALU (what DESIGN section 4 quotes for the lean softmax) and the two-stream overlap probe of the low-res passes
+(cd $R/tools/micro && hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -w -o op_rate op_rate.hip) > /dev/null 2>&1
+$R/tools/micro/op_rate 150 > $OUT/op_rate.txt 2>&1
+python3 $R/tools/micro/lr_overlap.py > $OUT/lowres_overlap_probe.txt 2>&1
 cd /tmp
 rm -rf $OUT/trace_sel16
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_sel16 -- python3 $R/tools/prof_select16.py > /dev/null 2>&1
