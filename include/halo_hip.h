@@ -96,7 +96,8 @@ int halo_hypermlr_bwd_terms(const double *x, const double *P, const double *A, c
                             double *dpa, double *dan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* F.interpolate(mode="bilinear", align_corners=True) (core/active/build.py:123-125,133-135;
- * classifier.py:375-377,556-557): planes x (h,w) -> planes x (H,W), dtype F32|F64. */
+ * classifier.py:375-377,556-557): planes x (h,w) -> planes x (H,W), dtype F32|F64.  ATen's order (columns first, rows second,
+ * every p*q + r*s as fma(p, q, r*s)): the bits torch's CPU kernel returns at the path's shapes. */
 int halo_bilinear_upsample(const void *src, void *dst, int dtype, int64_t planes, int64_t h, int64_t w,
                            int64_t H, int64_t W, void *stream);
 
