@@ -46,7 +46,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-LOGIT_LR_VALU_PER_PX = 1030.0      # updated from the PMC pass of tools/collect_profiles.sh
+LOGIT_LR_VALU_PER_PX = 1104.0      # SQ_INSTS_VALU per output pixel at 19 classes, profiles/r04_pmc_lowres.json (1162 before the integer forms, 1411 in round 3)
 HBM_PEAK_GBPS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 H, W, O = 1024, 2048, 19
 
@@ -710,7 +710,7 @@ def main():
             ks = []
             if lr_ms["logit"]:
                 # VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/r04_pmc_lowres.json; 1162 before the
-                # integer forms of the exp / log cores): interpolation 6 + lean softmax / entropy ~48 per class; peak = 256 CUs x 4
+                # integer forms of the exp / log cores): interpolation 6 + lean softmax / entropy ~52 per class; peak = 256 CUs x 4
                 # SIMDs x 32 lanes x 2.4 GHz (fma / mul / add issue in 2 cycles per wave, everything else in 4: tools/micro/op_rate.hip)
                 ks.append(entry("k_logit_maps_lr<%d>" % O, "valu", LOGIT_LR_VALU_PER_PX / 19 * O * B * Hh * Ww, float(np.mean(lr_ms["logit"])), 78.6, "T lane-ops/s",
                                 "f32 VALU instruction issue (no flops convention: compares, selects and conversions count)"))

@@ -78,14 +78,20 @@ def batched(items, nb):
 STAGING = os.environ.get("HALO_RS_STAGING", "table")
 REPEATS = int(os.environ.get("HALO_RS_REPEATS", "5"))
 for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
-    for (infl, wr, nb, tag) in ((0, 1, 1, "serial (in_flight=0, 1 writer)"), (8, 8, 1, "pipelined (in_flight=8, 4 streams, 8 writers)"),
-                                (8, 12, 1, "pipelined (in_flight=8, 4 streams, 12 writers)"), (8, None, 1, "pipelined (defaults)"),
-                                (8, None, 2, "pipelined (defaults), loader batch 2"), (8, None, 4, "pipelined (defaults), loader batch 4")):
+    CONFIGS = ((0, 1, 1, "serial (in_flight=0, 1 writer)"), (8, 8, 1, "pipelined (in_flight=8, 4 streams, 8 writers)"),
+               (8, 12, 1, "pipelined (in_flight=8, 4 streams, 12 writers)"), (None, None, 1, "pipelined (defaults)"),
+               (None, None, 2, "pipelined (defaults), loader batch 2"), (None, None, 4, "pipelined (defaults), loader batch 4"))
+    if os.environ.get("HALO_RS_SWEEP"):            # depth x writers sweep (no backbone only)
+        if MODE != "none":
+            continue
+        CONFIGS = tuple((d, w, 1, "in_flight=%d, %d writers" % (d, w)) for d in (8, 12, 16, 24) for w in (8, 12, 16))
+    for (infl, wr, nb, tag) in CONFIGS:
         if MODE != "none" and (wr == 12 or nb > 1):
             continue
         tmp = tempfile.mkdtemp(prefix="halo_rs_t_")
         items = batched(pool(tmp), nb) if nb > 1 else pool(tmp)
-        RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, in_flight=infl, writer_threads=wr, mask_staging=STAGING)
+        kw = {} if infl is None else {"in_flight": infl}
+        RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, writer_threads=wr, mask_staging=STAGING, **kw)
         torch.cuda.synchronize()
         # without a backbone a round over the pool takes ~0.1 s and its 0.4 GB of files land in the page cache: the number is
         # the MEDIAN of HALO_RS_REPEATS rounds (default 5; the files are overwritten), the range beside it
@@ -93,7 +99,7 @@ for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
         for _ in range(REPEATS if MODE == "none" else 1):
             st = {}
             t0 = time.perf_counter()
-            RegionSelection(cfg, Ident(), Head(busy), items, 1, in_flight=infl, writer_threads=wr, stats=st, mask_staging=STAGING)
+            RegionSelection(cfg, Ident(), Head(busy), items, 1, writer_threads=wr, stats=st, mask_staging=STAGING, **kw)
             runs.append((time.perf_counter() - t0, st))
         runs.sort(key=lambda r: r[0])
         dt, st = runs[len(runs) // 2]
