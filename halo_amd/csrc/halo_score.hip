@@ -1107,7 +1107,7 @@ constexpr int LR_TW = 64, LR_TH = 16, LR_PPT = 4;   // 64 x 16 output pixels per
 
 // bilinear weights of a lane's LR_PPT vertically adjacent output pixels (one column: lx shared, one ly pair per pixel).
 // The four taps are combined by bilerp (halo_devmath.hpp): columns first, rows second -- ATen's order.
-template <typename T> struct LrW { T lx0, lx1, ly0[LR_PPT], ly1[LR_PPT]; };
+template <typename T, int NPX = LR_PPT> struct LrW { T lx0, lx1, ly0[NPX], ly1[NPX]; };
 
 
 // One channel chunk of the window for a lane's LR_PPT vertically adjacent pixels, when their upper tap rows are
@@ -1555,13 +1555,90 @@ __device__ __forceinline__ void lr_imm_chunk(unsigned base, int cc, const LrW<do
     else lr_imm_steps<PAT, ROWS, UU, 0, CCF, false>(base, cc, first, wt, acc);
 }
 
-template <int MODE, int ROWS, int UU>
-__global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__restrict__ feat, long long bstride, int C, int h, int w,
+// ---- the same with NPX (8) vertically adjacent pixels per lane.  CODE holds the row of every pixel's upper tap relative to the
+// lane's first row, 2 bits per pixel (wave-uniform, compile-time, non-decreasing): the lane reads NR = last row + 2 source rows
+// (2 words each) per channel and interpolates every row's columns once -- for 8 pixels over 3-4 rows that is 30-32 float64
+// instructions and 6-8 LDS words per channel where two 4-pixel groups take 34-36 and 10-12; the A/B of round 4 (arithmetic removed
+// / LDS reads removed) found this kernel bound by float64 issue first and the LDS pipe second.  Same expressions per pixel: same bits.
+template <int NPX, unsigned CODE, int OFF, int STRIDE_B> struct LrRowsImmN {
+    static constexpr int row(int j) { return (int)((CODE >> (2 * j)) & 3u); }
+    static constexpr int NR = row(NPX - 1) + 2;
+    double v[NR][2];
+    template <int R> __device__ __forceinline__ void issue_rows(unsigned base)
+    {
+        if constexpr (R < NR) {
+            asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
+                         : "=&v"(v[R][0]), "=&v"(v[R][1]) : "v"(base), "n"(OFF + R * STRIDE_B), "n"(OFF + R * STRIDE_B + 8) : "memory");
+            issue_rows<R + 1>(base);
+        }
+    }
+    __device__ __forceinline__ void issue(unsigned base) { issue_rows<0>(base); }
+    // the values become readable: N = LDS reads issued AFTER this set's (they may stay in flight); the empty statements pin every
+    // use of a value behind the wait
+    template <int N> __device__ __forceinline__ void wait()
+    {
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { asm volatile("" : "+v"(v[r][0])); asm volatile("" : "+v"(v[r][1])); }
+    }
+    __device__ __forceinline__ void accumulate(const LrW<double, NPX> &wt, double (&acc)[NPX]) const
+    {
+        double t[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) t[r] = col_lerp(wt.lx0, wt.lx1, v[r][0], v[r][1]);
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int a = row(j);
+            const double x = col_lerp(wt.ly0[j], wt.ly1[j], t[a], t[a + 1]);
+            acc[j] = fma_t(x, x, acc[j]);
+        }
+    }
+};
+
+template <int NPX, unsigned CODE, int ROWS, int UU, int CH, int CCF, bool FULL>
+__device__ __forceinline__ void lr_immn_steps(unsigned base, int cc, LrRowsImmN<NPX, CODE, (CH % CCF) * ROWS * UU * 16, UU * 16> &cur,
+                                              const LrW<double, NPX> &wt, double (&acc)[NPX])
+{
+    constexpr int NREAD = 2 * LrRowsImmN<NPX, CODE, 0, UU * 16>::NR;
+    if constexpr (CH + 1 < CCF) {
+        LrRowsImmN<NPX, CODE, ((CH + 1) % CCF) * ROWS * UU * 16, UU * 16> nxt;
+        nxt.issue(base);
+        cur.template wait<NREAD>();
+        if (FULL || CH < cc) cur.accumulate(wt, acc);
+        lr_immn_steps<NPX, CODE, ROWS, UU, CH + 1, CCF, FULL>(base, cc, nxt, wt, acc);
+    } else {
+        cur.template wait<0>();
+        if (FULL || CH < cc) cur.accumulate(wt, acc);
+    }
+}
+template <int NPX, unsigned CODE, int ROWS, int UU, int CCF>
+__device__ __forceinline__ void lr_immn_chunk(unsigned base, int cc, const LrW<double, NPX> &wt, double (&acc)[NPX])
+{
+    LrRowsImmN<NPX, CODE, 0, UU * 16> first;
+    first.issue(base);
+    if (cc == CCF) lr_immn_steps<NPX, CODE, ROWS, UU, 0, CCF, true>(base, cc, first, wt, acc);
+    else lr_immn_steps<NPX, CODE, ROWS, UU, 0, CCF, false>(base, cc, first, wt, acc);
+}
+
+// row codes of 8 pixels the kernel is instantiated for: no step, one step before pixel g, two steps at least three pixels apart
+// (source rows are >= 3 output rows tall for the scales the host sends here, <= 1/3).  X(code)
+#ifndef HALO_LR8_WAVES
+#define HALO_LR8_WAVES 3
+#endif
+#define HALO_LR_CODES8(X) \
+    X(0x0000u) \
+    X(0x5554u) X(0x5550u) X(0x5540u) X(0x5500u) X(0x5400u) X(0x5000u) X(0x4000u) \
+    X(0xa954u) X(0xa554u) X(0x9554u) X(0xa550u) X(0x9550u) X(0x9540u) \
+    X(0xaa54u) X(0xa950u) X(0xa540u) X(0x9500u)
+
+template <int MODE, int ROWS, int UU, int PPT = LR_PPT>
+__global__ void __launch_bounds__(TPB, (PPT > LR_PPT ? HALO_LR8_WAVES : 1)) k_feat_reduce_lr_dmaf(const double *__restrict__ feat, long long bstride, int C, int h, int w,
                                                              int H, int W, double sh, double sw, double ks, double rks,
                                                              double *__restrict__ out, double *__restrict__ partials)
 {
     typedef double T;
     constexpr int PER = ROWS * UU, CCF = DMA_UNITS / PER, STRIDE = 2 * UU, PLANE = 2 * PER;
+    constexpr int TH = PPT * (TPB / 64);                        // output rows per block: a wave owns PPT consecutive rows x 64 columns
     extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
     T *img = reinterpret_cast<T *>(lr_smem);
     typedef __attribute__((address_space(3))) unsigned char *lds_bytes;
@@ -1572,7 +1649,7 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
     const unsigned tile_id = (xk < xr ? xk * (xq + 1) : xr * (xq + 1) + (xk - xr) * xq) + lin / 8;
     const int bx = (int)(tile_id % ntx), by = (int)((tile_id / ntx) % nty);
     const int b = (int)(tile_id / (ntx * nty));
-    const int X0 = bx * LR_TW, Y0 = by * LR_TH;
+    const int X0 = bx * LR_TW, Y0 = by * TH;
     const int lx = threadIdx.x & (LR_TW - 1), ly = threadIdx.x / LR_TW;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = X0 + lx;
@@ -1581,16 +1658,16 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
     const int tx_lo = make_taps<T>(X0, sw, w).i0 & ~1, tx_hi = make_taps<T>(xlast, sw, w).i1;
     const bool xin = x < W;
     const Taps<T> tx = make_taps<T>(xin ? x : W - 1, sw, w);
-    T acc[LR_PPT];
-    LrW<T> wt;
+    T acc[PPT];
+    LrW<T, PPT> wt;
     wt.lx0 = tx.l0; wt.lx1 = tx.l1;
-    int o00[LR_PPT], o10[LR_PPT];
-    bool live[LR_PPT];
+    int o00[PPT], o10[PPT];
+    bool live[PPT];
     int a0 = 0, pat = 0;
     bool regular = true;
 #pragma unroll
-    for (int j = 0; j < LR_PPT; ++j) {
-        const int y = Y0 + ly * LR_PPT + j;
+    for (int j = 0; j < PPT; ++j) {
+        const int y = Y0 + ly * PPT + j;
         live[j] = xin && y < H;
         const Taps<T> ty = make_taps<T>(y < H ? y : H - 1, sh, h);
         wt.ly0[j] = ty.l0; wt.ly1[j] = ty.l1;
@@ -1599,8 +1676,13 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
         acc[j] = (T)0;
         if (j == 0) a0 = ty.i0;
         const int d = ty.i0 - a0;
-        regular = regular && (d == 0 || d == 1);
-        if (j > 0) pat |= (d & 1) << (j - 1);
+        if constexpr (PPT == LR_PPT) {
+            regular = regular && (d == 0 || d == 1);
+            if (j > 0) pat |= (d & 1) << (j - 1);
+        } else {                                                    // 2 bits per pixel: LrRowsImmN's row code
+            regular = regular && d >= 0 && d <= 3;
+            pat |= (d & 3) << (2 * j);
+        }
     }
     const int dx1 = tx.i1 - tx.i0;
     const int upat = __builtin_amdgcn_readfirstlane(regular ? pat : -1);
@@ -1665,16 +1747,28 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
             __builtin_amdgcn_s_barrier();
         }
         const unsigned base = lds0 + (unsigned)(n & 1) * (DMA_UNITS * 16) + (unsigned)o00[0] * 8u;
-        if (upat == 0) lr_imm_chunk<0, ROWS, UU, CCF>(base, cc, wt, acc);
-        else if (upat == 4) lr_imm_chunk<4, ROWS, UU, CCF>(base, cc, wt, acc);
-        else if (upat == 6) lr_imm_chunk<6, ROWS, UU, CCF>(base, cc, wt, acc);
-        else if (upat == 7) lr_imm_chunk<7, ROWS, UU, CCF>(base, cc, wt, acc);
-        else {
+        bool done = false;
+        if constexpr (PPT == LR_PPT) {
+            done = true;
+            if (upat == 0) lr_imm_chunk<0, ROWS, UU, CCF>(base, cc, wt, acc);
+            else if (upat == 4) lr_imm_chunk<4, ROWS, UU, CCF>(base, cc, wt, acc);
+            else if (upat == 6) lr_imm_chunk<6, ROWS, UU, CCF>(base, cc, wt, acc);
+            else if (upat == 7) lr_imm_chunk<7, ROWS, UU, CCF>(base, cc, wt, acc);
+            else done = false;
+        } else {
+            switch (upat) {
+#define HALO_LR_CASE(CODE_) case (int)CODE_: lr_immn_chunk<PPT, CODE_, ROWS, UU, CCF>(base, cc, wt, acc); done = true; break;
+                HALO_LR_CODES8(HALO_LR_CASE)
+#undef HALO_LR_CASE
+                default: break;
+            }
+        }
+        if (!done) {
 #pragma unroll 1
             for (int ch = 0; ch < cc; ++ch) {
                 const T *tp = tile + (size_t)ch * PLANE;
 #pragma unroll
-                for (int j = 0; j < LR_PPT; ++j) {
+                for (int j = 0; j < PPT; ++j) {
                     const T v = bilerp<T>(tp[o00[j]], tp[o00[j] + dx1], tp[o10[j]], tp[o10[j] + dx1], wt.lx0, wt.lx1, wt.ly0[j], wt.ly1[j]);
                     acc[j] = fma_t(v, v, acc[j]);
                 }
@@ -1686,9 +1780,9 @@ __global__ void __launch_bounds__(TPB) k_feat_reduce_lr_dmaf(const double *__res
     double mn = 0.0, mx = 0.0;
     bool have = false;
 #pragma unroll
-    for (int j = 0; j < LR_PPT; ++j) {
+    for (int j = 0; j < PPT; ++j) {
         if (!live[j]) continue;
-        const int y = Y0 + ly * LR_PPT + j;
+        const int y = Y0 + ly * PPT + j;
         T r;
         if constexpr (MODE == 0) r = dist0_from_ssq(acc[j], ks, rks);
         else r = __builtin_sqrt(acc[j]);
@@ -2110,6 +2204,24 @@ static int launch_feat_lr(const T *feat, long long bstride, int C, const LrDims 
             // compile-time image geometries (k_feat_reduce_lr_dmaf): rows x pairs that cover the launch's largest window
             const int need_rows = max_rows, need_u = (max_cols + 2) / 2;
             const bool nofixed = getenv("HALO_LR_NOFIXED") != nullptr;                 // A/B switch: runtime strides
+            // 8 pixels per lane (64 x 32 output tiles) where a source row is at least 3 output rows tall: the row codes the kernel
+            // is instantiated for (HALO_LR_CODES8) then cover every wave; HALO_LR_PPT4=1 keeps the 4-pixel kernel (A/B, same bits)
+            if (!nofixed && (double)sh <= 1.0 / 3.0 && H >= 2 * LR_TH && getenv("HALO_LR_PPT4") == nullptr) {
+                int max_rows8;
+                lr_window<T>(H, lr.hf, 2 * LR_TH, max_rows8);
+                ++max_rows8;
+                dim3 grid8((unsigned)cdiv(W, LR_TW), (unsigned)cdiv(H, 2 * LR_TH), (unsigned)B);
+#define HALO_LR_FIXED8(R_, U_)                                                                                                             \
+                if (max_rows8 <= R_ && need_u <= U_) {                                                                                     \
+                    nblk = (int)(grid8.x * grid8.y);                                                                                       \
+                    if (mode == 0) hipLaunchKernelGGL((k_feat_reduce_lr_dmaf<0, R_, U_, 2 * LR_PPT>), grid8, block, lds, st, (const double *)feat, bstride, C, lr.hf, lr.wf, H, W, (double)sh, (double)sw, ks, rks, (double *)out, partials); \
+                    else hipLaunchKernelGGL((k_feat_reduce_lr_dmaf<1, R_, U_, 2 * LR_PPT>), grid8, block, lds, st, (const double *)feat, bstride, C, lr.hf, lr.wf, H, W, (double)sh, (double)sw, ks, rks, (double *)out, partials);           \
+                    return HALO_OK;                                                                                                        \
+                }
+                HALO_LR_FIXED8(8, 8)       // x6.4 (160x320 -> 1024x2048): 16 channels per image
+                HALO_LR_FIXED8(11, 10)     // x4: 9 channels per image
+#undef HALO_LR_FIXED8
+            }
 #define HALO_LR_FIXED(R_, U_)                                                                                                              \
             if (!nofixed && need_rows <= R_ && need_u <= U_) {                                                                             \
                 if (mode == 0) hipLaunchKernelGGL((k_feat_reduce_lr_dmaf<0, R_, U_>), grid, block, lds, st, (const double *)feat, bstride, C, lr.hf, lr.wf, H, W, (double)sh, (double)sw, ks, rks, (double *)out, partials); \

@@ -2220,3 +2220,26 @@ def test_device_resize_is_torchs_cpu_interpolate_bit_for_bit(dev, dtype, shape):
     want = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
     got = bilinear_align_corners(x.to(dev), (H, W)).cpu()
     assert got.dtype == want.dtype and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("C,hf,wf,H,W", [(40, 160, 320, 1024, 2048), (17, 64, 128, 256, 512), (9, 22, 44, 64, 128), (12, 40, 64, 150, 250),
+                                          (8, 16, 32, 100, 136), (5, 30, 50, 95, 190), (33, 12, 24, 80, 192)])
+def test_lowres_exact_mode_staging_variants_agree_bitwise(dev, C, hf, wf, H, W):
+    """The exact low-res embedding pass has four statements of one arithmetic: LDS-DMA with a compile-time window geometry and 8
+    pixels per lane (default where a source row is at least 3 output rows tall; row codes of HALO_LR_CODES8, anything else takes
+    the in-kernel generic loop), the same with 4 pixels per lane (HALO_LR_PPT4=1), runtime strides (HALO_LR_NOFIXED=1) and
+    register staging (HALO_LR_NODMA=1).  Same bits from all of them -- at x6.4 and x4, at a scale of exactly 1/3 (three-row runs,
+    three steps inside a lane's 8 pixels), at heights that are no multiple of 32 and widths that are no multiple of 64 -- and
+    the same bits as upsample-then-score."""
+    from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
+    from halo_amd.core.utils.hyperbolic import bilinear_align_corners
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(C * 13 + hf)
+    emb_lr = ho.expmap((rng.standard_normal((2, C, hf, wf)) * 0.2).astype(np.float32), 1.0, dim=1)
+    lg, em = t(rng.standard_normal((2, 19, hf, wf)).astype(np.float32), dev), t(emb_lr, dev)
+    want = score_maps(bilinear_align_corners(lg, (H, W)), bilinear_align_corners(em, (H, W)), "entropy", "radius", True, None, size=3)
+    for env in ({}, {"HALO_LR_PPT4": "1"}, {"HALO_LR_NOFIXED": "1"}, {"HALO_LR_NODMA": "1"}):
+        got = _with_env(env, lambda: score_maps_lowres(lg, em, (H, W), "entropy", "radius", True, None, ksize=3, mode="exact"))
+        torch.cuda.synchronize()
+        for x, y in zip(got, want):
+            assert bits_equal(x.cpu().numpy(), y.cpu().numpy()), env

@@ -1,4 +1,5 @@
-"""A/B of the exact low-res embedding pass: LDS-DMA double buffer with compile-time image geometry (k_feat_reduce_lr_dmaf, default),
+"""A/B of the exact low-res embedding pass: LDS-DMA double buffer with compile-time image geometry (k_feat_reduce_lr_dmaf: 8 pixels
+per lane where a source row is at least 3 output rows tall, default; 4 pixels per lane with HALO_LR_PPT4=1),
 the same with runtime strides (HALO_LR_NOFIXED=1), register staging
 (HALO_LR_NODMA=1): bit equality of the maps and ms per 16 images (HIP events around the embedding pass), several geometries."""
 import ctypes, os, sys
@@ -18,8 +19,8 @@ for (B, C, hl, wl, hf, wf, tag) in ((16, 256, 256, 512, 256, 512, "bench ring x4
     lg = torch.randn((B, O, hl, wl), generator=g, device=dev)
     em = HyperMapper(1.0).expmap(torch.randn((B, C, hf, wf), generator=g, device=dev) * 0.1, dim=1)
     res = {}
-    for name, env in (("dma", None), ("dma_rt", "HALO_LR_NOFIXED"), ("regs", "HALO_LR_NODMA")):
-        os.environ.pop("HALO_LR_NODMA", None); os.environ.pop("HALO_LR_NOFIXED", None)
+    for name, env in (("dma", None), ("dma4", "HALO_LR_PPT4"), ("dma_rt", "HALO_LR_NOFIXED"), ("regs", "HALO_LR_NODMA")):
+        os.environ.pop("HALO_LR_NODMA", None); os.environ.pop("HALO_LR_NOFIXED", None); os.environ.pop("HALO_LR_PPT4", None)
         if env:
             os.environ[env] = "1"
         ms = []
@@ -34,11 +35,14 @@ for (B, C, hl, wl, hf, wf, tag) in ((16, 256, 256, 512, 256, 512, "bench ring x4
             for e in ev:
                 L.halo_event_destroy(e)
         res[name] = (min(ms), out)
-    os.environ.pop("HALO_LR_NODMA", None); os.environ.pop("HALO_LR_NOFIXED", None)
+    os.environ.pop("HALO_LR_NODMA", None); os.environ.pop("HALO_LR_NOFIXED", None); os.environ.pop("HALO_LR_PPT4", None)
     same_rt = all(torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a.view(torch.int32),
                               b.view(torch.int64) if b.dtype == torch.float64 else b.view(torch.int32)) for a, b in zip(res["dma_rt"][1], res["regs"][1]))
     same = same_rt and all(torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a.view(torch.int32),
                            b.view(torch.int64) if b.dtype == torch.float64 else b.view(torch.int32)) for a, b in zip(res["dma"][1], res["regs"][1]))
-    flops = 9.0 * B * H * W * C
-    print(f"{tag}: dma {res['dma'][0]:.3f} ms ({flops / res['dma'][0] / 1e9:.1f} TFLOP/s = {flops / res['dma'][0] / 1e9 / 78.6:.2f} of FP64 vector peak), "
-          f"runtime-stride DMA {res['dma_rt'][0]:.3f} ms, register staging {res['regs'][0]:.3f} ms, bit-identical {same}", flush=True)
+    same = same and all(torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a.view(torch.int32),
+                        b.view(torch.int64) if b.dtype == torch.float64 else b.view(torch.int32)) for a, b in zip(res["dma4"][1], res["regs"][1]))
+    flops = 11.0 * B * H * W * C            # the reference formula's flops (ATen bilinear + square-accumulate)
+    print(f"{tag}: dma {res['dma'][0]:.3f} ms ({flops / res['dma'][0] / 1e9:.1f} TFLOP/s by the reference formula's 11 flops per pixel and channel), "
+          f"4 pixels per lane {res['dma4'][0]:.3f} ms, runtime-stride DMA {res['dma_rt'][0]:.3f} ms, register staging {res['regs'][0]:.3f} ms, "
+          f"bit-identical {same}", flush=True)
