@@ -1549,10 +1549,20 @@ __device__ __forceinline__ void lr_imm_steps(unsigned base, int cc, LrRowsImm<PA
 template <int PAT, int ROWS, int UU, int CCF>
 __device__ __forceinline__ void lr_imm_chunk(unsigned base, int cc, const LrW<double> &wt, double (&acc)[LR_PPT])
 {
-    LrRowsImm<PAT, 0, UU * 16> first;
-    first.issue(base);
-    if (cc == CCF) lr_imm_steps<PAT, ROWS, UU, 0, CCF, true>(base, cc, first, wt, acc);
-    else lr_imm_steps<PAT, ROWS, UU, 0, CCF, false>(base, cc, first, wt, acc);
+    // The first channel's reads are issued INSIDE each branch: between a set's issue and its wait there must be no control-flow
+    // merge.  The compiler takes an asm output for a value that exists when the statement ends; issued before the branch, the two
+    // arms wanted the set in different registers and the copies (v_mov_b64 of registers whose LDS data was still in flight) were
+    // placed in front of the wait: channel 0 of every partial chunk read stale registers, now and then
+    // (test_lowres_exact_mode_staging_variants_agree_bitwise found it one day after the branch went in).
+    if (cc == CCF) {
+        LrRowsImm<PAT, 0, UU * 16> first;
+        first.issue(base);
+        lr_imm_steps<PAT, ROWS, UU, 0, CCF, true>(base, cc, first, wt, acc);
+    } else {
+        LrRowsImm<PAT, 0, UU * 16> first;
+        first.issue(base);
+        lr_imm_steps<PAT, ROWS, UU, 0, CCF, false>(base, cc, first, wt, acc);
+    }
 }
 
 // ---- the same with NPX (8) vertically adjacent pixels per lane.  CODE holds the row of every pixel's upper tap relative to the
@@ -1614,10 +1624,15 @@ __device__ __forceinline__ void lr_immn_steps(unsigned base, int cc, LrRowsImmN<
 template <int NPX, unsigned CODE, int ROWS, int UU, int CCF>
 __device__ __forceinline__ void lr_immn_chunk(unsigned base, int cc, const LrW<double, NPX> &wt, double (&acc)[NPX])
 {
-    LrRowsImmN<NPX, CODE, 0, UU * 16> first;
-    first.issue(base);
-    if (cc == CCF) lr_immn_steps<NPX, CODE, ROWS, UU, 0, CCF, true>(base, cc, first, wt, acc);
-    else lr_immn_steps<NPX, CODE, ROWS, UU, 0, CCF, false>(base, cc, first, wt, acc);
+    if (cc == CCF) {                          // (issue inside each arm: see lr_imm_chunk)
+        LrRowsImmN<NPX, CODE, 0, UU * 16> first;
+        first.issue(base);
+        lr_immn_steps<NPX, CODE, ROWS, UU, 0, CCF, true>(base, cc, first, wt, acc);
+    } else {
+        LrRowsImmN<NPX, CODE, 0, UU * 16> first;
+        first.issue(base);
+        lr_immn_steps<NPX, CODE, ROWS, UU, 0, CCF, false>(base, cc, first, wt, acc);
+    }
 }
 
 // row codes of 8 pixels the kernel is instantiated for: no step, one step before pixel g, two steps at least three pixels apart
