@@ -310,3 +310,26 @@ def test_writer_threads_follow_the_ranks_share_of_the_host(monkeypatch):
     assert _host.host_threads_per_rank(cap=8) == 8 and _host.host_threads_per_rank() == 16
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "64")
     assert _host.host_threads_per_rank(cap=8) == 1
+
+
+def test_native_png_encoder_around_the_match_length_limits(tmp_path):
+    """The run-length encoder splits a run into deflate matches of at most 258 bytes and must leave no 1- or 2-byte tail a match
+    cannot take: rows built from runs of 1-5, 257-262, 516-520 bytes and whole rows, at widths on both sides of 258 / 516 / 774
+    / 1032, the filter byte joining a leading run of zeros -- decoded by PIL, pixel for pixel."""
+    from PIL import Image
+    from halo_amd import _hostlib
+    rng = np.random.default_rng(0)
+    p = str(tmp_path / "a.png")
+    for trial in range(150):
+        H = int(rng.integers(1, 7))
+        W = int(rng.choice([1, 2, 3, 7, 255, 256, 257, 258, 259, 260, 261, 262, 515, 516, 517, 518, 519, 520, 521, 774, 775, 776, 777, 1031, 1033, 2048]))
+        a = np.empty((H, W), np.uint8)
+        for y in range(H):
+            x = 0
+            while x < W:
+                L = int(rng.choice([1, 2, 3, 4, 5, 257, 258, 259, 260, 261, 262, 516, 517, 518, 519, 520, W]))
+                a[y, x:x + L] = int(rng.choice([0, 0, 255, 255, int(rng.integers(0, 256))]))
+                x += L
+        _hostlib.png_gray8_write(p, a)
+        b = np.array(Image.open(p))
+        assert b.shape == a.shape and np.array_equal(a, b), (trial, H, W)
