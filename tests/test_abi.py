@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 import torch
 
