@@ -2243,3 +2243,30 @@ def test_lowres_exact_mode_staging_variants_agree_bitwise(dev, C, hf, wf, H, W):
         torch.cuda.synchronize()
         for x, y in zip(got, want):
             assert bits_equal(x.cpu().numpy(), y.cpu().numpy()), env
+
+
+def test_the_visualize_wrong_call_pattern(dev, monkeypatch):
+    """The path's second caller (core/utils/visualize.py:20-34): `FloatingRegionScore(in_channels, size).cuda()` -- the
+    purity window taken from the global cfg -- and three forwards on the head's outputs: ('entropy', 'ripu'), ('hyperbolic',
+    'ripu'), ('certainty', 'ripu'), normalised, with a decoder_out the ripu purity never reads.  Under a ripu configuration
+    (configs/gtav/ripu.yaml) the two vestigial uncertainty names are zero maps (floating_region.py:83-92), so their normalised
+    uncertainty is 0/0 = NaN everywhere: same maps as the oracle, bit for bit.  Under the default cfg (PURITY 'hyper': a 100-bin
+    purity window) the reference's depthwise conv rejects the 19-class one-hot; the mirror raises too."""
+    from halo_amd.core.active import floating_region as fr
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(5)
+    H, W, O, C = 40, 72, 19, 8
+    logit = rng.standard_normal((1, O, H, W)).astype(np.float32) * 3
+    emb = ho.expmap((rng.standard_normal((1, C, H, W)) * 0.2).astype(np.float32), 1.0, dim=1)
+    monkeypatch.setattr(fr.cfg.ACTIVE, "PURITY", "hyper", raising=False)
+    with pytest.raises(RuntimeError):
+        fr.FloatingRegionScore(in_channels=O, size=3).cuda()(t(logit, dev), decoder_out=t(emb, dev), unc_type="entropy", pur_type="ripu", normalize=True)
+    monkeypatch.setattr(fr.cfg.ACTIVE, "PURITY", "ripu", raising=False)
+    frs = fr.FloatingRegionScore(in_channels=O, size=3).cuda()
+    for unc in ("entropy", "hyperbolic", "certainty"):
+        s, i, u = frs(t(logit, dev), decoder_out=t(emb, dev), unc_type=unc, pur_type="ripu", normalize=True)
+        so, io, uo = ho.floating_region_score(logit, emb, unc, "ripu", True, None, size=3)
+        assert s.shape == (H, W) and s.dtype == torch.float32
+        assert bits_equal(s.cpu().numpy(), so) and bits_equal(i.cpu().numpy(), io) and bits_equal(u.cpu().numpy(), uo), unc
+        if unc != "entropy":
+            assert np.isnan(u.cpu().numpy()).all()
