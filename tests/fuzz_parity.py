@@ -63,6 +63,20 @@ def one_case(i):
         hl, wl = int(rng.integers(1, H + 1)), int(rng.integers(1, W + 1))
         hf, wf = int(rng.integers(1, H + 1)), int(rng.integers(1, W + 1))
         mode = "exact" if (f32 or rng.random() < 0.5) else "gram"
+        if rng.random() < 0.35:
+            # head-like geometry: the embedding upsampled x3 ... x8 from an even-width grid, enough channels for several LDS
+            # chunks with a partial last one -- the LDS-DMA kernels with compile-time window geometry (4 and 8 pixels per lane)
+            f = float(rng.choice([3.0, 4.0, 5.0, 6.4, 8.0]))
+            if H < 40:
+                H = int(rng.integers(40, 200))
+            if W < 70:
+                W = int(rng.integers(70, 400))
+            hf, wf = max(2, int(round(H / f))), max(2, int(round(W / f)) // 2 * 2)
+            C = int(rng.integers(5, 71))
+            gt = rng.integers(0, O, (B, H, W)).astype(np.int64)
+            act = rng.random((B, H, W)) < 0.03
+            hl, wl = min(hl, H), min(wl, W)
+            desc.update(H=H, W=W, C=C)
         desc.update(hl=hl, wl=wl, hf=hf, wf=wf, mode=mode)
         logit_lr = (rng.standard_normal((B, O, hl, wl)) * 2).astype(np.float32)
         emb_lr = ho.expmap((rng.standard_normal((B, C, hf, wf)) * scale).astype(np.float32), c, dim=1)
