@@ -2222,13 +2222,14 @@ def test_device_resize_is_torchs_cpu_interpolate_bit_for_bit(dev, dtype, shape):
     assert got.dtype == want.dtype and torch.equal(got, want)
 
 
-@pytest.mark.parametrize("C,hf,wf,H,W", [(40, 160, 320, 1024, 2048), (17, 64, 128, 256, 512), (9, 22, 44, 64, 128), (12, 40, 64, 150, 250),
+@pytest.mark.parametrize("C,hf,wf,H,W", [(40, 160, 320, 1024, 2048), (22, 256, 512, 1024, 2048), (17, 64, 128, 256, 512), (9, 22, 44, 64, 128), (12, 40, 64, 150, 250),
                                           (8, 16, 32, 100, 136), (5, 30, 50, 95, 190), (33, 12, 24, 80, 192)])
 def test_lowres_exact_mode_staging_variants_agree_bitwise(dev, C, hf, wf, H, W):
     """The exact low-res embedding pass has four statements of one arithmetic: LDS-DMA with a compile-time window geometry and 8
     pixels per lane (default where a source row is at least 3 output rows tall; row codes of HALO_LR_CODES8, anything else takes
     the in-kernel generic loop), the same with 4 pixels per lane (HALO_LR_PPT4=1), runtime strides (HALO_LR_NOFIXED=1) and
-    register staging (HALO_LR_NODMA=1).  Same bits from all of them -- at x6.4 and x4, at a scale of exactly 1/3 (three-row runs,
+    register staging (HALO_LR_NODMA=1).  Same bits from all of them -- at x6.4 and x4 at FULL size with a partial last chunk (the
+    race of round 4 -- NOTES.md -- only fired with a full chip of waves in flight), at a scale of exactly 1/3 (three-row runs,
     three steps inside a lane's 8 pixels), at heights that are no multiple of 32 and widths that are no multiple of 64 -- and
     the same bits as upsample-then-score."""
     from halo_amd.core.active.floating_region import score_maps, score_maps_lowres
