@@ -845,7 +845,9 @@ extern "C" int halo_expmap0_project(const void *x, int x_dtype, double *y, int64
     if (x_dtype == HALO_F32 && inner >= 4 && inner % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
         !getenv("HALO_EXPMAP_PLANES")) {                       // A/B switch: the two-pass kernel
         pshift = 8;                                             // P = 256
-        while (pshift > 5 && ((size_t)C << pshift) * 4 > 32 * 1024) --pshift;
+        const char *ekb = getenv("HALO_EXPMAP_TILE_KB");                    // A/B switch: LDS bytes of a tile (default 32 KiB)
+        const size_t tile_cap = (size_t)(ekb ? atoi(ekb) : 32) * 1024;
+        while (pshift > 5 && ((size_t)C << pshift) * 4 > tile_cap) --pshift;
         while (pshift > 2 && (1ll << (pshift - 1)) >= inner) --pshift;      // tiny planes: no wider than needed
         lds = ((size_t)C << pshift) * 4 + 3 * ((size_t)8 << pshift);
         if (lds > 96 * 1024) pshift = 0;
