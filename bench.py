@@ -689,18 +689,18 @@ def main():
             else:
                 # k_feat_reduce_lr*: per output pixel and channel ATen's bilinear (3 mul + 3 fma: columns first, rows second) and one
                 # fma into the sum of squares = 11 flops in 7 VALU slots as upsample-then-reduce executes them.  The kernel shares
-                # a source row's column interpolation between the 4 vertically adjacent pixels of a lane: 16 (two source rows) or
-                # 18 (three) slots per channel and 4 pixels, ~4.4 per pixel at this geometry -- `valu_slot_frac` prices the slots
+                # a source row's column interpolation between the 8 (4) vertically adjacent pixels of a lane: 30-32 slots per channel
+                # and 8 pixels, ~3.9 per pixel at this geometry -- `valu_slot_frac` prices the slots
                 # it actually issues against the FP64 (FP32) vector issue rate, `frac` the reference-formula flops against the spec.
                 flops = 11.0 * B * Hh * Ww * C
-                slots = 4.4 * B * Hh * Ww * C
+                slots = 3.9 * B * Hh * Ww * C          # 8 pixels per lane at this x4 geometry (SQ_INSTS_VALU, profiles/r04_pmc_lowres.json); 4.4 with 4
                 peak = 78.6 if fdtype == torch.float64 else 157.3
                 ach = flops / (t_feat * 1e-3) / 1e12
                 out["roofline"] = {"bound": "valu", "kernel": "k_feat_reduce_lr_dmaf" if fdtype == torch.float64 else "k_feat_reduce_lr", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": None, "flops_per_launch": flops,
                                    "avg_launch_ms": round(t_feat, 4), "launches_timed": len(lr_feat_ms),
                                    "valu_slot_frac": round(slots / (t_feat * 1e-3) / 1e12 / (peak / 2.0), 4),
-                                   "flops_convention": "the reference's formula (ATen bilinear + square-accumulate), 11 per pixel and channel; the kernel issues ~4.4 of its 7 instructions"}
+                                   "flops_convention": "the reference's formula (ATen bilinear + square-accumulate), 11 per pixel and channel; the kernel issues ~3.9 of its 7 instructions"}
             out["lowres_passes_ms"] = {"logit_pass(k_logit_maps_lr, f32 VALU-bound)": round(t_logit, 4), "embedding_pass": round(t_feat, 4)}
             # one roofline entry per kernel of the low-res step; `roofline` above stays the embedding pass
             def entry(kernel, bound, work, t_ms, peak, unit, what):
