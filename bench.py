@@ -45,6 +45,7 @@ if "GPU_MAX_HW_QUEUES" not in os.environ:
 import numpy as np
 import torch
 import torch.distributed as dist
+from halo_amd import _lib as _halo_lib  # noqa: E402  (constants only; the library loads on first use)
 
 LOGIT_LR_VALU_PER_PX = 1104.0      # SQ_INSTS_VALU per output pixel at 19 classes, profiles/r04_pmc_lowres.json (1162 before the integer forms, 1411 in round 3)
 HBM_PEAK_GBPS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
@@ -98,12 +99,21 @@ def parse():
                          "within a few seconds of the end of another large GPU process measures ~3 %% low -- the driver is still "
                          "busy with the memory that process gave back (profiles/r03_process_alternation.txt); 0 = do not wait")
     ap.add_argument("--sel-priority", type=int, default=-1, help="stream priority of the selection streams (-1 = high)")
+    ap.add_argument("--data", default="gaussian",
+                    help="synthetic value distribution, '+'-joined modifiers of the SURVEY 8(d) default ('gaussian'): late_round = half of the "
+                         "pixels already active (-inf) in 11x11 blocks, as after several acquisition rounds; saturated = latents x 40 over "
+                         "the right half of the image (embeddings projected onto the ball's boundary: one exact radius there); peaked = "
+                         "logits x 30 (saturated softmax: exactly equal entropies over large regions).  The selector's hand-over counters "
+                         "(`selection`) say what each does to the value-binned sweep")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
 
 
-def make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres=False):
+DATA_MODS = ("gaussian", "late_round", "saturated", "peaked")
+
+
+def make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres=False, data=("gaussian",)):
     """Synthetic pool per SURVEY.md 8(d): low-res latent z ~ N(0, 0.1^2), seed 1234 + image id (`seeds[r]` for ring slot r);
     embed = expmap0_project(z); logit = HyperMLR(embed), P/A ~ kaiming_uniform(a=sqrt 5) seed 7;
     both upsampled x4 (align_corners) -- all by this package's own kernels, untimed."""
@@ -120,8 +130,12 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres=False):
         for r in range(R):
             g = torch.Generator(device=dev).manual_seed(1234 + int(seeds[r]))
             z = torch.randn((1, C, h, w), generator=g, device=dev, dtype=torch.float32) * 0.1
+            if "saturated" in data:
+                z[..., w // 2:] *= 40.0          # tanh saturates: project() puts these vectors ON the ball's boundary
             emb = mapper.expmap(z, dim=1)
             lg = mlr._hyper_logits(emb, out_dtype=torch.float32)
+            if "peaked" in data:
+                lg *= 30.0                       # softmax saturates: p = 1 / 0 exactly over large regions
             if lowres:
                 logit[r:r + 1] = lg
                 feat[r:r + 1] = emb if fdtype == torch.float64 else emb.float()
@@ -133,8 +147,15 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres=False):
             lab = torch.randint(0, O, (Hh, Ww), generator=g, device=dev, dtype=torch.int64)
             lab[torch.rand((Hh, Ww), generator=g, device=dev) < 0.05] = 255
             gt[r] = lab
+        prior = None
+        if "late_round" in data:                 # what earlier rounds left behind: `active` windows (build.py:56-57) over half the image
+            prior = torch.empty((R, Hh, Ww), dtype=torch.bool, device=dev)
+            for r in range(R):
+                g = torch.Generator(device=dev).manual_seed(99991 + int(seeds[r]))
+                blocks = torch.rand(((Hh + 10) // 11, (Ww + 10) // 11), generator=g, device=dev) < 0.5
+                prior[r] = blocks.repeat_interleave(11, 0).repeat_interleave(11, 1)[:Hh, :Ww]
     torch.cuda.synchronize(dev)
-    return feat, logit, gt
+    return feat, logit, gt, prior
 
 
 BRANCHES = {   # name -> (unc_type, pur_type, normalize, mask radius, K)
@@ -149,7 +170,7 @@ class Pipeline:
     collect in one wire block that is exchanged ONCE, behind the last step."""
 
     def __init__(self, dev, feat, logit, gt, B, n_regions, rows, depth, lowres=False, branch="halo",
-                 resets="undo", sel_priority=-1, lr_mode="exact", tail="auto"):
+                 resets="undo", sel_priority=-1, lr_mode="exact", tail="auto", prior=None):
         from halo_amd import _lib
         self.lib = _lib.lib()
         self.dev, self.feat, self.logit, self.gt, self.B, self.n = dev, feat, logit, gt, B, n_regions
@@ -175,7 +196,8 @@ class Pipeline:
         from halo_amd.core.active.floating_region import new_score_range
         # normalised maps: the scorer bounds their value range for free and the selector skips its range pass
         self.rng = [new_score_range(B, dev) if self.norm else None for _ in range(D)]
-        self.resets = resets
+        self.prior = prior                 # (R,H,W) bool or None: the `active` map each image enters the round with
+        self.resets = "prior" if prior is not None else resets
         self.s_house = torch.cuda.Stream(dev)
         self.reset_done = [torch.cuda.Event() for _ in range(D)]
         self.scored = [torch.cuda.Event() for _ in range(D)]
@@ -198,6 +220,9 @@ class Pipeline:
         # (halo_amd/pool.py, padded to ceil(N / world) rows) ONCE, right before the round's one collective
         self.round_tables = torch.zeros((rows, n_regions, 3), dtype=torch.float64, device=dev)
         self.round_counts = torch.zeros((rows,), dtype=torch.int32, device=dev)
+        # what the value-binned sweep did with each image: {reason, picks before the hand-over} (halo_greedy_select_ex)
+        self.handover = [torch.zeros((B, 2), dtype=torch.int32, device=dev) for _ in range(D)]
+        self.round_handover = torch.zeros((rows, 2), dtype=torch.int32, device=dev)
         self.wire = torch.zeros((rows, 3 * n_regions + 1), dtype=torch.int32, device=dev)
         self.rows_done = 0
         self.slot_out = [None] * D
@@ -240,7 +265,12 @@ class Pipeline:
             # round-1 state for this batch (the loader's job in the reference, cityscapes.py:245-251).
             # Kept on the scoring stream by default: moving the fills to the slot's select stream measured
             # 5-8 % SLOWER end to end (they then run at high priority beside the feature stream).
-            if self.resets in ("kernel", "fills"):
+            if self.resets == "prior":                               # three torch ops per step: harness work on the scoring stream
+                self.s_score.wait_event(self.selected_done[k])
+                self.active[k][:b].copy_(self.prior[lo:lo + b])
+                self.selected[k].zero_()
+                self.amask[k].fill_(255)
+            elif self.resets in ("kernel", "fills"):
                 self.s_score.wait_event(self.selected_done[k])      # buffers k free again
                 self._restore_state(k)
             elif self.resets == "undo" or self.step_no < self.D:
@@ -271,7 +301,8 @@ class Pipeline:
             self.s_sel[k].wait_event(self.scored[k])
             dst = (self.tables[k][:b], self.counts[k][:b]) if row is None else (self.round_tables[row:row + b], self.round_counts[row:row + b])
             picks, npk = greedy_select(self.score[k][:b], self.n, 1, self.mrad, self.active[k][:b], self.selected[k][:b],
-                                       self.amask[k][:b], gb, out=dst, score_range=None if self.rng[k] is None else self.rng[k][:b])
+                                       self.amask[k][:b], gb, out=dst, score_range=None if self.rng[k] is None else self.rng[k][:b],
+                                       handover=self.handover[k][:b] if row is None else self.round_handover[row:row + b])
             self.slot_out[k] = dst
             if row is not None:
                 self.rows_done = max(self.rows_done, row + b)
@@ -399,10 +430,21 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(feat, logit, gt, n_images, n_regions, branch):
-    """The CPU oracle (kind 'port': C restatement, OpenMP over all host cores) on the first ring images:
-    one untimed warm-up image, then `n_images` timed ones: score + mask + select, median
-    s/image -> images/s.  Also returns image 0's picks so the caller can compare them with the GPU's."""
+def parity_slots(R, B, n_rows, want):
+    """Ring slots the oracle scores: spread over EVERY resident batch (offsets 0, B/3, 2B/3, B-1 of each), so that images
+    whose feature tensor starts past 2^32 elements of the batch's allocation are covered, not only image 0 (VERDICT r4 #1)."""
+    offs = sorted({0, B // 3, (2 * B) // 3, B - 1})
+    slots = [lo + o for lo in range(0, R, B) for o in offs if lo + o < min(R, n_rows)]
+    if len(slots) > want:                      # keep the spread: every (len/want)-th slot, first and last included
+        idx = sorted({round(i * (len(slots) - 1) / max(1, want - 1)) for i in range(want)})
+        slots = [slots[i] for i in idx]
+    return slots
+
+
+def cpu_baseline(feat, logit, gt, prior, slots, n_regions, branch):
+    """The CPU oracle (kind 'port': C restatement, OpenMP over all host cores) on ring images `slots` (after one untimed
+    warm-up pass over the first of them; SURVEY 8d): score + mask + select, median s/image -> images/s.  Returns every
+    image's pick table so the caller can compare them with the rows the TIMED pipeline wrote for the same images."""
     import ctypes
     from oracle import halo_oracle as ho
     ho.lib()
@@ -412,22 +454,21 @@ def cpu_baseline(feat, logit, gt, n_images, n_regions, branch):
         ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)        # the oracle's OpenMP team = the usable cores
     except OSError:
         cores = os.cpu_count() or 1
-    times, picks = [], []
-    R = feat.shape[0]
-    for j in range(n_images + 1):
-        i = j % R
+    times, picks = [], {}
+    for j, i in enumerate([slots[0]] + list(slots)):
         lg = logit[i].cpu().numpy()
         ft = feat[i].cpu().numpy()
         g = gt[i].cpu().numpy()
         Hh, Ww = g.shape
+        act0 = prior[i].cpu().numpy() if prior is not None else np.zeros((Hh, Ww), bool)
         t0 = time.perf_counter()
         s, _, _ = ho.floating_region_score(lg, ft, unc, pur, norm, g, size=3, purity_type=pur, K=K)
-        act = np.zeros((Hh, Ww), bool); sel = np.zeros((Hh, Ww), bool); am = np.full((Hh, Ww), 255, np.int64)
+        act = act0.copy(); sel = np.zeros((Hh, Ww), bool); am = np.full((Hh, Ww), 255, np.int64)
         s[act] = -np.inf
         _, _, _, _, pk = ho.select_pixels_to_label(s, n_regions, 1, mrad, act, sel, am, g, True)
         if j > 0:
             times.append(time.perf_counter() - t0)
-        picks.append(pk)
+        picks[i] = pk
     return float(np.median(times)), cores, picks
 
 
@@ -517,6 +558,10 @@ def main():
     lowres = a.source == "lowres"
     if lowres:
         a.cpu_images = 0
+    data = tuple(a.data.split("+"))
+    for m_ in data:
+        if m_ not in DATA_MODS:
+            sys.exit("bench.py: --data modifier %r (known: %s)" % (m_, ", ".join(DATA_MODS)))
 
     # ---- the pool and this rank's block of it (halo_amd.pool.shard_range: contiguous ceil(N/world) images per rank)
     from halo_amd.pool import shard_range
@@ -534,8 +579,9 @@ def main():
         a.steps = math.ceil(rows / B)                                  # steps of the largest block
     else:
         seeds = [rank * R + s_ for s_ in range(R)]                      # every rank its own R images
-    feat, logit, gt = make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres)
-    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, rows, a.depth, lowres, a.branch, a.resets, a.sel_priority, a.lr_mode, a.tail)
+    feat, logit, gt, prior = make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres, data)
+    pipe = Pipeline(dev, feat, logit, gt, B, n_regions, rows, a.depth, lowres, a.branch, a.resets, a.sel_priority, a.lr_mode, a.tail,
+                    prior=prior)
 
     for _ in range(a.warmup):
         pipe.step(False)
@@ -557,10 +603,10 @@ def main():
     pipe.drain(check=False)
     torch.cuda.synchronize(dev)
     dt_rank = time.perf_counter() - t0
-    pipe.self_check()                                                   # host-synchronising checks: after the clock stopped
     if use_dist:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0                                       # the clock stops here, on both sides of the barrier
+    pipe.self_check()                                                   # host-synchronising checks: after it
     rank_dts = [dt_rank]
     if use_dist:
         cdev = torch.device("cpu") if host_backend else dev
@@ -577,7 +623,8 @@ def main():
     if sched:      # what came back for this rank's block is what its selector wrote
         assert torch.equal(tables[lo_r:hi_r], pipe.round_tables[:n_local]), "gathered tables differ from the local ones"
         assert torch.equal(counts[lo_r:hi_r], pipe.round_counts[:n_local])
-    assert int(counts.min()) == n_regions, "a gathered image has fewer picks than regions"
+    if prior is None:       # (half of an image already active can leave fewer than n_regions pickable windows)
+        assert int(counts.min()) == n_regions, "a gathered image has fewer picks than regions"
     exchange_checked = 0
     if pool_mode and n_local > 0:
         g_ = torch.arange(n_pool, device=dev)
@@ -618,7 +665,18 @@ def main():
         except Exception as exc:                  # never part of the measurement
             flat = None
             print("bench.py: flat-read probe unavailable (%s)" % exc, file=sys.stderr)
-    assert pipe.min_picked == n_regions, "selection stopped early"
+    assert prior is not None or pipe.min_picked == n_regions, "selection stopped early"
+    # every rank's own k_feat_reduce average (HIP events on its scoring stream): the N > 1 line carries the per-rank roofline
+    # fractions beside the images/s (north_star: "HBM-bandwidth fraction reported in the same run")
+    my_feat_ms = float(np.mean(feat_ms)) if feat_ms else float("nan")
+    rank_feat_ms = [my_feat_ms]
+    if use_dist:
+        cdev = torch.device("cpu") if host_backend else dev
+        allf = torch.zeros((world,), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allf, torch.tensor([my_feat_ms], dtype=torch.float64, device=cdev))
+        rank_feat_ms = [float(x) for x in allf.cpu()]
+    # what the value-binned sweep did with this rank's images (a cost counter; rank 0's block is reported)
+    ho_ = pipe.round_handover[:n_local].cpu().numpy() if n_local else np.zeros((0, 2), np.int32)
     assert pipe.tables_consistent, "pick tables of the same images differ between steps (race in the pipeline)"
 
     if rank == 0:
@@ -638,10 +696,12 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if pool_mode else "weak",       # --pool-images fixes the total work, --steps the per-GPU work
             "vs_baseline": None, "dtype": a.feat_dtype, "data": "synthetic",
-            "config": {"workload": "configs[%d]: synthetic pool, %dx%d, C=%d %s embedding, %d classes, %s branch "
+            "config": {"workload": "configs[%d]: synthetic pool of %d image evaluations (%s), %dx%d, C=%d %s embedding, %d classes, %s branch "
                                    "(%s x %s, %s, 3x3), %d regions/image, radius 1, mask radius %d"
-                                   % (2 if a.pool_images == 2975 else 1, Hh, Ww, C, a.feat_dtype, O, a.branch.upper(), unc, pur,
-                                      "normalised" if norm else "not normalised", n_regions, mrad),
+                                   % (2 if a.pool_images == 2975 else 1, images,
+                                      "the Cityscapes train list" if a.pool_images == 2975 else "configs[1] names 500", Hh, Ww, C, a.feat_dtype,
+                                      O, a.branch.upper(), unc, pur, "normalised" if norm else "not normalised", n_regions, mrad),
+                       "data": a.data,
                        "images_per_step_per_gpu": B, "batches_in_flight": a.depth, "resident_ring": R, "image_evaluations": images,
                        "outputs_written": "score, region_impurity, prediction_uncertainty (+ masks, pick tables)",
                        "sharding": "image-wise, %d rank(s), contiguous blocks of %d image(s)%s"
@@ -657,12 +717,26 @@ def main():
             "path_algorithmic_GBps": round(path_bytes_per_image * value / world / 1e9, 1),
             "pipeline_tables_consistent": bool(pipe.tables_consistent),
             "exchange": {"collectives_per_round": 1 if use_dist else 0, "ms": None if pipe.exchange_ms is None else round(pipe.exchange_ms, 3),
-                         "bytes_per_rank": int(pipe.wire.numel() * 4), "rows_checked_against_local_results": exchange_checked},
+                         "bytes_per_rank": int(pipe.wire.numel() * 4), "rows_checked_against_local_results": exchange_checked,
+                         "ranks": dist.get_world_size() if use_dist else 1,
+                         "backend": (dist.get_backend() if use_dist else None)},
+            # halo_greedy_select_ex's counters for rank 0's images: how many the value-binned sweep handed to the serial kernel
+            # (8-14 ms per image instead of 0.06 ms amortised), why, and after how many of its own picks
+            "selection": {"images": int(ho_.shape[0]), "handed_over": int((ho_[:, 0] != 0).sum()),
+                          "reasons": {_halo_lib.SWEEP_REASONS[r_]: int((ho_[:, 0] == r_).sum()) for r_ in range(1, 6) if (ho_[:, 0] == r_).any()},
+                          "sweep_picks_before_handover": None if not (ho_[:, 0] != 0).any() else
+                          {"min": int(ho_[ho_[:, 0] != 0, 1].min()), "mean": round(float(ho_[ho_[:, 0] != 0, 1].mean()), 1)},
+                          "picks_per_image": {"min": int(pipe.round_counts[:n_local].min()), "max": int(pipe.round_counts[:n_local].max())} if n_local else None},
             "state_resets": a.resets, "host_threads_per_rank": host_threads, "settle_s_before_first_gpu_call": settled,
             "tail": "on its own stream beside the next feature kernel (halo_score_maps_split)" if pipe.split else "inline on the scoring stream",
         }
         per_rank = [(shard_range(n_pool, r_, world)[1] - shard_range(n_pool, r_, world)[0]) / rank_dts[r_] for r_ in range(world)]
         out["per_rank_images_per_s"] = {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)}
+        if feat_ms and not lowres:
+            fr = [launch_bytes / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBPS for m_ in rank_feat_ms if m_ == m_]
+            if fr:
+                out["roofline"]["per_rank_frac"] = {"min": round(min(fr), 4), "max": round(max(fr), 4)}
+                out["roofline"]["per_rank_avg_launch_ms"] = [round(m_, 4) for m_ in rank_feat_ms]
         out["devices"] = device_ids                       # rank order; distinct unless HALO_BENCH_SHARE_GPU (test switch)
         out["distinct_devices"] = len(set(device_ids))
         assert share_gpu or out["distinct_devices"] == out["n_gpus"], "n_gpus must equal the number of distinct devices"
@@ -728,38 +802,51 @@ def main():
                                 float(np.mean(lr_ms["tail"])), HBM_PEAK_GBPS, "GB/s",
                                 "radius + entropy read (entropy twice: min/max pass and combine), active read, three maps written"))
             out["roofline_kernels"] = ks
-        for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if out["roofline"] is None or lowres or not os.path.exists(pmc):
                 continue
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("dtype") == a.feat_dtype and rec.get("shape_HWCO") == [Hh, Ww, C, O]:
-                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                    # not measured in THIS run (PMC counters need their own rocprofv3 passes): the collection's figure for this
+                    # exact launch shape, under its own name; `traffic` stays null
+                    out["roofline"]["traffic_from_profile"] = rec["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = "profiles/" + name
                     break
             except Exception:
                 pass
         if a.cpu_images > 0 and world == 1:
-            s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, a.cpu_images, n_regions, a.branch)
+            slots = parity_slots(R, B, n_local, a.cpu_images)
+            s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, prior, slots, n_regions, a.branch)
             out["cpu_baseline"] = {"value": round(1.0 / s_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                                   "sample": "1 warm-up + %d timed ring images, oracle/halo_oracle.c (OpenMP, %d threads = usable "
+                                   "sample": "1 warm-up + %d timed ring images (slots %s), oracle/halo_oracle.c (OpenMP, %d threads = usable "
                                              "host cores of %d visible), median s/image = %.2f"
-                                             % (a.cpu_images, cores, os.cpu_count() or 1, s_img),
+                                             % (len(slots), ",".join(str(i_) for i_ in slots), cores, os.cpu_count() or 1, s_img),
                                    # the honest anchor for "the reference's PyTorch path on host cores": its own code, measured by the
                                    # survey in the build container (the reference cannot travel to the GPU box)
                                    "reference_pytorch_probe": "SURVEY.md section 6: the reference's own code (torch CPU, 8 threads, geoopt/yacs "
                                                               "stand-ins) scored + selected 0.11-0.17 images/s at this shape"}
-            # same inputs -> the GPU picks of image 0 must equal the oracle's
-            from halo_amd.core.active.build import acquire_batch
-            act = torch.zeros((1, Hh, Ww), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
-            am = torch.full((1, Hh, Ww), 255, dtype=torch.int64, device=dev)
-            with torch.no_grad():
-                pk, nk = acquire_batch(logit[0:1], feat[0:1], gt[0:1], act, sel, am, unc_type=unc, pur_type=pur, normalize=norm,
-                                       n_regions=n_regions, active_radius=1, mask_radius=mrad, K=K)
-            out["parity_vs_cpu"] = bool(np.array_equal(pk[0, :int(nk[0])].cpu().numpy(), picks_cpu[0]))
+            # the TIMED pipeline's own pick tables (B images per launch: ring slot i was written to rows i, i + R, ... of the
+            # round's table) against the oracle's picks for the same images -- every occurrence, bit for bit
+            rt = pipe.round_tables[:n_local].cpu().numpy()
+            rc_ = pipe.round_counts[:n_local].cpu().numpy()
+            ok, rows_checked = True, 0
+            for i_ in slots:
+                want = np.ascontiguousarray(picks_cpu[i_])
+                for row_ in range(i_, n_local, R):
+                    k_ = int(rc_[row_])
+                    same = k_ == len(want) and np.array_equal(np.ascontiguousarray(rt[row_, :k_]).view(np.int64), want.view(np.int64))
+                    ok = ok and same
+                    rows_checked += 1
+            out["parity_vs_cpu"] = bool(ok)
+            out["parity_images_checked"] = len(slots)
+            out["parity_rows_checked"] = rows_checked
+            out["parity_what"] = "pick tables written by the timed %d-image launches vs the oracle, ring slots %s" % (B, ",".join(str(i_) for i_ in slots))
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+        if out.get("parity_vs_cpu") is False:
+            sys.exit("bench.py: the timed pipeline's pick tables differ from the CPU oracle's")
     if rank == 0 and a.dump_tables:
         np.savez(a.dump_tables, tables=tables.cpu().numpy(), counts=counts.cpu().numpy(), n_pool=n_pool, world=world)
     if use_dist:

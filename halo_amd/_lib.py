@@ -15,6 +15,7 @@ UNC_ZEROS = 3
 PUR = {"ripu": 0, "oracle_ripu": 1, "hyper": 2, "none": 3, "radius": 4, "euc_norm": 5}
 E_UNSUPPORTED = -2
 SELECT = {"auto": 0, "serial": 1, "binned": 2}                      # HALO_SELECT_* of include/halo_hip.h
+SWEEP_REASONS = ("done", "bad_values", "bin_overflow", "survivors", "exhausted", "not_run")      # HALO_SWEEP_*
 PAD = {"zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}     # HALO_PAD_*: nn.Conv2d's padding_mode values
 FLAG_NORMALIZE = 1
 
@@ -75,13 +76,15 @@ SIGNATURES = {
     "halo_score_range": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp]),
     "halo_greedy_select_ranged": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _sz, _int, _vp, _vp]),
+    "halo_greedy_select_ex": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _sz, _int, _vp, _vp, _vp]),
     "halo_greedy_select": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _sz, _int, _vp]),
 }
 
 # must equal HALO_ABI_VERSION of include/halo_hip.h; bumped whenever an exported signature changes, so a stale
 # library with the same symbol names but older argument lists is refused instead of being called with shifted arguments
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lock = threading.Lock()
 _handle = None

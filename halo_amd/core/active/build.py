@@ -22,7 +22,7 @@ from .floating_region import FloatingRegionScore, new_score_range, score_maps, s
 
 
 def greedy_select(score, n_regions, active_radius, mask_radius, active, selected, active_mask, ground_truth,
-                  return_picks=True, method=None, out=None, score_range=None):
+                  return_picks=True, method=None, out=None, score_range=None, handover=None):
     """Batched device-side selection.  score (B,H,W) f32|f64, active/selected (B,H,W) bool,
     active_mask/ground_truth (B,H,W) int64 -- all on one ROCm device, all mutated in place.
     Returns (picks (B,n,3) float64 rows (h, w, value), n_picked (B,) int32) or None.
@@ -31,7 +31,10 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     out: optional (picks (B,n,3) float64, n_picked (B,) int32) contiguous device tensors to write the tables into
     (pipelined callers collect a whole round's tables in one buffer); rows past an image's count are left as they are.
     score_range: the records score_maps / score_maps_lowres filled for these maps (new_score_range): the sweep then skips its
-    pass over the map for the value range (the records only have to bound the values: the picks do not depend on them)."""
+    pass over the map for the value range (the records only have to bound the values: the picks do not depend on them).
+    handover: optional (B,2) int32 device tensor that receives, per image, {reason, picks made by the sweep} -- reason 0
+    (_lib.SWEEP_REASONS[0]) = the value-binned sweep finished the image, anything else = the serial kernel continued it from that
+    pick on.  A cost counter only: results never depend on which kernel made a pick."""
     dev = _lib.require_device(score, active, selected, active_mask, ground_truth)
     B, H, W = score.shape
     for t in (score, active, selected, active_mask, ground_truth):
@@ -48,7 +51,11 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     elif return_picks:
         picks = torch.zeros((B, max(n, 1), 3), dtype=torch.float64, device=dev)
         n_picked = torch.zeros((B,), dtype=torch.int32, device=dev)
+    if handover is not None:
+        assert handover.shape == (B, 2) and handover.dtype == torch.int32 and handover.is_contiguous() and handover.device == dev
     if n == 0 or B == 0:
+        if handover is not None:
+            handover.zero_()
         return (picks[:, :0], n_picked) if return_picks else None
     L = _lib.lib()
     name = method or os.environ.get("HALO_SELECT", "auto")
@@ -59,10 +66,10 @@ def greedy_select(score, n_regions, active_radius, mask_radius, active, selected
     ws = _workspace(dev, nws, "select")
     if score_range is not None:
         assert score_range.is_contiguous() and score_range.device == dev and score_range.numel() >= L.halo_score_range_bytes(B)
-    rc = L.halo_greedy_select_ranged(_lib.ptr(score), _lib.dtype_code(score), B, H, W, n, int(active_radius),
-                                     int(mask_radius), _lib.ptr(active), _lib.ptr(selected), _lib.ptr(active_mask),
-                                     _lib.ptr(ground_truth), _lib.ptr(picks), _lib.ptr(n_picked), _lib.ptr(ws), ws.numel(),
-                                     method, _lib.ptr(score_range), _lib.stream_ptr(dev))
+    rc = L.halo_greedy_select_ex(_lib.ptr(score), _lib.dtype_code(score), B, H, W, n, int(active_radius),
+                                 int(mask_radius), _lib.ptr(active), _lib.ptr(selected), _lib.ptr(active_mask),
+                                 _lib.ptr(ground_truth), _lib.ptr(picks), _lib.ptr(n_picked), _lib.ptr(ws), ws.numel(),
+                                 method, _lib.ptr(score_range), _lib.ptr(handover), _lib.stream_ptr(dev))
     _lib.check(rc, "halo_greedy_select")
     return (picks, n_picked) if return_picks else None
 

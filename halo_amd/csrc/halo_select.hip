@@ -332,6 +332,25 @@ extern "C" int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int6
                                          int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                                          void *workspace, size_t workspace_bytes, int method, const void *score_range, void *stream)
 {
+    return halo_greedy_select_ex(score, dtype, B, H, W, n_regions, active_radius, mask_radius, active, selected, active_mask, gt, picks,
+                                 n_picked, workspace, workspace_bytes, method, score_range, nullptr, stream);
+}
+
+namespace halo {
+// the sweep did not run for these images (serial method, or a geometry it does not serve): {HALO_SWEEP_NOT_RUN, 0} rows
+__global__ void __launch_bounds__(256) k_sel_not_run(int *__restrict__ handover, int n_images)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < n_images) { handover[2 * b] = HALO_SWEEP_NOT_RUN; handover[2 * b + 1] = 0; }
+}
+}  // namespace halo
+
+extern "C" int halo_greedy_select_ex(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,
+                                     int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
+                                     int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
+                                     void *workspace, size_t workspace_bytes, int method, const void *score_range,
+                                     int32_t *handover, void *stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (!score || !active || !selected || !active_mask || !gt || B <= 0 || H <= 0 || W <= 0)
         return fail(HALO_E_ARG, "halo_greedy_select: null/empty argument");
@@ -342,6 +361,7 @@ extern "C" int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int6
     if (n_regions > H * W) n_regions = H * W;            // there are no more pixels than that to pick
     if (n_regions == 0) {
         if (n_picked && hipMemsetAsync(n_picked, 0, (size_t)B * 4, st) != hipSuccess) return fail(HALO_E_LAUNCH, "halo_greedy_select: memset failed");
+        if (handover && hipMemsetAsync(handover, 0, (size_t)B * 8, st) != hipSuccess) return fail(HALO_E_LAUNCH, "halo_greedy_select: memset failed");
         return HALO_OK;
     }
     if (!serial_supported(H, W)) return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: image too large for the tile table");
@@ -354,13 +374,16 @@ extern "C" int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int6
         if (p.ok) {
             SelHdr *hdr = nullptr;
             const int rc = binned_select(score, dtype, B, p, active, selected, active_mask, gt, picks, n_picked, workspace,
-                                         workspace_bytes, st, &hdr, score_range);
+                                         workspace_bytes, st, &hdr, score_range, handover);
             if (rc != HALO_OK) return rc;
             resume = hdr;
         } else if (method == HALO_SELECT_BINNED)
             return fail(HALO_E_UNSUPPORTED, "halo_greedy_select: the binned selector does not serve this geometry "
                                             "(mask radius above 14 or pick grid larger than LDS)");
     }
+
+    if (handover && !resume)
+        hipLaunchKernelGGL(k_sel_not_run, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, handover, (int)B);
 
     // ---- serial tile-table kernel: the whole job, or only the images the sweep handed over
     const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * (SEL_TPB_MAIN / 64) * 12 + 64;

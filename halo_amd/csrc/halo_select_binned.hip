@@ -59,6 +59,7 @@ struct BinWs {
     unsigned long long *ckey;                // nfmax * BIN_CAP: bin f owns slots [f * BIN_CAP, (f + 1) * BIN_CAP)
     unsigned *cpos;                          // nfmax * BIN_CAP
     unsigned *plist;                         // n_regions: picks as (w << 16) | h
+    int *handover;                           // optional (B, 2): {HALO_SWEEP_* reason, picks the sweep made}; NULL = not reported
 };
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
@@ -441,6 +442,7 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
 
     int np = 0;                                  // maintained by wave 0
     int fin = 0;                                 // 0 running, 1 done, 2 bail
+    int why = HALO_SWEEP_DONE;                   // reason of a hand-over (reported through ws.handover)
     const int r = g.mrad, cs = g.cs;
 
     // ---- the candidate stream.  Bins are cut into chunks of <= 256 candidates (one per thread); an iterator over the
@@ -546,7 +548,7 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
             t_surv += sc; if (sc > t_smax) t_smax = sc;
 #endif
             int state = 0;
-            if (sc > (unsigned)SW_SURV) state = 2;                           // more unsuppressed ties than fit: hand over
+            if (sc > (unsigned)SW_SURV) state = 3;                           // more unsuppressed ties than fit: hand over
             else if (sc) {
                 // at most 64 survivors (the common case): all at once; more: the sequential arg-max loop, four per lane
                 if (sc <= 64u) state = resolve_bin_parallel(skey, spos, sc, lane, r, cs, g, grid, plist, np);
@@ -557,12 +559,13 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
         STAMP(t_r)
         lds_barrier();
         fin = (int)ctl[1];
+        if (fin == 3) { fin = 2; why = HALO_SWEEP_SURVIVORS; }
         STAMP(t_b)
 #ifdef HALO_SWEEP_STAMPS
         ++nb;
 #endif
     };
-    if (overflowed) fin = 2;
+    if (overflowed) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; }
     Chunk c0 = next_chunk(), c1, c2;
     Regs d0, d1, d2;
     issue(c0, d0);
@@ -586,7 +589,11 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     }
 #endif
     if (tid == 0) {
-        if (fin == 0) fin = truncated ? 2 : 1;   // candidates exhausted: final unless the threshold bin was dropped
+        if (fin == 0) {                          // candidates exhausted: final unless the threshold bin was dropped
+            fin = truncated ? 2 : 1;
+            if (truncated) why = hdr->t1 >= (unsigned)NB1 ? HALO_SWEEP_BAD_VALUES : HALO_SWEEP_EXHAUSTED;
+        }
+        if (ws.handover) { ws.handover[2 * b] = fin == 1 ? HALO_SWEEP_DONE : why; ws.handover[2 * b + 1] = np; }
         hdr->np = np;
         hdr->status = fin == 1 ? SEL_DONE : SEL_BAIL;
         if (fin == 1 && n_picked) n_picked[b] = np;
@@ -719,7 +726,7 @@ int score_range_exact(const void *score, int dtype, int64_t B, int64_t hw, void 
 
 int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *active, uint8_t *selected, int64_t *active_mask,
                   const int64_t *gt, double *picks, int32_t *n_picked, void *workspace, size_t workspace_bytes, hipStream_t st,
-                  SelHdr **hdr_out, const void *score_range)
+                  SelHdr **hdr_out, const void *score_range, int32_t *handover)
 {
     if (!workspace || workspace_bytes < p.total_bytes) return fail(HALO_E_WORKSPACE, "halo_greedy_select: workspace too small");
     char *base = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -735,6 +742,7 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     ws.ckey = (unsigned long long *)(base + p.off_ckey);
     ws.cpos = (unsigned *)(base + p.off_cpos);
     ws.plist = (unsigned *)(base + p.off_plist);
+    ws.handover = handover;
     const BinGeom &g = p.g;
     const long long hw = (long long)g.H * g.W;
     {   // zero_bytes is a multiple of 256 (take() aligns every array), base is 256-byte aligned

@@ -27,7 +27,7 @@ BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t 
 // (`*hdr_out`, B entries) for the serial kernel to continue.
 int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *active, uint8_t *selected, int64_t *active_mask,
                   const int64_t *gt, double *picks, int32_t *n_picked, void *workspace, size_t workspace_bytes, hipStream_t st,
-                  SelHdr **hdr_out, const void *score_range = nullptr);
+                  SelHdr **hdr_out, const void *score_range = nullptr, int32_t *handover = nullptr);
 
 // Exact value range of B score maps (hw pixels each) as range records (one SelHdr-sized record per image).
 int score_range_exact(const void *score, int dtype, int64_t B, int64_t hw, void *range_out, hipStream_t st);

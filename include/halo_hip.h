@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 5
+#define HALO_ABI_VERSION 6
 
 enum { HALO_F32 = 0, HALO_F64 = 1 };
 
@@ -240,6 +240,22 @@ int halo_greedy_select_ranged(void *score, int dtype, int64_t B, int64_t H, int6
                               int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
                               int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
                               void *workspace, size_t workspace_bytes, int method, const void *score_range, void *stream);
+
+/* halo_greedy_select_ranged that also REPORTS what the value-binned sweep did with each image: `handover` (B,2) i32, NULL = do
+ * not report; row b = {reason, picks the sweep made before it stopped}.  Reason 0 = the sweep finished the image; anything else =
+ * the serial kernel continued it from that pick on (results are identical either way -- this is a cost counter: a handed-over
+ * image costs milliseconds instead of tens of microseconds). */
+enum { HALO_SWEEP_DONE = 0,
+       HALO_SWEEP_BAD_VALUES = 1,     /* NaN / +inf in the map, a constant map, or nothing pickable: no value range to bin */
+       HALO_SWEEP_BIN_OVERFLOW = 2,   /* a run of candidates too dense for its value bins (a plateau of ties) */
+       HALO_SWEEP_SURVIVORS = 3,      /* more unsuppressed candidates in one step than the resolve stage holds */
+       HALO_SWEEP_EXHAUSTED = 4,      /* candidates ran out behind a dropped threshold bin / a stale histogram */
+       HALO_SWEEP_NOT_RUN = 5 };      /* serial method, or a geometry the sweep does not serve */
+int halo_greedy_select_ex(void *score, int dtype, int64_t B, int64_t H, int64_t W, int64_t n_regions,
+                          int64_t active_radius, int64_t mask_radius, uint8_t *active, uint8_t *selected,
+                          int64_t *active_mask, const int64_t *gt, double *picks, int32_t *n_picked,
+                          void *workspace, size_t workspace_bytes, int method, const void *score_range,
+                          int32_t *handover, void *stream);
 
 /* ---- pool side of the round: image-wise sharding, ONE all-gather of pick tables (the reference runs the
  * round on rank 0 only, core/train_learners.py:307-326) ----

@@ -1426,6 +1426,28 @@ def test_bench_contract_on_a_small_shape(dev):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "images/s" and d["parity_vs_cpu"] is True
     assert d["pipeline_tables_consistent"] is True
+    # the oracle checks the TIMED launches' own tables, images spread over the batch, every occurrence in the round
+    assert d["parity_images_checked"] >= 1 and d["parity_rows_checked"] >= d["parity_images_checked"]
+    sel = d["selection"]
+    assert sel["images"] == 12 and 0 <= sel["handed_over"] <= sel["images"] and isinstance(sel["reasons"], dict)
+    assert d["roofline"]["traffic"] is None and "12 image evaluations" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("data", ["late_round", "saturated", "peaked", "late_round+saturated+peaked"])
+def test_bench_data_variants_on_a_small_shape(dev, data):
+    """bench.py --data: the value distributions that stress the selector (half the map already active, projected radii,
+    saturated softmax) -- the timed tables still equal the oracle's and the hand-over counters are reported."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--height", "128", "--width", "256", "--channels", "16",
+                        "--steps", "3", "--warmup", "1", "--batch", "4", "--ring", "8", "--cpu-images", "4", "--data", data],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["parity_vs_cpu"] is True and d["parity_images_checked"] == 4 and d["config"]["data"] == data
+    assert d["selection"]["images"] == 12 and d["pipeline_tables_consistent"] is True
 
 
 def test_fused_and_unfused_entropy_paths_agree_bitwise(dev):
@@ -2271,3 +2293,109 @@ def test_the_visualize_wrong_call_pattern(dev, monkeypatch):
         assert bits_equal(s.cpu().numpy(), so) and bits_equal(i.cpu().numpy(), io) and bits_equal(u.cpu().numpy(), uo), unc
         if unc != "entropy":
             assert np.isnan(u.cpu().numpy()).all()
+
+
+# ------------------------------------------------------------------ the launch shape bench.py times: B = 16 full-size images in ONE call
+def _device_pool(dev, B, H, W, C, O, seed, fdtype=torch.float64):
+    """B distinct smooth full-size images (latent -> expmap -> HyperMLR -> x4 resize) produced on the device: inputs are inputs,
+    whoever made them -- the checked images are copied to the host and handed to the oracle byte for byte."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners
+    rng = np.random.default_rng(seed)
+    h, w = H // 4, W // 4
+    mapper = HyperMapper(c=1.0)
+    torch.manual_seed(seed)
+    mlr = HyperMLR(C, O, c=1.0).to(dev)
+    feat = torch.empty((B, C, H, W), dtype=fdtype, device=dev)
+    logit = torch.empty((B, O, H, W), dtype=torch.float32, device=dev)
+    feat_lr = torch.empty((B, C, h, w), dtype=torch.float64, device=dev)
+    logit_lr = torch.empty((B, O, h, w), dtype=torch.float32, device=dev)
+    gt = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        for b in range(B):
+            z = t((rng.standard_normal((1, C, h, w)) * 0.1).astype(np.float32), dev)
+            emb = mapper.expmap(z, dim=1)
+            lg = mlr._hyper_logits(emb, out_dtype=torch.float32)
+            feat_lr[b:b + 1], logit_lr[b:b + 1] = emb, lg
+            logit[b:b + 1] = bilinear_align_corners(lg, (H, W))
+            up = bilinear_align_corners(emb, (H, W))
+            feat[b:b + 1] = up if fdtype == torch.float64 else up.float()
+            del up
+            g = rng.integers(0, O, (H, W)).astype(np.int64)
+            g[rng.random((H, W)) < 0.05] = 255
+            gt[b] = t(g, dev)
+    torch.cuda.synchronize(dev)
+    return feat, logit, gt, feat_lr, logit_lr
+
+
+def _check_batch_images_vs_oracle(dev, maps, picks, npk, act, sel, am, sc_after, logit, feat, gt, images, n, mrad, tag):
+    """images `images` of one batched call against the oracle, bit for bit: three maps, pick table, masks, mutated score"""
+    from oracle import halo_oracle as ho
+    H, W = gt.shape[-2:]
+    for b in images:
+        so, io, uo = ho.floating_region_score(logit[b:b + 1].cpu().numpy(), feat[b:b + 1].cpu().numpy(), "entropy", "radius", True,
+                                              gt[b].cpu().numpy(), size=3, purity_type="radius")
+        assert bits_equal(maps[2][b].cpu().numpy(), uo), (tag, b, "uncertainty")
+        assert bits_equal(maps[1][b].cpu().numpy(), io), (tag, b, "impurity")
+        assert bits_equal(maps[0][b].cpu().numpy(), so), (tag, b, "score")
+        a_o = np.zeros((H, W), bool); s_o = np.zeros((H, W), bool); m_o = np.full((H, W), 255, np.int64)
+        _, _, _, _, pk_o = ho.select_pixels_to_label(so, n, 1, mrad, a_o, s_o, m_o, gt[b].cpu().numpy(), True)
+        k = int(npk[b])
+        assert k == len(pk_o) == n, (tag, b)
+        assert bits_equal(picks[b, :k].cpu().numpy(), pk_o), (tag, b, "picks")
+        assert np.array_equal(act[b].cpu().numpy(), a_o) and np.array_equal(sel[b].cpu().numpy(), s_o), (tag, b, "indicators")
+        assert np.array_equal(am[b].cpu().numpy(), m_o), (tag, b, "mask")
+        assert bits_equal(sc_after[b].cpu().numpy(), so), (tag, b, "score after selection")     # so was mutated by the oracle's selection
+
+
+@pytest.mark.parametrize("B,C,O,images", [(16, 256, 19, (0, 7, 8, 15)), (8, 512, 16, (0, 3, 4, 7))])
+def test_headline_launch_shape_batched_full_size_vs_oracle(dev, B, C, O, images):
+    """what bench.py times is ONE score_maps + ONE greedy_select call over 16 full-size images (1024x2048,
+    C = 256 float64: 8.6 G feature elements, the only place where element offsets pass 2^32 -- image 8 starts exactly there, image
+    7 ends there; at C = 512 image 4 does).  Images spread over the batch are checked against the oracle bit for bit: maps, the
+    2331 picks in order, the masks and the mutated score map (floating_region.py:129-217, build.py:137-160)."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps
+    H, W, n, mrad = 1024, 2048, 2331, 5
+    feat, logit, gt, _, _ = _device_pool(dev, B, H, W, C, O, 500 + C)
+    assert feat.numel() > (1 << 32)
+    with torch.no_grad():
+        maps = score_maps(logit, feat, "entropy", "radius", True, gt, size=3)
+        act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+        sc = maps[0].clone()
+        picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt)
+    torch.cuda.synchronize(dev)
+    _check_batch_images_vs_oracle(dev, maps, picks, npk, act, sel, am, sc, logit, feat, gt, images, n, mrad, "B=%d C=%d" % (B, C))
+
+
+def test_headline_launch_shape_lowres_sources_batched_vs_oracle(dev):
+    """The same batch through the RegionSelection boundary (N1): 16 x4 low-res head outputs in ONE score_maps_lowres call (default
+    'exact' order) == the oracle's upsample-then-score, images 0 / 7 / 15, plus selection."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from oracle import halo_oracle as ho
+    B, H, W, C, O, n, mrad = 16, 1024, 2048, 256, 19, 2331, 5
+    rng = np.random.default_rng(77)
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
+    torch.manual_seed(77)
+    mlr = HyperMLR(C, O, c=1.0).to(dev)
+    with torch.no_grad():
+        z = t((rng.standard_normal((B, C, H // 4, W // 4)) * 0.1).astype(np.float32), dev)
+        feat_lr = HyperMapper(c=1.0).expmap(z, dim=1)
+        logit_lr = mlr._hyper_logits(feat_lr, out_dtype=torch.float32)
+        gt = t(rng.integers(0, O, (B, H, W)).astype(np.int64), dev)
+        maps = score_maps_lowres(logit_lr, feat_lr, (H, W), "entropy", "radius", True, gt, ksize=3, mode="exact")
+        act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+        sc = maps[0].clone()
+        picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, gt)
+    torch.cuda.synchronize(dev)
+    for b in (0, 7, 15):
+        lg = ho.bilinear(logit_lr[b:b + 1].cpu().numpy(), (H, W))
+        em = ho.bilinear(feat_lr[b:b + 1].cpu().numpy(), (H, W))
+        so, io, uo = ho.floating_region_score(lg, em, "entropy", "radius", True, gt[b].cpu().numpy(), size=3, purity_type="radius")
+        assert bits_equal(maps[0][b].cpu().numpy(), so) and bits_equal(maps[1][b].cpu().numpy(), io) and bits_equal(maps[2][b].cpu().numpy(), uo), b
+        a_o = np.zeros((H, W), bool); s_o = np.zeros((H, W), bool); m_o = np.full((H, W), 255, np.int64)
+        _, _, _, _, pk_o = ho.select_pixels_to_label(so, n, 1, mrad, a_o, s_o, m_o, gt[b].cpu().numpy(), True)
+        assert int(npk[b]) == n == len(pk_o) and bits_equal(picks[b].cpu().numpy(), pk_o), b
+        assert np.array_equal(act[b].cpu().numpy(), a_o) and np.array_equal(am[b].cpu().numpy(), m_o), b

@@ -182,6 +182,12 @@ def test_bench_eight_ranks_on_one_gpu_score_the_2975_image_pool_like_one_rank(de
     assert len(one["devices"]) == 1 and one["distinct_devices"] == 1
     assert eight["per_rank_images_per_s"]["min"] > 0 and eight["pipeline_tables_consistent"] is True
     assert eight["host_threads_per_rank"] == max(1, one["host_threads_per_rank"] // 8)
+    # per-rank evidence in the N > 1 line: every rank's own feature-kernel average and roofline fraction
+    rf = eight["roofline"]
+    assert len(rf["per_rank_avg_launch_ms"]) == 8 and all(v > 0 for v in rf["per_rank_avg_launch_ms"])
+    assert 0 < rf["per_rank_frac"]["min"] <= rf["per_rank_frac"]["max"]
+    assert eight["exchange"]["ranks"] == 8 and eight["exchange"]["backend"] == "gloo" and one["exchange"]["ranks"] == 1
+    assert eight["selection"]["images"] == 372 and one["selection"]["images"] == 2975
     a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "eight.npz")
     assert int(a["n_pool"]) == int(b["n_pool"]) == 2975 and int(b["world"]) == 8
     assert np.array_equal(a["counts"], b["counts"]) and a["tables"].shape == b["tables"].shape == (2975, 10, 3)
