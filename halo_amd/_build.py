@@ -38,7 +38,7 @@ def is_stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "_asmcheck.py")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -91,30 +91,77 @@ def build(force=False, verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
+class AsmCheckError(RuntimeError):
+    """the emitted device assembly breaks a contract of the hand-scheduled inline assembly (halo_amd/_asmcheck.py)"""
+
+
+def device_asm_path(objdir, src):
+    """where `-save-temps=obj` leaves the device assembly of the compile that produced the object file"""
+    return os.path.join(objdir, src.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def check_device_asm(path, src):
+    """The gate between compile and link: a translation unit that hand-issues LDS reads / LDS-DMA in inline assembly is scanned on
+    the assembly hipcc JUST emitted for it (registers with a read in flight, counted waits of the DMA double buffer); a hit refuses
+    the build -- another hipcc, other flags or HALO_LR8_WAVES can bring the round-4 race back silently.
+    HALO_ASMCHECK=warn reports and carries on, =off skips (debugging aids; never set by the package)."""
+    mode = os.environ.get("HALO_ASMCHECK", "enforce")
+    if mode == "off":
+        return None
+    import io
+    from . import _asmcheck
+    if not os.path.exists(path):
+        raise AsmCheckError("%s: the compiler left no device assembly at %s to check" % (src, path))
+    buf = io.StringIO()
+    with open(path) as f:
+        checked, flagged = _asmcheck.check_text(f.read(), out=buf)
+    if checked == 0:
+        raise AsmCheckError("%s hand-issues LDS reads / LDS-DMA but no function of %s carries them: the scan is looking at the wrong file" % (src, path))
+    if flagged:
+        msg = "%s: %d violation(s) in %d hand-scheduled function(s) of the emitted assembly:\n%s" % (src, flagged, checked, buf.getvalue()[:6000])
+        if mode == "warn":
+            sys.stderr.write("halo_amd._build: WARNING, " + msg + "\n")
+        else:
+            raise AsmCheckError(msg + "\nlibhalo_hip.so was NOT linked (HALO_ASMCHECK=warn overrides)")
+    return checked, flagged
+
+
+def _build_locked(verbose, objdir=None, so=None):
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = objdir or os.path.join(CSRC, "build")
+    so = so or SO
     os.makedirs(objdir, exist_ok=True)
+    from . import _asmcheck
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        with open(os.path.join(CSRC, src)) as f:
+            scan = _asmcheck.source_needs_check(f.read()) and os.environ.get("HALO_ASMCHECK", "enforce") != "off"
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-save-temps=obj"] if scan else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, obj, scan, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     objs = []
-    for src, obj, p in procs:
+    for src, obj, scan, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
+        if scan:
+            res = check_device_asm(device_asm_path(objdir, src), src)
+            if verbose and res:
+                print("%s: %d hand-scheduled function(s) scanned, %d flagged" % (src, res[0], res[1]))
+            stem = src.replace(".hip", "")
+            for fn in os.listdir(objdir):              # the temporaries of -save-temps (bitcode, preprocessed source, 10 MB of assembly);
+                if fn.startswith((stem + "-", stem + ".hip-")):      # a flagged .s stays behind for inspection (the raise above)
+                    os.remove(os.path.join(objdir, fn))
         objs.append(obj)
-    tmp = SO + ".tmp.%d" % os.getpid()
+    tmp = so + ".tmp.%d" % os.getpid()
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout)
-    os.replace(tmp, SO)
-    return SO
+    os.replace(tmp, so)
+    return so
 
 
 if __name__ == "__main__":

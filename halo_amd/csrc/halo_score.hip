@@ -1723,20 +1723,26 @@ __global__ void __launch_bounds__(TPB, (PPT > LR_PPT ? HALO_LR8_WAVES : 1)) k_fe
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) sp[i] = fb + (size_t)sch[i] * hwl + soff[i];
     const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(wv * 64) * 16u));
+    // ONE straight-line block of DMA_PER_WAVE instructions per chunk, whatever the chunk: the counted wait below counts them, and
+    // halo_amd/_asmcheck.py (run by the build) verifies on the emitted assembly that nothing else is outstanding at that wait.  A
+    // partial last chunk steps the lanes whose channel lies past it back onto its last channel (round 4 had one issue block per
+    // case: the compiler spilled the second block's pointers and reloaded each with s_waitcnt vmcnt(0) between two DMAs)
     auto issue = [&](int c0, int buf) {
         const int cc = C - c0 < CCF ? C - c0 : CCF;
-        if (cc == CCF) {
+        long long back[DMA_PER_WAVE];
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) back[i] = 0;
+        if (cc != CCF) {
 #pragma unroll
             for (int i = 0; i < DMA_PER_WAVE; ++i) {
-                glds16(sp[i], dst0 + (unsigned)buf * (DMA_UNITS * 16) + (unsigned)(i * (TPB / 64) * 64) * 16u);
-                sp[i] += (size_t)CCF * hwl;
+                const int ex = (int)sch[i] - (cc - 1);
+                back[i] = ex > 0 ? (long long)ex * hwl : 0ll;
             }
-        } else {
+        }
 #pragma unroll
-            for (int i = 0; i < DMA_PER_WAVE; ++i) {
-                const unsigned ch = sch[i] < (unsigned)cc ? sch[i] : (unsigned)(cc - 1);
-                glds16(fb + (size_t)(c0 + ch) * hwl + soff[i], dst0 + (unsigned)buf * (DMA_UNITS * 16) + (unsigned)(i * (TPB / 64) * 64) * 16u);
-            }
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            glds16(sp[i] - back[i], dst0 + (unsigned)buf * (DMA_UNITS * 16) + (unsigned)(i * (TPB / 64) * 64) * 16u);
+            sp[i] += (size_t)CCF * hwl;
         }
     };
     const int pu = (w - tx_lo) >> 1;                              // the pair that starts at column w, if the image holds it

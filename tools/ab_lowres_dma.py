@@ -46,3 +46,6 @@ for (B, C, hl, wl, hf, wf, tag) in ((16, 256, 256, 512, 256, 512, "bench ring x4
     print(f"{tag}: dma {res['dma'][0]:.3f} ms ({flops / res['dma'][0] / 1e9:.1f} TFLOP/s by the reference formula's 11 flops per pixel and channel), "
           f"4 pixels per lane {res['dma4'][0]:.3f} ms, runtime-stride DMA {res['dma_rt'][0]:.3f} ms, register staging {res['regs'][0]:.3f} ms, "
           f"bit-identical {same}", flush=True)
+    # an A/B of staging variants that disagree is a FAILURE of the run, not a line to be read later (round 4: this tool printed
+    # "bit-identical False" for the race of 3ae5865 and exited 0)
+    assert same, f"{tag}: the staging variants of the exact low-res pass disagree bitwise"
