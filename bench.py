@@ -104,13 +104,14 @@ def parse():
                          "pixels already active (-inf) in 11x11 blocks, as after several acquisition rounds; saturated = latents x 40 over "
                          "the right half of the image (embeddings projected onto the ball's boundary: one exact radius there); peaked = "
                          "logits x 30 (saturated softmax: exactly equal entropies over large regions).  The selector's hand-over counters "
-                         "(`selection`) say what each does to the value-binned sweep")
+                         "(`selection`) say what each does to the value-binned sweep; plateau = the contrived worst case, a quarter of the image "
+                         "with all-equal logits AND boundary embeddings: one exact score at the TOP of the map, every pick a tie-break")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     return ap.parse_args()
 
 
-DATA_MODS = ("gaussian", "late_round", "saturated", "peaked")
+DATA_MODS = ("gaussian", "late_round", "saturated", "peaked", "plateau")
 
 
 def make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres=False, data=("gaussian",)):
@@ -136,6 +137,12 @@ def make_ring(dev, R, C, Hh, Ww, fdtype, seeds, lowres=False, data=("gaussian",)
             lg = mlr._hyper_logits(emb, out_dtype=torch.float32)
             if "peaked" in data:
                 lg *= 30.0                       # softmax saturates: p = 1 / 0 exactly over large regions
+            if "plateau" in data:
+                # all-equal logits (uniform softmax: the maximal entropy, the same bits in every pixel) on embeddings of norm 1.001
+                # (outside the ball: dist0 clamps its argument to 1 - 1e-7, one exact radius): the TOP score of the map, exactly tied
+                # over a quarter of the image -- every pick is a tie-break by position
+                lg[..., : h // 2, : w // 2] = 0.0
+                emb[..., : h // 2, : w // 2] = 1.001 / math.sqrt(C)
             if lowres:
                 logit[r:r + 1] = lg
                 feat[r:r + 1] = emb if fdtype == torch.float64 else emb.float()

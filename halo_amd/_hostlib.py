@@ -4,7 +4,7 @@ import threading
 
 from . import _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lock = threading.Lock()
 _handle = None
 
@@ -35,8 +35,11 @@ def lib():
                                                    C.c_size_t, C.c_void_p, C.c_void_p]
                 h.halo_retire_image.restype = C.c_int
                 h.halo_retire_image.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
-                                                C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
                                                 C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+                h.halo_compose_indicators.restype = C.c_int
+                h.halo_compose_indicators.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                      C.c_int64, C.c_int64, C.c_int64]
                 _handle = h
     return _handle
 
@@ -50,10 +53,27 @@ def png_gray8_write(path, arr):
         raise OSError("halo_png_gray8_write(%r) failed (%d)" % (path, rc))
 
 
-def retire_image(path_png, path_indicator, origin_mask, origin_label, picks, k, radius, active, selected, template):
+def compose_indicators(prior_active, prior_selected, picks, k, radius, mask_radius):
+    """-> (active, selected) (H, W) bool arrays after the round: the maps the image entered it with plus the windows of the first k
+    picks (halo_compose_indicators, build.py:56-59).  GIL-free."""
+    import numpy as np
+    H, W = prior_active.shape
+    pa, ps = np.ascontiguousarray(prior_active).view(np.uint8), np.ascontiguousarray(prior_selected).view(np.uint8)
+    pk = np.ascontiguousarray(picks, dtype=np.float64)
+    a, s = np.empty((H, W), np.uint8), np.empty((H, W), np.uint8)
+    rc = lib().halo_compose_indicators(a.ctypes.data, s.ctypes.data, pa.ctypes.data, ps.ctypes.data, H, W, pk.ctypes.data, int(k),
+                                       int(radius), int(mask_radius))
+    if rc != 0:
+        raise ValueError("halo_compose_indicators failed (%d)" % rc)
+    return a.view(np.bool_), s.view(np.bool_)
+
+
+def retire_image(path_png, path_indicator, origin_mask, origin_label, picks, k, radius, active, selected, template, compose_mask_radius=-1):
     """One image's two files in one GIL-free call (halo_retire_image): origin_mask / origin_label (H, W) contiguous integer
     numpy arrays, picks (>= k, 3) contiguous float64, active / selected (H, W) contiguous bool / uint8 arrays (pinned staging
-    memory is fine), template: the shape's _IndicatorTemplate (raw bytes + field offsets) or None to skip the indicator."""
+    memory is fine), template: the shape's _IndicatorTemplate (raw bytes + field offsets) or None to skip the indicator.
+    compose_mask_radius >= 0: active / selected are the maps the image ENTERED the round with; the round's windows (that mask
+    radius; `radius` for selected) are added on the way."""
     import os
     H, W = origin_mask.shape
     for a in (origin_mask, origin_label, active, selected):
@@ -67,6 +87,6 @@ def retire_image(path_png, path_indicator, origin_mask, origin_label, picks, k, 
         tpl, tlen, off_a, off_s, fa, fs, pind = None, 0, 0, 0, None, None, None
     rc = lib().halo_retire_image(os.fsencode(path_png), pind, origin_mask.ctypes.data, origin_mask.dtype.itemsize, origin_label.ctypes.data,
                                  origin_label.dtype.itemsize, H, W, picks.ctypes.data, int(k), int(radius), active.ctypes.data,
-                                 selected.ctypes.data, tpl, tlen, off_a, off_s, fa, fs)
+                                 selected.ctypes.data, int(compose_mask_radius), tpl, tlen, off_a, off_s, fa, fs)
     if rc != 0:
         raise OSError("halo_retire_image(%r, %r) failed (%d)" % (path_png, path_indicator, rc))

@@ -171,7 +171,7 @@ class AcquisitionParams:
 class _InFlight:
     """One loader batch (b images of one label size, b = 1 in the reference) whose staging, scoring, selection and device->host
     copies have been enqueued on a side stream."""
-    __slots__ = ("done", "keep", "picks", "npk", "slot", "buf", "b", "left", "lock", "table", "radius")
+    __slots__ = ("done", "keep", "picks", "npk", "slot", "buf", "b", "left", "lock", "table", "radius", "compose", "mask_radius", "write")
 
 
 class _SlotBuffers:
@@ -249,7 +249,7 @@ def _side_streams(dev, n):
 
 
 def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in, selected_in, dev, slot, lowres_mode=None, stats=None,
-            mask_staging="table"):
+            mask_staging="table", write_files=True):
     """Enqueue b images of one label size (build.py:113-166 for each) on the slot's stream: stage what the device needs, score ->
     mask -> select as ONE batch, copy the results back into the slot's pinned buffers.  Fully asynchronous: `rec.done` fires
     when the pinned buffers hold the results of all b images.
@@ -274,6 +274,9 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
     scorer_reads_gt = prm.unc == "oracle_acc" or prm.pur == "oracle_ripu"
     # masks that already live on the device are composed there
     rec.table = mask_staging == "table" and not origin_mask.is_cuda and not origin_label.is_cuda
+    # ... and so are the indicator maps, when the loader's copies are host tensors (they always are in the reference)
+    rec.compose = rec.table and not active_in.is_cuda and not selected_in.is_cuda
+    rec.write = bool(write_files)
     n_regions = prm.regions(size[0] * size[1])
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))             # the head outputs are complete from here on
@@ -284,7 +287,8 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
         if not rec.table or scorer_reads_gt:
             buf.d_gt.copy_(origin_label, non_blocking=True)
         buf.d_active.copy_(active_in, non_blocking=True)
-        buf.d_selected.copy_(selected_in, non_blocking=True)
+        if not rec.compose:                                   # (composed on the host: the kernel's window writes land in scratch)
+            buf.d_selected.copy_(selected_in, non_blocking=True)
         # table staging: the selection kernel still writes its windows (active_mask[window] = ground_truth[window]) -- into the
         # slot's scratch mask, from itself when no label map is resident: nobody reads that buffer
         gt_dev = buf.d_gt if (not rec.table or scorer_reads_gt) else buf.d_amask
@@ -303,15 +307,16 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
             # reference's cast-after-copy, build.py:67-68,162)
             buf.d_mask8.copy_(buf.d_amask)
             buf.out_mask.copy_(buf.d_mask8, non_blocking=True)
-        buf.out_active.copy_(buf.d_active, non_blocking=True)
-        buf.out_selected.copy_(buf.d_selected, non_blocking=True)
+        if not rec.compose:
+            buf.out_active.copy_(buf.d_active, non_blocking=True)
+            buf.out_selected.copy_(buf.d_selected, non_blocking=True)
         buf.out_npk.copy_(rec.npk, non_blocking=True)       # (a .item() in the writer thread would queue behind the backbone's kernels)
         rec.done = torch.cuda.Event(blocking=True)           # the writer threads sleep on it instead of spinning
         rec.done.record(stream)
     # what the side stream and the writer threads still read: the head outputs and the loader's tensors, kept alive until the
     # batch is retired
     rec.keep = (logits_lr, embed_lr, origin_mask, origin_label, active_in, selected_in)
-    rec.radius = prm.radius
+    rec.radius, rec.mask_radius = prm.radius, prm.mask_radius
     if stats is not None:
         stats["main_launch_s"] += time.perf_counter() - t1
     return rec
@@ -337,6 +342,20 @@ def compose_mask(origin_mask, origin_label, picks, active_radius):
         rr, cc = rows[ok], cols[ok]
         mask[rr, cc] = origin_label[rr, cc].astype(np.uint8)     # the same wrap for the labels
     return mask
+
+
+def compose_indicators(prior_active, prior_selected, picks, active_radius, mask_radius):
+    """`active` / `selected` (H, W) bool after a round, from the maps the image entered it with and the round's picks
+    (build.py:56-59: active[h-R:h+R+1, w-R:w+R+1] = True with R = mask radius, selected[...] with R = radius; slices clipped at the
+    borders like the reference's).  The native twin is halo_compose_indicators (libhalo_host.so); this is its numpy statement."""
+    H, W = prior_active.shape
+    act = np.array(prior_active, dtype=bool, copy=True)
+    sel = np.array(prior_selected, dtype=bool, copy=True)
+    for row in np.asarray(picks)[:, :2].astype(np.int64):
+        h, w = int(row[0]), int(row[1])
+        for dst, r in ((act, int(mask_radius)), (sel, int(active_radius))):
+            dst[max(h - r, 0):h + r + 1, max(w - r, 0):w + r + 1] = True
+    return act, sel
 
 
 _PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
@@ -528,9 +547,18 @@ def _finish(rec, i, paths, slots, stats=None):
         t1 = time.perf_counter()
         buf = rec.buf
         k = int(buf.out_npk[i])
+        if not rec.write:                                        # global-budget rounds: the files follow once the pool's keep-mask is known
+            return (rec.picks[i], k)
         is_png = bool(buf.out_mask[i].numel()) and str(paths[0]).lower().endswith(".png")
         mask = active = selected = None
         retire = _native_retire() if (rec.table and is_png) else None
+        # the indicator maps: the device's results in the pinned buffers, or -- composed on the host -- the loader's own maps
+        if rec.compose:
+            ind_a, ind_s, cmr = rec.keep[4][i].numpy(), rec.keep[5][i].numpy(), rec.mask_radius
+            if retire is not None and not (ind_a.flags["C_CONTIGUOUS"] and ind_s.flags["C_CONTIGUOUS"] and ind_a.itemsize == 1 and ind_s.itemsize == 1):
+                retire = None
+        else:
+            ind_a, ind_s, cmr = buf.out_active[i].numpy(), buf.out_selected[i].numpy(), -1
         if retire is not None:
             # mask_staging="table": ONE call without the interpreter lock composes the mask from the loader's maps and the pick
             # table, encodes it, and writes the indicator from the pinned maps through the shape's template
@@ -538,11 +566,14 @@ def _finish(rec, i, paths, slots, stats=None):
             if om.flags["C_CONTIGUOUS"] and gt.flags["C_CONTIGUOUS"] and om.dtype.kind in "iub" and gt.dtype.kind in "iub" \
                     and om.ctypes.data % om.dtype.itemsize == 0 and gt.ctypes.data % gt.dtype.itemsize == 0:      # (naturally aligned elements)
                 tpl = _IndicatorTemplate.get(om.shape)
-                retire(paths[0], paths[1], om, gt, buf.out_picks[i].numpy(), k, rec.radius, buf.out_active[i].numpy(),
-                       buf.out_selected[i].numpy(), tpl if tpl.ok else None)
+                retire(paths[0], paths[1], om, gt, buf.out_picks[i].numpy(), k, rec.radius, ind_a, ind_s, tpl if tpl.ok else None,
+                       compose_mask_radius=cmr)
                 native = True
                 if not tpl.ok:
-                    active, selected = torch.from_numpy(buf.out_active[i].numpy().copy()), torch.from_numpy(buf.out_selected[i].numpy().copy())
+                    if rec.compose:
+                        active, selected = (torch.from_numpy(x) for x in compose_indicators(ind_a, ind_s, buf.out_picks[i, :k].numpy(), rec.radius, cmr))
+                    else:
+                        active, selected = torch.from_numpy(ind_a.copy()), torch.from_numpy(ind_s.copy())
                 t_png = time.perf_counter() - t1
         if not native:
             if rec.table:
@@ -557,7 +588,10 @@ def _finish(rec, i, paths, slots, stats=None):
             t_png = t2 - t1
             # the indicator must hold plain tensors as from `.cpu()`: one streaming copy each (numpy on purpose: a torch CPU op
             # here would wake an intra-op thread pool as wide as the host)
-            active, selected = torch.from_numpy(buf.out_active[i].numpy().copy()), torch.from_numpy(buf.out_selected[i].numpy().copy())
+            if rec.compose:
+                active, selected = (torch.from_numpy(x) for x in compose_indicators(ind_a, ind_s, table, rec.radius, cmr))
+            else:
+                active, selected = torch.from_numpy(ind_a.copy()), torch.from_numpy(ind_s.copy())
             t_copy = time.perf_counter() - t2
         out = (rec.picks[i], k)
     finally:
@@ -589,8 +623,56 @@ def _finish(rec, i, paths, slots, stats=None):
     return out
 
 
+def persist_image(path_mask, path_indicator, origin_mask, origin_label, prior_active, prior_selected, picks, k, active_radius, mask_radius):
+    """One image's two files (build.py:162-166) from HOST data and the first `k` rows of its pick table: the mask = origin_mask with
+    the labels of the picks' windows, the indicators = the maps the image entered the round with plus the picks' windows.  No GPU
+    involved: what RegionSelection's writer threads do in table staging, and what a global-budget round does once the pool-wide
+    keep-mask says how many of an image's picks were kept.  origin_* / prior_*: (H, W) torch tensors or numpy arrays."""
+    def np_(x):
+        return x.numpy() if torch.is_tensor(x) else np.asarray(x)
+    om, gt, pa, ps = np_(origin_mask), np_(origin_label), np_(prior_active), np_(prior_selected)
+    pk = np.ascontiguousarray(np_(picks)[:int(k)], dtype=np.float64).reshape(-1, 3)
+    retire = _native_retire() if str(path_mask).lower().endswith(".png") else None
+    ok = retire is not None and all(a.flags["C_CONTIGUOUS"] for a in (om, gt, pa, ps)) and om.dtype.kind in "iub" and gt.dtype.kind in "iub" \
+        and pa.itemsize == 1 and ps.itemsize == 1
+    if ok:
+        tpl = _IndicatorTemplate.get(om.shape)
+        if tpl.ok:
+            retire(path_mask, path_indicator, om, gt, pk if len(pk) else np.zeros((1, 3)), len(pk), active_radius, pa, ps, tpl,
+                   compose_mask_radius=mask_radius)
+            return
+    act, sel = compose_indicators(pa, ps, pk, active_radius, mask_radius)
+    _persist(compose_mask(om, gt, pk, active_radius), torch.from_numpy(act), torch.from_numpy(sel), path_mask, path_indicator)
+
+
+def persist_from_tables(cfg, loader, tables, counts, writer_threads=None):
+    """Write the round's files for every image of `loader` (in loader order) from pick tables: image j gets the windows of the first
+    counts[j] rows of tables[j] (rows (h, w, score), as RegionSelection(return_tables=True) / the all-gather deliver them).  Used by
+    the global-budget mode of halo_amd.pool.region_selection_sharded, where counts = the KEPT picks per image.  Host only."""
+    from concurrent.futures import ThreadPoolExecutor
+    if writer_threads is None:
+        from ..._host import host_threads_per_rank
+        writer_threads = host_threads_per_rank(cap=8)
+    radius, mask_radius = cfg.ACTIVE.RADIUS_K, cfg.ACTIVE.MASK_RADIUS_K
+    tables = tables.cpu().numpy() if torch.is_tensor(tables) else np.asarray(tables)
+    counts = [int(c) for c in (counts.cpu().tolist() if torch.is_tensor(counts) else counts)]
+    j, pending = 0, []
+    with ThreadPoolExecutor(max_workers=max(1, writer_threads)) as writers:
+        for batch in loader:
+            for i in range(len(batch["origin_mask"])):
+                pending.append(writers.submit(persist_image, batch["path_to_mask"][i], batch["path_to_indicator"][i], batch["origin_mask"][i],
+                                              batch["origin_label"][i], batch["active"][i], batch["selected"][i], tables[j], counts[j],
+                                              radius, mask_radius))
+                j += 1
+            while len(pending) > 4 * max(1, writer_threads):      # bound the loader items kept alive by queued work
+                pending.pop(0).result()
+        for f in pending:
+            f.result()
+    assert j == len(counts), "loader yielded %d images, %d tables given" % (j, len(counts))
+
+
 def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_number, *, in_flight=8, writer_threads=None,
-                    streams=4, return_tables=False, lowres_mode=None, stats=None, mask_staging=None):
+                    streams=4, return_tables=False, lowres_mode=None, stats=None, mask_staging=None, write_files=True):
     """Drop-in for build.py:71-186: same positional arguments, same files written (uint8 mode-L PNG mask
     at path_to_mask, torch.save({'active','selected'}) at path_to_indicator), models left in train mode,
     every file on disk when the call returns.  Returns None like the reference, or -- keyword-only
@@ -611,7 +693,9 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
     the exact order, the reference's files on every test vector -- but not the reference's evaluation order).
     `stats`: an optional dict that receives where the host time went (seconds per phase, main thread and writers);
     `mask_staging`: "table" (default; environment HALO_MASK_STAGING) or "device" -- whether the int64 mask / label maps travel to
-    the GPU at all (see _launch): same files either way."""
+    the GPU at all (see _launch): same files either way.
+    `write_files=False` (with return_tables): score and select only -- halo_amd.pool.region_selection_sharded's global-budget mode
+    writes the files afterwards from the KEPT picks (persist_from_tables)."""
     import queue
     import threading
     import time
@@ -669,7 +753,7 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
                     try:
                         rec = _launch(prm, logits_lr[lo:hi], embed_lr[lo:hi], sizes[lo], batch["origin_mask"][lo:hi],
                                       batch["origin_label"][lo:hi], batch["active"][lo:hi], batch["selected"][lo:hi], dev, slot,
-                                      lowres_mode, stats, mask_staging)
+                                      lowres_mode, stats, mask_staging, write_files)
                     except BaseException:
                         slots.put(slot)
                         raise

@@ -35,7 +35,7 @@ int halo_host_version(void) { return HALO_HOST_ABI_VERSION; }
  * goes through the carry-less-multiplication folding of Gopal et al., "Fast CRC Computation for Generic Polynomials Using
  * PCLMULQDQ" (64 bytes per iteration, ~10 bytes per cycle), which tests/test_abi.py checks against zlib on random lengths. ---- */
 static uint32_t crc_table[8][256];
-static int crc_ready = 0;
+static int crc_ready = 0;                           /* published with release / read with acquire: a writer thread that sees 1 sees the tables */
 static void crc_init(void)
 {
     for (uint32_t n = 0; n < 256; ++n) {
@@ -45,12 +45,12 @@ static void crc_init(void)
     }
     for (uint32_t n = 0; n < 256; ++n)
         for (int t = 1; t < 8; ++t) crc_table[t][n] = crc_table[0][crc_table[t - 1][n] & 0xffu] ^ (crc_table[t - 1][n] >> 8);
-    crc_ready = 1;
+    __atomic_store_n(&crc_ready, 1, __ATOMIC_RELEASE);
 }
 /* raw register update (no pre/post inversion) */
 static uint32_t crc_tables_raw(uint32_t crc, const uint8_t *p, size_t n)
 {
-    if (!crc_ready) crc_init();                     /* idempotent: a race between threads writes the same values */
+    if (!__atomic_load_n(&crc_ready, __ATOMIC_ACQUIRE)) crc_init();      /* idempotent: racing initialisers store the same values */
     while (n >= 8) {
         uint64_t v;
         memcpy(&v, p, 8);
@@ -194,7 +194,7 @@ static void huff_init(void)
         len_xbits[L] = (uint8_t)xb[k];
         len_xval[L] = (uint16_t)(L - base[k]);
     }
-    huff_ready = 1;
+    __atomic_store_n(&huff_ready, 1, __ATOMIC_RELEASE);
 }
 static inline void put_literal(bitw_t *w, unsigned v) { bw_put(w, lit_code[v], lit_len[v]); }
 static inline void put_match_d1(bitw_t *w, int L)              /* L bytes repeating the previous byte */
@@ -244,7 +244,7 @@ size_t halo_png_gray8_encode(const uint8_t *img, int64_t H, int64_t W, int64_t r
 {
     if (!img || !out || H <= 0 || W <= 0 || row_stride < W || H > 0x7fffffff || W > 0x7fffffff) return 0;
     if (cap < halo_png_gray8_bound(H, W)) return 0;
-    if (!huff_ready) huff_init();
+    if (!__atomic_load_n(&huff_ready, __ATOMIC_ACQUIRE)) huff_init();
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     uint8_t *p = out;
     memcpy(p, sig, 8); p += 8;
@@ -357,6 +357,31 @@ int halo_compose_mask(uint8_t *mask, const void *origin_mask, int mask_itemsize,
     return 0;
 }
 
+/* active / selected (H, W) bool bytes after a round, from the maps the image ENTERED the round with and the round's pick table
+ * (build.py:56-59: active[mask-radius window] = True, selected[radius window] = True around every pick; windows clipped at the
+ * borders): the device's results without copying them back.  Out-of-place; prior_* may equal the outputs. */
+int halo_compose_indicators(uint8_t *active, uint8_t *selected, const uint8_t *prior_active, const uint8_t *prior_selected, int64_t H,
+                            int64_t W, const double *picks, int64_t k, int64_t radius, int64_t mask_radius)
+{
+    if (!active || !selected || !prior_active || !prior_selected || H <= 0 || W <= 0 || k < 0 || radius < 0 || mask_radius < 0 ||
+        (k > 0 && !picks)) return -1;
+    const size_t n = (size_t)H * (size_t)W;
+    if (active != prior_active) memcpy(active, prior_active, n);
+    if (selected != prior_selected) memcpy(selected, prior_selected, n);
+    for (int64_t p = 0; p < k; ++p) {
+        const int64_t h = (int64_t)picks[3 * p], w = (int64_t)picks[3 * p + 1];
+        for (int which = 0; which < 2; ++which) {
+            const int64_t r = which ? radius : mask_radius;
+            uint8_t *dst = which ? selected : active;
+            const int64_t y0 = h - r < 0 ? 0 : h - r, y1 = h + r >= H ? H - 1 : h + r;
+            const int64_t x0 = w - r < 0 ? 0 : w - r, x1 = w + r >= W ? W - 1 : w + r;
+            if (x1 < x0) continue;
+            for (int64_t y = y0; y <= y1; ++y) memset(dst + y * W + x0, 1, (size_t)(x1 - x0 + 1));
+        }
+    }
+    return 0;
+}
+
 static int write_file(const char *path, const uint8_t *buf, size_t n)
 {
     FILE *f = fopen(path, "wb");
@@ -411,10 +436,22 @@ int halo_write_indicator(const char *path, const uint8_t *tpl, size_t tpl_len, c
  * 0 on success, -1 bad argument / out of memory, -2 I/O error on the mask, -3 I/O error on the indicator. */
 int halo_retire_image(const char *path_png, const char *path_indicator, const void *origin_mask, int mask_itemsize,
                       const void *origin_label, int label_itemsize, int64_t H, int64_t W, const double *picks, int64_t k, int64_t radius,
-                      const uint8_t *active, const uint8_t *selected, const uint8_t *tpl, size_t tpl_len, size_t off_a, size_t off_s,
-                      const uint64_t *crc_fields_a, const uint64_t *crc_fields_s)
+                      const uint8_t *active, const uint8_t *selected, int64_t compose_mask_radius, const uint8_t *tpl, size_t tpl_len,
+                      size_t off_a, size_t off_s, const uint64_t *crc_fields_a, const uint64_t *crc_fields_s)
 {
     if (!path_png || H <= 0 || W <= 0) return -1;
+    if (compose_mask_radius >= 0 && tpl && path_indicator) {
+        /* active / selected are the maps the image entered the round with: the round's windows are added here */
+        const size_t n2 = (size_t)H * (size_t)W;
+        uint8_t *ind = (uint8_t *)malloc(2 * n2);
+        if (!ind) return -1;
+        int rc2 = halo_compose_indicators(ind, ind + n2, active, selected, H, W, picks, k, radius, compose_mask_radius);
+        if (rc2 == 0)
+            rc2 = halo_retire_image(path_png, path_indicator, origin_mask, mask_itemsize, origin_label, label_itemsize, H, W, picks, k, radius,
+                                    ind, ind + n2, -1, tpl, tpl_len, off_a, off_s, crc_fields_a, crc_fields_s);
+        free(ind);
+        return rc2;
+    }
     const size_t n = (size_t)H * (size_t)W, cap = halo_png_gray8_bound(H, W);
     uint8_t *mask = (uint8_t *)malloc(n + cap);
     if (!mask) return -1;

@@ -434,7 +434,6 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     const unsigned long long *ckey = ws.ckey + (size_t)b * g.nfmax * BIN_CAP;
     const unsigned *cpos = ws.cpos + (size_t)b * g.nfmax * BIN_CAP;
     unsigned *plist = ws.plist + (size_t)b * g.n_regions;
-    const bool overflowed = (hdr->flags & SEL_F_OVERFLOW) != 0u;       // a fine bin ran out of slots: hand the image over untouched
 
     for (unsigned i = tid * 16; i < g.grid_bytes; i += SW_TPB * 16) *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
@@ -457,13 +456,16 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     struct Chunk { unsigned start[SW_MB], cnt[SW_MB], total; bool last, valid; };
     unsigned fw0 = 0, fwn = 0;                   // fwin holds the candidate counts of bins fw0 .. fw0 + fwn - 1
     unsigned it_f = 0;                           // next bin to look at
+    bool hit_full = false;                       // the iterator reached a bin that ran out of slots (a plateau of ties): the stream ends
+                                                 // in front of it -- everything above it is swept, the serial kernel continues from there
+                                                 // (round 4 handed such an image over untouched, wherever the full bin lay)
     auto next_chunk = [&]() {
         Chunk c;
 #pragma unroll
         for (int i = 0; i < SW_MB; ++i) { c.start[i] = 0; c.cnt[i] = 0; }
         c.total = 0; c.last = true; c.valid = false;
         int nb = 0;
-        while (it_f < nf) {
+        while (it_f < nf && !hit_full) {
             if (fwn == 0 || it_f >= fw0 + fwn) {             // stage the next window of bin counts (uniform: every thread gets here together)
                 lds_barrier();
                 fw0 = it_f;
@@ -471,9 +473,9 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
                 for (unsigned i = tid; i < fwn; i += SW_TPB) fwin[i] = fcnt[fw0 + i];
                 __syncthreads();
             }
-            unsigned n = fwin[it_f - fw0];
-            n = n < (unsigned)BIN_CAP ? n : (unsigned)BIN_CAP;
+            const unsigned n = fwin[it_f - fw0];
             if (n == 0) { ++it_f; continue; }
+            if (n > (unsigned)BIN_CAP) { hit_full = true; break; }
             if (nb == SW_MB || c.total + n > (unsigned)SW_TPB) break;        // this bin opens the next chunk
 #pragma unroll
             for (int i = 0; i < SW_MB; ++i)
@@ -565,7 +567,6 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
         ++nb;
 #endif
     };
-    if (overflowed) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; }
     Chunk c0 = next_chunk(), c1, c2;
     Regs d0, d1, d2;
     issue(c0, d0);
@@ -589,6 +590,7 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     }
 #endif
     if (tid == 0) {
+        if (fin == 0 && hit_full) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; }
         if (fin == 0) {                          // candidates exhausted: final unless the threshold bin was dropped
             fin = truncated ? 2 : 1;
             if (truncated) why = hdr->t1 >= (unsigned)NB1 ? HALO_SWEEP_BAD_VALUES : HALO_SWEEP_EXHAUSTED;

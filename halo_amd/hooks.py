@@ -13,7 +13,10 @@ The reference enters the round on rank 0 only while the other DDP ranks stall
 every rank scores its contiguous block of the pool (halo_amd.pool.region_selection_sharded), the
 pick tables are all-gathered, and all ranks leave together.  The checkpoint is still written by
 rank 0 only.  Bind it with `use_sharded_rounds(SourceFreeLearner)` (or assign the method on any
-learner class with the same attributes); nothing else in the learner changes.  No Lightning import
+learner class with the same attributes); nothing else in the learner changes.  Optional attributes
+of the learner: `acquisition_group` (process group), `acquisition_driver` (test stand-in) and
+`acquisition_global_budget` (None = reference behaviour; an integer G switches the round to the
+pool-wide budget of halo_amd.pool.region_selection_sharded).  No Lightning import
 is needed here: the method only touches attributes the reference's learner already has.
 """
 import os
@@ -31,7 +34,10 @@ def sharded_on_train_batch_start(self, batch, batch_idx):
         self.last_round_tables = region_selection_sharded(self.cfg, self.feature_extractor, self.classifier,
                                                           self.active_loader, self.active_round,
                                                           group=getattr(self, "acquisition_group", None),
-                                                          driver=getattr(self, "acquisition_driver", None))
+                                                          driver=getattr(self, "acquisition_driver", None),
+                                                          # None (default) = the reference's per-image budget; an integer G =
+                                                          # spend G regions over the whole pool this round (opt-in)
+                                                          global_budget=getattr(self, "acquisition_global_budget", None))
         if self.local_rank == 0:
             self.log("active_round", self.active_round, on_step=True, on_epoch=False)
         self.active_round += 1          # on every rank: all of them ran the round

@@ -12,8 +12,11 @@ float64 score as two words, then the pick count -- 12 bytes per pick, 28 KB per 
 Shard sizes follow from (n_images, world) alone (`shard_range`), so no size exchange and no host
 synchronisation is needed: every rank pads its block to ceil(N / world) rows.
 
-With `global_budget=None` (default, = reference behaviour) the result does not depend on the
-world size.
+With `global_budget=None` (default, = reference behaviour: build.py:148-150 budgets per image) the
+result does not depend on the world size.  `global_budget=G` (north_star's "global budget
+selection"; NOT reference behaviour, opt-in) spends G regions over the whole pool: every image
+still proposes its n_regions greedy picks, the gathered tables are re-ranked pool-wide, and each
+image's files are written from the KEPT prefix of its table -- also independent of the world size.
 """
 import math
 import os
@@ -185,16 +188,29 @@ def assert_distinct_devices(device_index, group=None):
 
 def global_budget_select(tables, counts, total_regions):
     """OPTIONAL, not reference behaviour: re-rank the gathered picks pool-wide and keep the best
-    `total_regions` (ties: lower image index, then earlier pick).  Returns a bool mask (images, n).
-    The reference spends exactly n_regions per image; keep this off to match it."""
+    `total_regions` (ties: lower image index, then earlier pick; NaN scores rank first, as in the
+    selector).  Returns a bool mask (images, n).  An image's greedy picks are non-increasing in
+    score, so what is kept of an image is a PREFIX of its table: its files are the state of the
+    reference's loop after that many iterations (kept_counts).  The reference spends exactly
+    n_regions per image; keep this off to match it."""
     I, n, _ = tables.shape
     valid = torch.arange(n, device=tables.device)[None, :] < counts[:, None].to(torch.int64)
     score = torch.where(valid, tables[:, :, 2], torch.full_like(tables[:, :, 2], -float("inf")))
+    score = torch.where(torch.isnan(score), torch.full_like(score, float("inf")), score)      # the selector's order: NaN above everything
     order = torch.argsort(score.reshape(-1), descending=True, stable=True)
     keep = torch.zeros(I * n, dtype=torch.bool, device=tables.device)
     k = torch.clamp(valid.sum(), max=int(total_regions))
     keep[order] = torch.arange(I * n, device=tables.device) < k
     return keep.reshape(I, n) & valid
+
+
+def kept_counts(keep):
+    """picks kept per image under a global budget; the kept picks of an image are the first k of its table"""
+    k = keep.sum(dim=1).to(torch.int32)
+    n = keep.shape[1]
+    prefix = torch.arange(n, device=keep.device)[None, :] < k[:, None].to(torch.int64)
+    assert bool((prefix == keep).all()), "global-budget keep-mask is not a prefix of every image's table"
+    return k
 
 
 def acquire_pool(images, acquire_fn, n_regions, group=None, global_budget=None):
@@ -216,7 +232,7 @@ def acquire_pool(images, acquire_fn, n_regions, group=None, global_budget=None):
 
 
 def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_loader, round_number, group=None,
-                             loader_kwargs=None, global_budget=None, driver=None, n_regions=None):
+                             loader_kwargs=None, global_budget=None, driver=None, n_regions=None, writer_threads=None):
     """RegionSelection (build.py:71-186) with the pool sharded over the ranks of `group`.
 
     Each rank runs the drop-in driver on its block of the dataset and writes its own mask /
@@ -225,7 +241,14 @@ def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_load
     every rank knows that all files are on disk (it replaces the reference's "ranks != 0 stall in
     the next DDP all-reduce", train_learners.py:308).  Returns a dict: `range` (this rank's block),
     `tables` (N, n, 3), `counts` (N,), `owner` (N,) for the whole pool on every rank, `keep` (the
-    optional global-budget mask, None by default = reference behaviour).
+    optional global-budget mask, None by default = reference behaviour), `kept` (picks kept per
+    image, None by default).
+
+    `global_budget=G` (opt-in; NOT reference behaviour, which budgets per image: build.py:148-150):
+    the ranks score and select WITHOUT writing (`driver(..., write_files=False)`), exchange the
+    tables, rank all proposed picks pool-wide (global_budget_select) and then every rank writes its
+    block's files from the kept prefix of each table in a second, model-free pass over its loader
+    (core.active.build.persist_from_tables).  Files and tables are independent of the world size.
 
     `driver(cfg, feature_extractor, classifier, loader, round_number) -> [(picks (n,3), count)]` per
     image defaults to the HIP RegionSelection; the CPU tests inject a stand-in.  `n_regions` = the
@@ -242,9 +265,11 @@ def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_load
     if driver is None:
         from .core.active.build import RegionSelection
 
-        def driver(*a):
-            return RegionSelection(*a, return_tables=True)
-    per_image = driver(cfg, feature_extractor, classifier, loader, round_number)      # pipelined, async writers
+        def driver(*a, **kw):
+            return RegionSelection(*a, return_tables=True, **kw)
+    defer = global_budget is not None
+    # pipelined, async writers; under a global budget the files wait for the pool-wide keep-mask
+    per_image = driver(cfg, feature_extractor, classifier, loader, round_number, **({"write_files": False} if defer else {}))
     assert len(per_image) == hi - lo
     n = max([p.shape[0] for p, _ in per_image], default=0) if n_regions is None else int(n_regions)
     if world > 1 and n_regions is None:     # images may differ in size: agree on the widest table
@@ -253,13 +278,23 @@ def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_load
         n = int(nt.item())
     dev = _comm_device(per_image)
     picks = torch.zeros((hi - lo, max(n, 1), 3), dtype=torch.float64, device=dev)
-    npk = torch.zeros((hi - lo,), dtype=torch.int32, device=dev)
-    for j, (p, k) in enumerate(per_image):
-        picks[j, :p.shape[0]] = p.to(dev)
-        npk[j] = int(k)
+    if per_image and all(p.shape[0] == n for p, _ in per_image):
+        picks = torch.stack([p for p, _ in per_image]).to(dev)        # one copy for the block (round 4: one per image)
+    else:
+        for j, (p, k) in enumerate(per_image):
+            picks[j, :p.shape[0]] = p.to(dev)
+    # the counts are host integers already (the writer threads read them from pinned memory): no per-image device sync
+    npk = torch.tensor([int(k) for _, k in per_image], dtype=torch.int32).to(dev)
     tables, counts, owner = gather_tables(picks, npk, n_images, group)
-    keep = global_budget_select(tables, counts, global_budget) if global_budget is not None else None
-    return {"range": (lo, hi), "tables": tables, "counts": counts, "owner": owner, "keep": keep}
+    keep = kept = None
+    if defer:
+        keep = global_budget_select(tables, counts, global_budget)
+        kept = kept_counts(keep)
+        from .core.active.build import persist_from_tables
+        persist_from_tables(cfg, loader, tables[lo:hi], kept[lo:hi], writer_threads=writer_threads)
+        if world > 1:
+            dist.barrier(group=group)                                    # every rank's files are on disk when anyone returns
+    return {"range": (lo, hi), "tables": tables, "counts": counts, "owner": owner, "keep": keep, "kept": kept}
 
 
 def _comm_device(per_image):

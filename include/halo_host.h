@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HALO_HOST_ABI_VERSION 2
+#define HALO_HOST_ABI_VERSION 3
 int halo_host_version(void);
 
 /* ---- 8-bit greyscale PNG (build.py:162-164).  What must be identical to PIL's file is the DECODED image: filter type 0 on every
@@ -51,12 +51,20 @@ int halo_compose_mask(uint8_t *mask, const void *origin_mask, int mask_itemsize,
 int halo_write_indicator(const char *path, const uint8_t *tpl, size_t tpl_len, const uint8_t *active, const uint8_t *selected, size_t n,
                          size_t off_a, size_t off_s, const uint64_t *crc_fields_a, const uint64_t *crc_fields_s);
 
+/* ---- the round's indicator maps from the maps an image ENTERED the round with and its pick table (build.py:56-59:
+ * active[h-R:h+R+1, w-R:w+R+1] = True with R = mask_radius, selected[...] = True with R = radius, around every pick; slices
+ * clipped at the borders): what the selection kernel leaves on the device, recomputed on the host so that the 2 x H x W bytes need
+ * not be copied back, and the files of a GLOBAL-budget round, written from the kept prefix of each table. */
+int halo_compose_indicators(uint8_t *active, uint8_t *selected, const uint8_t *prior_active, const uint8_t *prior_selected, int64_t H,
+                            int64_t W, const double *picks, int64_t k, int64_t radius, int64_t mask_radius);
+
 /* ---- both files of one image in one call: halo_compose_mask -> halo_png_gray8_encode -> write, then halo_write_indicator
- * (skipped when tpl is NULL). */
+ * (skipped when tpl is NULL).  compose_mask_radius < 0: `active` / `selected` are the round's RESULTS (copied back from the device);
+ * >= 0: they are the maps the image entered the round with and halo_compose_indicators (that mask radius) runs first. */
 int halo_retire_image(const char *path_png, const char *path_indicator, const void *origin_mask, int mask_itemsize,
                       const void *origin_label, int label_itemsize, int64_t H, int64_t W, const double *picks, int64_t k, int64_t radius,
-                      const uint8_t *active, const uint8_t *selected, const uint8_t *tpl, size_t tpl_len, size_t off_a, size_t off_s,
-                      const uint64_t *crc_fields_a, const uint64_t *crc_fields_s);
+                      const uint8_t *active, const uint8_t *selected, int64_t compose_mask_radius, const uint8_t *tpl, size_t tpl_len,
+                      size_t off_a, size_t off_s, const uint64_t *crc_fields_a, const uint64_t *crc_fields_s);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import numpy as np
 
 NB1 = 2048
 SW_SURV = 256
-BIN_CAP = 128     # slots per fine bin (k_sel_place): a fuller bin hands the image over untouched
+BIN_CAP = 128     # slots per fine bin (k_sel_place): the sweep stops IN FRONT of a fuller bin and hands the image over from there
 
 
 def order_key(v):
@@ -75,9 +75,7 @@ def binned_select(score, n_regions, mrad, target=64, captot=None):
     kk = key[cand]
     pos = (xs.astype(np.int64) << 16) | ys
     stats["ncand"] = int(cand.sum())
-    if len(f) and np.bincount(f).max() > BIN_CAP:
-        stats["reason"] = "overflow"
-        return "bail", [], stats
+    full = set(np.nonzero(np.bincount(f) > BIN_CAP)[0].tolist()) if len(f) else set()
     order = np.argsort(f, kind="stable")
     f, kk, pos, ys, xs = f[order], kk[order], pos[order], ys[order], xs[order]
     # sweep
@@ -90,6 +88,9 @@ def binned_select(score, n_regions, mrad, target=64, captot=None):
         e = i
         while e < N and f[e] == f[i]:
             e += 1
+        if int(f[i]) in full:                        # a bin that ran out of slots: everything above it is done, the rest is handed over
+            stats["reason"] = "overflow"
+            return "bail", picks, stats
         stats["bins"] += 1
         surv = []
         for q in range(i, e):

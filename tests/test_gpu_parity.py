@@ -2142,6 +2142,28 @@ for i, (mask, act, sel, picks) in enumerate(want):
     assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
     k = int(res["counts"][i])
     assert k == len(picks) and np.array_equal(res["tables"][i, :k].cpu().numpy().view(np.int64), np.ascontiguousarray(picks).view(np.int64)), i
+# the opt-in pool-wide budget with the real driver: score + select without writing, ONE all-gather, files from the kept prefixes
+import copy
+for f in os.listdir(root):
+    if f.endswith((".png", ".pth")):
+        os.remove(os.path.join(root, f))
+G = 8
+resg = region_selection_sharded(_cfg(), Tap(), head, DS(), 1, loader_kwargs=dict(pin_memory=False), global_budget=G)
+kept = resg["kept"].cpu().numpy()
+assert int(kept.sum()) == G and torch.equal(resg["tables"], res["tables"]) and kept.max() > kept.min()
+for i, it in enumerate(pool.items):
+    H, W = it["origin_label"].shape
+    cfg_i = copy.deepcopy(_cfg())
+    cfg_i.ACTIVE.SELECT_ITER = [0]
+    cfg_i.ACTIVE.BUDGET = max(0.0, (int(kept[i]) - 0.5) * 9.0 / (H * W))
+    (mask, act, sel, picks), = ho.region_selection(cfg_i, [dict(logit_lr=it["logit_lr"][None].numpy(), embed_lr=it["embed_lr"][None].numpy(),
+                                                                 origin_label=it["origin_label"].numpy(), origin_mask=it["origin_mask"].numpy(),
+                                                                 active=it["active"].numpy(), selected=it["selected"].numpy())],
+                                                   lowres_mode=lowres_mode(None))
+    assert len(picks) == kept[i], i
+    assert np.array_equal(np.array(Image.open(os.path.join(root, "m%d.png" % i))), mask), i
+    ind = torch.load(os.path.join(root, "i%d.pth" % i))
+    assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
 dist.destroy_process_group()
 print("sharded ok")
 '''
@@ -2399,3 +2421,50 @@ def test_headline_launch_shape_lowres_sources_batched_vs_oracle(dev):
         _, _, _, _, pk_o = ho.select_pixels_to_label(so, n, 1, mrad, a_o, s_o, m_o, gt[b].cpu().numpy(), True)
         assert int(npk[b]) == n == len(pk_o) and bits_equal(picks[b].cpu().numpy(), pk_o), b
         assert np.array_equal(act[b].cpu().numpy(), a_o) and np.array_equal(am[b].cpu().numpy(), m_o), b
+
+
+def test_sweep_hand_over_counters(dev):
+    """halo_greedy_select_ex's cost counters: which images the value-binned sweep finished, which it handed to the serial kernel,
+    why, and after how many of its own picks -- with the picks identical to the oracle's either way.  A plateau of exact ties
+    BELOW the values the picks need no longer hands the image over (round 4: any full bin did, from pick 0)."""
+    from halo_amd import _lib
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(21)
+    H, W, n, mrad = 256, 512, 150, 5
+    smooth = ho.bilinear(rng.standard_normal((1, H // 4, W // 4)), (H, W))[0] + 1e-4 * rng.standard_normal((H, W))
+    floor, cap = np.quantile(smooth, 0.5), np.quantile(smooth, 0.997)
+    low = smooth.copy(); low[low < floor] = floor                                   # half the map one value, never reached
+    mid = smooth.copy(); mid[(mid > floor) & (mid < cap)] = 0.5 * (floor + cap)      # a plateau the picks must cross
+    nan = smooth.copy(); nan[5, 7] = np.nan
+    const = np.full((H, W), 0.25)
+    maps = [smooth, low, mid, nan, const]
+    B = len(maps)
+    s0 = np.ascontiguousarray(np.stack(maps))
+    gt = rng.integers(0, 19, (B, H, W)).astype(np.int64)
+    want_reason = ["done", "done", "bin_overflow", "bad_values", "bad_values"]
+    for method in ("auto", "serial"):
+        s = t(s0, dev).clone()
+        act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+        ho_t = torch.full((B, 2), -7, dtype=torch.int32, device=dev)
+        picks, npk = greedy_select(s, n, 1, mrad, act, sel, am, t(gt, dev), method=method, handover=ho_t)
+        hv = ho_t.cpu().numpy()
+        for b in range(B):
+            so = s0[b].copy()
+            a_o = np.zeros((H, W), bool); s_o = np.zeros((H, W), bool); m_o = np.full((H, W), 255, np.int64)
+            _, _, _, _, po = ho.select_pixels_to_label(so, n, 1, mrad, a_o, s_o, m_o, gt[b], True)
+            k = int(npk[b])
+            assert k == len(po) and bits_equal(picks[b, :k].cpu().numpy(), po), (method, b)
+            assert np.array_equal(act[b].cpu().numpy(), a_o) and np.array_equal(am[b].cpu().numpy(), m_o), (method, b)
+            reason = _lib.SWEEP_REASONS[int(hv[b, 0])]
+            if method == "serial":
+                assert reason == "not_run" and hv[b, 1] == 0, b
+            else:
+                assert reason == want_reason[b], (b, reason, hv[b])
+                if reason == "done":
+                    assert hv[b, 1] == k
+                if reason == "bin_overflow":
+                    assert 0 < hv[b, 1] < k, hv[b]          # everything above the plateau came from the sweep
+                if reason == "bad_values":
+                    assert hv[b, 1] == 0

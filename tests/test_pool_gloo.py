@@ -215,9 +215,9 @@ def _cfg():
                                      BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
 
 
-def _oracle_driver(cfg, feature_extractor, classifier, loader, round_number):
+def _oracle_driver(cfg, feature_extractor, classifier, loader, round_number, write_files=True):
     """Stand-in for the HIP RegionSelection with the same contract (files written through the product's own
-    _persist; per-image pick tables returned): the CPU oracle does the arithmetic."""
+    _persist unless write_files=False; per-image pick tables returned): the CPU oracle does the arithmetic."""
     from halo_amd.core.active.build import _persist
     from oracle import halo_oracle as ho
     tables = []
@@ -226,7 +226,8 @@ def _oracle_driver(cfg, feature_extractor, classifier, loader, round_number):
                   origin_label=batch["origin_label"][0].numpy(), origin_mask=batch["origin_mask"][0].numpy(),
                   active=batch["active"][0].numpy(), selected=batch["selected"][0].numpy())
         (mask, act, sel, picks), = ho.region_selection(cfg, [im])
-        _persist(mask, torch.from_numpy(act), torch.from_numpy(sel), batch["path_to_mask"][0], batch["path_to_indicator"][0])
+        if write_files:
+            _persist(mask, torch.from_numpy(act), torch.from_numpy(sel), batch["path_to_mask"][0], batch["path_to_indicator"][0])
         tables.append((torch.from_numpy(np.ascontiguousarray(picks)).reshape(-1, 3), len(picks)))
     return tables
 
@@ -279,6 +280,92 @@ def test_region_selection_sharded_ranks_write_the_single_process_files(tmp_path,
     assert int(ref["counts"].min()) > 0
 
 
+def _budget_worker(rank, world, port, n_images, root, budget):
+    import sys
+    torch.set_num_threads(1)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from halo_amd.pool import region_selection_sharded
+    res = region_selection_sharded(_cfg(), None, None, _Pool(root, n_images), 1, driver=_oracle_driver,
+                                   loader_kwargs=dict(pin_memory=False), global_budget=budget, writer_threads=2)
+    np.savez(os.path.join(root, f"rank{rank}.npz"), kept=res["kept"].numpy(), keep=res["keep"].numpy(), tables=res["tables"].numpy())
+    dist.destroy_process_group()
+
+
+def test_global_budget_round_writes_the_kept_picks_files_at_any_world_size(tmp_path):
+    """The opt-in pool-wide budget (north_star's "global budget selection"; NOT reference behaviour, which budgets per image:
+    build.py:148-150): every image proposes its n_regions greedy picks, the best G of the pool are kept, and each image's files
+    are what the reference's loop leaves after as many iterations as picks of that image were kept -- checked against the ORACLE
+    run with exactly that many regions -- identically at world 1, 2 and 8 (uneven and empty blocks)."""
+    import copy
+    from PIL import Image
+    from halo_amd.pool import region_selection_sharded
+    from oracle import halo_oracle as ho
+    n_images, budget = 5, 8
+    dirs = {w: tmp_path / ("w%d" % w) for w in (1, 2, 8)}
+    for d in dirs.values():
+        d.mkdir()
+    one = region_selection_sharded(_cfg(), None, None, _Pool(str(dirs[1]), n_images), 1, driver=_oracle_driver,
+                                   loader_kwargs=dict(pin_memory=False), global_budget=budget, writer_threads=2)
+    kept = one["kept"].numpy()
+    assert int(kept.sum()) == budget == int(one["keep"].sum()) and kept.max() > kept.min()       # the images do NOT get equal shares
+    # the kept picks are the pool's top scores
+    sc = one["tables"].numpy()[:, :, 2]
+    valid = np.arange(sc.shape[1])[None, :] < one["counts"].numpy()[:, None]
+    assert sc[one["keep"].numpy()].min() >= np.sort(sc[valid])[-budget]
+    pool = _Pool(str(tmp_path), n_images)
+    for i in range(n_images):
+        it = pool[i]
+        H, W = it["origin_label"].shape
+        cfg_i = copy.deepcopy(_cfg())
+        cfg_i.ACTIVE.SELECT_ITER = [0]
+        cfg_i.ACTIVE.BUDGET = max(0.0, (int(kept[i]) - 0.5) * 9.0 / (H * W))                      # ceil(H W budget / 9) == kept[i]
+        im = dict(logit_lr=it["logit_lr"][None].numpy(), embed_lr=it["embed_lr"][None].numpy(), origin_label=it["origin_label"].numpy(),
+                  origin_mask=it["origin_mask"].numpy(), active=it["active"].numpy(), selected=it["selected"].numpy())
+        (mask, act, sel, picks), = ho.region_selection(cfg_i, [im])
+        assert len(picks) == kept[i], i
+        assert np.array_equal(np.array(Image.open(dirs[1] / f"m{i}.png")), mask), i
+        ind = torch.load(dirs[1] / f"i{i}.pth")
+        assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), i
+        assert ind["active"].dtype == torch.bool and Image.open(dirs[1] / f"m{i}.png").mode == "L"
+    for world in (2, 8):
+        mp.spawn(_budget_worker, args=(world, _free_port(), n_images, str(dirs[world]), budget), nprocs=world, join=True)
+        for r in range(world):
+            got = np.load(dirs[world] / ("rank%d.npz" % r))
+            assert np.array_equal(got["kept"], kept) and np.array_equal(got["keep"], one["keep"].numpy())
+            assert np.array_equal(got["tables"].view(np.int64), one["tables"].numpy().view(np.int64))
+        for i in range(n_images):
+            assert (dirs[world] / f"m{i}.png").read_bytes() == (dirs[1] / f"m{i}.png").read_bytes(), (world, i)
+            a, b = torch.load(dirs[world] / f"i{i}.pth"), torch.load(dirs[1] / f"i{i}.pth")
+            assert torch.equal(a["active"], b["active"]) and torch.equal(a["selected"], b["selected"]), (world, i)
+
+
+def test_host_composition_of_the_indicator_maps_native_and_numpy():
+    """halo_compose_indicators (libhalo_host.so) == its numpy statement == the oracle's select loop on the windows: clipped at the
+    borders, prior maps kept, k = 0 leaves them unchanged."""
+    from halo_amd import _hostlib
+    from halo_amd.core.active.build import compose_indicators
+    rng = np.random.default_rng(8)
+    H, W = 37, 53
+    pa, ps = rng.random((H, W)) < 0.1, rng.random((H, W)) < 0.05
+    picks = np.stack([rng.integers(0, H, 40), rng.integers(0, W, 40), rng.standard_normal(40)], 1).astype(np.float64)
+    picks[0, :2] = (0, 0); picks[1, :2] = (H - 1, W - 1); picks[2, :2] = (0, W - 1)
+    for k in (0, 1, 40):
+        for r, mr in ((1, 5), (2, 3), (0, 0)):
+            a_np, s_np = compose_indicators(pa, ps, picks[:k], r, mr)
+            a_c, s_c = _hostlib.compose_indicators(pa, ps, picks, k, r, mr)
+            assert np.array_equal(a_np, a_c) and np.array_equal(s_np, s_c), (k, r, mr)
+            ea, es = pa.copy(), ps.copy()
+            for h, w in picks[:k, :2].astype(int):
+                ea[max(h - mr, 0):h + mr + 1, max(w - mr, 0):w + mr + 1] = True
+                es[max(h - r, 0):h + r + 1, max(w - r, 0):w + r + 1] = True
+            assert np.array_equal(a_np, ea) and np.array_equal(s_np, es)
+
+
 class _FakeLearner:
     """The attributes SourceFreeLearner.on_train_batch_start touches (core/train_learners.py:307-326)."""
 
@@ -307,6 +394,13 @@ def test_sharded_hook_replaces_the_rank0_gate(tmp_path):
     assert ln.active_round == 1 and ln.saved == [os.path.join(str(tmp_path), "model_before_round_0.ckpt")]
     assert ln.logged and ln.last_round_tables["tables"].shape[0] == 3
     assert all(os.path.exists(tmp_path / f"m{i}.png") and os.path.exists(tmp_path / f"i{i}.pth") for i in range(3))
+    assert ln.last_round_tables["keep"] is None and ln.last_round_tables["kept"] is None          # the default: the reference's per-image budget
     ln.debug = True
     ln.on_train_batch_start("batch", 0)
     assert ln.active_round == 1
+    # the opt-in switch of the hook: a pool-wide budget for the round
+    ln.debug = False
+    ln.acquisition_global_budget = 7
+    ln.active_iters = [9]
+    ln.on_train_batch_start("batch", 9)
+    assert int(ln.last_round_tables["kept"].sum()) == 7 and ln.active_round == 2

@@ -84,3 +84,24 @@ def test_degenerate_maps_bail_or_finish_correctly():
             assert status == "bail" and st["reason"] == "range" and not picks, kind
         if kind == "exhaust":
             assert status == "done" and len(picks) == len(want) < n, kind
+
+
+def test_a_full_bin_only_matters_when_the_sweep_reaches_it():
+    """A plateau of exact ties overfills its fine bin.  Below the values the n picks need it is never visited (round 4 handed the
+    whole image over untouched as soon as ANY bin from the threshold bin up was full); in the middle of them the sweep keeps every
+    pick above the plateau and hands over from there."""
+    rng = np.random.default_rng(11)
+    H, W, mrad = 96, 160, 3
+    sc = _smooth(rng, H, W, np.float64) + 1e-3 * rng.standard_normal((H, W))
+    floor = np.quantile(sc, 0.45)
+    low = sc.copy(); low[low < floor] = floor                 # 45 % of the map is one value, at the BOTTOM of the candidates
+    n = 12
+    want = _oracle(low, n, mrad)
+    status, picks, st = binned_select(low, n, mrad, captot=H * W)      # the plateau's bin is inside the threshold bin's range
+    assert status == "done" and picks == want, st
+    cap = np.quantile(sc, 0.97)
+    mid = sc.copy(); mid[(mid > floor) & (mid < cap)] = 0.5 * (floor + cap)      # a plateau the picks must cross
+    n = 120
+    want = _oracle(mid, n, mrad)
+    status, picks, st = binned_select(mid, n, mrad, captot=H * W)
+    assert status == "bail" and st["reason"] == "overflow" and 0 < len(picks) < n and picks == want[:len(picks)], (status, st, len(picks))
