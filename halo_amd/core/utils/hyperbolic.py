@@ -348,21 +348,22 @@ class HyperMetrics(object):
         self.mapper = HyperMapper(c=self.c)
 
     def compute(self, x, y):
+        """x, y (N, d) on a ROCm device -> dict of the six metrics of hyperbolic.py:202-228: mse and cosine distance of the
+        Euclidean vectors; after the exponential map, the two Euclidean radii, the angle between the points' directions in degrees
+        and their Poincare distance."""
         _lib.require_device(x, y)
-        metrics = {}
-        metrics['mse'] = torch.nn.functional.mse_loss(x, y)
-        metrics['cosine_dist'] = self.mapper.cosine_distance(x, y)
-        x_h = self.mapper.expmap(x)
-        y_h = self.mapper.expmap(y)
-        radius_x = torch.linalg.norm(x_h, dim=-1)
-        radius_y = torch.linalg.norm(y_h, dim=-1)
-        metrics['radius_x'] = radius_x
-        metrics['radius_y'] = radius_y
-        x_norm_e = x_h / radius_x.reshape(-1, 1)
-        y_norm_e = y_h / radius_y.reshape(-1, 1)
-        metrics['ang_e'] = torch.acos((x_norm_e * y_norm_e).sum(dim=-1)) * 180 / math.pi
-        metrics['poincare_dist'] = self.mapper.poincare_distance(x_h, y_h)
-        return metrics
+        on_ball = [self.mapper.expmap(v) for v in (x, y)]                          # HIP: halo_expmap0_project
+        radii = [torch.linalg.norm(p, dim=-1) for p in on_ball]
+        directions = [p / r.unsqueeze(-1) for p, r in zip(on_ball, radii)]
+        cosine = (directions[0] * directions[1]).sum(dim=-1)
+        return {
+            "mse": torch.nn.functional.mse_loss(x, y),
+            "cosine_dist": self.mapper.cosine_distance(x, y),
+            "radius_x": radii[0],
+            "radius_y": radii[1],
+            "ang_e": torch.acos(cosine) * 180 / math.pi,
+            "poincare_dist": self.mapper.poincare_distance(*on_ball),              # HIP: halo_pdist
+        }
 
 
 def bilinear_align_corners(x, size):

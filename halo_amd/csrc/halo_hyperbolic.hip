@@ -238,27 +238,43 @@ __global__ void __launch_bounds__(HTPB) k_pdist(const double *__restrict__ x, co
 // ---------------------------------------------------------------- HyperMLR  (hyperbolic.py:120-184)
 // prep: per class  pp = ||P||^2 (as sqrt then square), anorm = ||A||, An = A / max(anorm,1e-12), pa = <-P, An>
 // consts layout: [O] pp | [O] anorm | [O] pa | [O*C] An | [O*C] negP
+// One wave per class (round 5; rounds 1-4 ran one LANE per class: 19 lanes walking 2 x C uncoalesced doubles each in three
+// dependent passes took 78 us at C = 256 -- as long as the contraction it prepares at the head's own shape).  The rows of P and A
+// are staged in LDS with coalesced loads, lane 0 runs the three fma chains IN CHANNEL ORDER from there (the same sums as before,
+// bit for bit), the element-wise parts (A / ||A||, -P) are spread over the lanes.
 __global__ void __launch_bounds__(64) k_mlr_prep(const double *__restrict__ P, const double *__restrict__ A, int O, int C,
                                                  double *__restrict__ consts)
 {
-    const int o = blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+    double *sP = reinterpret_cast<double *>(smem_p), *sA = sP + C;     // P row | A row, then A^ row in place of A
+    __shared__ double s_dn;
+    const int o = blockIdx.x, lane = threadIdx.x;
     if (o >= O) return;
-    double sp = 0, sa = 0;
-    for (int j = 0; j < C; ++j) { sp = __builtin_fma(P[o * C + j], P[o * C + j], sp); sa = __builtin_fma(A[o * C + j], A[o * C + j], sa); }
-    const double np_ = __builtin_sqrt(sp);
-    const double an = __builtin_sqrt(sa);
-    const double dn = an < 1e-12 ? 1e-12 : an;
-    double *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
-    double s = 0;
-    for (int j = 0; j < C; ++j) {
-        const double v = A[o * C + j] / dn;
-        An[o * C + j] = v;
-        nP[o * C + j] = -P[o * C + j];
-        s = __builtin_fma(-P[o * C + j], v, s);
+    for (int j = lane; j < C; j += 64) { sP[j] = P[(size_t)o * C + j]; sA[j] = A[(size_t)o * C + j]; }
+    __syncthreads();
+    if (lane == 0) {
+        double sp = 0, sa = 0;
+        for (int j = 0; j < C; ++j) { sp = __builtin_fma(sP[j], sP[j], sp); sa = __builtin_fma(sA[j], sA[j], sa); }
+        const double np_ = __builtin_sqrt(sp), an = __builtin_sqrt(sa);
+        consts[o] = np_ * np_;
+        consts[O + o] = an;
+        s_dn = an < 1e-12 ? 1e-12 : an;
     }
-    consts[o] = np_ * np_;
-    consts[O + o] = an;
-    consts[2 * O + o] = s;
+    __syncthreads();
+    const double dn = s_dn;
+    double *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    for (int j = lane; j < C; j += 64) {
+        const double v = sA[j] / dn;
+        sA[j] = v;
+        An[(size_t)o * C + j] = v;
+        nP[(size_t)o * C + j] = -sP[j];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double s_ = 0;
+        for (int j = 0; j < C; ++j) s_ = __builtin_fma(-sP[j], sA[j], s_);
+        consts[2 * O + o] = s_;
+    }
 }
 
 __device__ __forceinline__ double clamp_min_nanprop(double v, double lo) { return (v != v) ? v : (v < lo ? lo : v); }
@@ -927,7 +943,8 @@ extern "C" int halo_hypermlr_logits(const double *x, const double *P, const doub
     if (!workspace || workspace_bytes < halo_hypermlr_workspace_bytes(O, C)) return fail(HALO_E_WORKSPACE, "halo_hypermlr_logits: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     double *consts = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)cdiv(O, 64)), dim3(64), 0, st, P, A, (int)O, (int)C, consts);
+    if (C > 3968) return fail(HALO_E_UNSUPPORTED, "HyperMLR: more than 3968 channels (the class rows are staged in 64 KiB of LDS)");
+    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)O), dim3(64), (size_t)2 * C * sizeof(double), st, P, A, (int)O, (int)C, consts);
     // matrix-core path: up to 32 classes (two 16-column tiles per operand); anything else takes the VALU kernel
     if (out_dtype != HALO_F32 && out_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_hypermlr_logits: bad out dtype");
     // weights-resident matrix-core kernel when the [-P | A^] image plus the per-wave staging fits LDS
@@ -1159,7 +1176,9 @@ static void launch_bilinear_rows(const void *src, void *dst, int64_t planes, int
     // keeps the one-row kernel (A/B switch, same bits)
     const int64_t srows = (int64_t)((double)sh * (double)(BL_RO - 1)) + 3;
     const size_t lds_r = (size_t)BL_PCR * srows * span * sizeof(T);
-    if (srows <= BL_SR && lds_r <= 48 * 1024 && cdiv(H, BL_RO) <= 65535 && !getenv("HALO_BILINEAR_ROWS") &&
+    // (float32 with 4 pixels per lane stays on the one-row kernel: on the four-row kernel it needs 178 registers -- two blocks per CU --
+    // and measured no faster at the v2 head's 640x1280 -> 1024x2048, 0.066 against 0.069 ms, and slower at x4: 0.044 against 0.039)
+    if (!(sizeof(T) == 4 && VEC == 4) && srows <= BL_SR && lds_r <= 48 * 1024 && cdiv(H, BL_RO) <= 65535 && !getenv("HALO_BILINEAR_ROWS") &&
         !getenv("HALO_BILINEAR_LDS1")) {
         const unsigned gyr = (unsigned)cdiv(H, BL_RO);
         int64_t gzl = cdiv(8192, (int64_t)gx * gyr);
@@ -1236,7 +1255,8 @@ extern "C" int halo_hypermlr_bwd_terms(const double *x, const double *P, const d
     if (!workspace || workspace_bytes < halo_hypermlr_workspace_bytes(O, C)) return fail(HALO_E_WORKSPACE, "halo_hypermlr_bwd_terms: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     double *consts = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)cdiv(O, 64)), dim3(64), 0, st, P, A, (int)O, (int)C, consts);
+    if (C > 3968) return fail(HALO_E_UNSUPPORTED, "HyperMLR: more than 3968 channels (the class rows are staged in 64 KiB of LDS)");
+    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)O), dim3(64), (size_t)2 * C * sizeof(double), st, P, A, (int)O, (int)C, consts);
     dim3 grid(nblocks(hw), (unsigned)B);
     hipLaunchKernelGGL((k_hypermlr_bwd_terms<10>), grid, dim3(HTPB), 0, st, x, (const double *)consts, gout, (int)O, (int)C, (long long)hw, c, dpx, dxa, dxx, dpp, dpa, dan);
     return check_launch("halo_hypermlr_bwd_terms");

@@ -942,7 +942,10 @@ __global__ void __launch_bounds__(TPB) k_combine(const TI *__restrict__ imp_raw,
 // writes: lo = 0, scale = NB1 -- exactly what k_sel_hist1 would count from the stored map (same coarse_bin, same exclusions).
 constexpr int CB_ROWS = 16;        // at most; fewer when the launch would otherwise not fill the chip (one image at a time)
 
-template <typename TI>
+// NTS: the impurity / uncertainty maps are stored non-temporally (nothing on the device reads them again) and the raw impurity is
+// loaded non-temporally (read exactly once); the score map -- the selector's input -- and the entropy rows (shared with the
+// neighbouring workgroups) keep the default policy.
+template <typename TI, bool NTS>
 __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp_raw, const float *__restrict__ ent,
                                                       const double *__restrict__ stats, const unsigned char *__restrict__ active,
                                                       int H, int W, int pk, int normalize, TI *__restrict__ score,
@@ -1026,11 +1029,22 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
         if (!live) continue;
         const size_t o = (size_t)b * hw + (size_t)y * W + x;
         TI im[4];
+        typedef double cb_d2 __attribute__((ext_vector_type(2)));
+        typedef float cb_f4 __attribute__((ext_vector_type(4)));
         if constexpr (sizeof(TI) == 8) {
-            const double2 q0 = *reinterpret_cast<const double2 *>(imp_raw + o), q1 = *reinterpret_cast<const double2 *>(imp_raw + o + 2);
+            cb_d2 q0, q1;
+            if constexpr (NTS) {
+                q0 = __builtin_nontemporal_load(reinterpret_cast<const cb_d2 *>(imp_raw + o));
+                q1 = __builtin_nontemporal_load(reinterpret_cast<const cb_d2 *>(imp_raw + o + 2));
+            } else {
+                q0 = *reinterpret_cast<const cb_d2 *>(imp_raw + o);
+                q1 = *reinterpret_cast<const cb_d2 *>(imp_raw + o + 2);
+            }
             im[0] = q0.x; im[1] = q0.y; im[2] = q1.x; im[3] = q1.y;
         } else {
-            const float4 q = *reinterpret_cast<const float4 *>(imp_raw + o);
+            cb_f4 q;
+            if constexpr (NTS) q = __builtin_nontemporal_load(reinterpret_cast<const cb_f4 *>(imp_raw + o));
+            else q = *reinterpret_cast<const cb_f4 *>(imp_raw + o);
             im[0] = q.x; im[1] = q.y; im[2] = q.z; im[3] = q.w;
         }
         if (normalize) {
@@ -1062,14 +1076,25 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
             *reinterpret_cast<double2 *>(score + o) = make_double2(sc[0], sc[1]);
             *reinterpret_cast<double2 *>(score + o + 2) = make_double2(sc[2], sc[3]);
             if (imp_out) {
-                *reinterpret_cast<double2 *>(imp_out + o) = make_double2(im[0], im[1]);
-                *reinterpret_cast<double2 *>(imp_out + o + 2) = make_double2(im[2], im[3]);
+                if constexpr (NTS) {
+                    __builtin_nontemporal_store((cb_d2){im[0], im[1]}, reinterpret_cast<cb_d2 *>(imp_out + o));
+                    __builtin_nontemporal_store((cb_d2){im[2], im[3]}, reinterpret_cast<cb_d2 *>(imp_out + o + 2));
+                } else {
+                    *reinterpret_cast<double2 *>(imp_out + o) = make_double2(im[0], im[1]);
+                    *reinterpret_cast<double2 *>(imp_out + o + 2) = make_double2(im[2], im[3]);
+                }
             }
         } else {
             *reinterpret_cast<float4 *>(score + o) = make_float4(sc[0], sc[1], sc[2], sc[3]);
-            if (imp_out) *reinterpret_cast<float4 *>(imp_out + o) = make_float4(im[0], im[1], im[2], im[3]);
+            if (imp_out) {
+                if constexpr (NTS) __builtin_nontemporal_store((cb_f4){im[0], im[1], im[2], im[3]}, reinterpret_cast<cb_f4 *>(imp_out + o));
+                else *reinterpret_cast<float4 *>(imp_out + o) = make_float4(im[0], im[1], im[2], im[3]);
+            }
         }
-        if (unc_out) *reinterpret_cast<float4 *>(unc_out + o) = make_float4(un[0], un[1], un[2], un[3]);
+        if (unc_out) {
+            if constexpr (NTS) __builtin_nontemporal_store((cb_f4){un[0], un[1], un[2], un[3]}, reinterpret_cast<cb_f4 *>(unc_out + o));
+            else *reinterpret_cast<float4 *>(unc_out + o) = make_float4(un[0], un[1], un[2], un[3]);
+        }
     }
     if (count) {
         __syncthreads();
@@ -2501,8 +2526,11 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
         int crows = CB_ROWS;                 // rows per workgroup: as many as leave >= 1024 workgroups in the launch
         while (crows > 1 && cdiv(W, TPB * 4) * cdiv(H, crows) * B < 1024) crows >>= 1;
         dim3 gridc((unsigned)cdiv(W, TPB * 4), (unsigned)cdiv(H, crows), (unsigned)B);
-        if (f64out) hipLaunchKernelGGL((k_combine_box3<double>), gridc, block, 0, st, (const double *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (double *)score, (double *)impurity, uncertainty, rng_free, rng_hist, crows);
-        else hipLaunchKernelGGL((k_combine_box3<float>), gridc, block, 0, st, (const float *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (float *)score, (float *)impurity, uncertainty, rng_free, rng_hist, crows);
+        static const bool cb_nt = !getenv("HALO_COMBINE_NO_NT");      // A/B switch (same bits)
+#define HALO_CB(T, NT_) hipLaunchKernelGGL((k_combine_box3<T, NT_>), gridc, block, 0, st, (const T *)imp_raw, (const float *)ent, stats, active, (int)H, (int)W, hist ? pksize : 0, normalize, (T *)score, (T *)impurity, uncertainty, rng_free, rng_hist, crows)
+        if (f64out) { if (cb_nt) HALO_CB(double, true); else HALO_CB(double, false); }
+        else { if (cb_nt) HALO_CB(float, true); else HALO_CB(float, false); }
+#undef HALO_CB
     } else if (f64out) hipLaunchKernelGGL((k_combine<double>), grid1, block, 0, st, (const double *)imp_raw, unc_raw, stats, active, hw, normalize, (double *)score, (double *)impurity, uncertainty);
     else hipLaunchKernelGGL((k_combine<float>), grid1, block, 0, st, (const float *)imp_raw, unc_raw, stats, active, hw, normalize, (float *)score, (float *)impurity, uncertainty);
     if (score_range && !rng_free) {
