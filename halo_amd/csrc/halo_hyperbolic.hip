@@ -172,6 +172,85 @@ __global__ void __launch_bounds__(HTPB, 4) k_expmap0_project_tile(const float *_
     }
 }
 
+// ---------------------------------------------------------------- expmap0 + project, register-resident (C <= CC)
+// The head's own channel count is small (MODEL.HYPER_DIM = 64, defaults.py:14): a lane can hold ALL channels of its two pixels in
+// registers (CC float2 values).  So: every plane load of the lane is issued up front (CC 8-byte non-temporal loads in flight, 512
+// contiguous bytes per wave and plane), the norm's fma chain runs over registers in channel order, and the lane writes its CC
+// 16-byte non-temporal stores -- x is read once, no LDS tile, no barrier, no lane idles while one lane per pixel runs the chain
+// (k_expmap0_project_tile above: 0.32-0.35 of the HBM spec at 160x320x64, 0.59-0.63 at 640x1280x64).  Same operations in the same
+// order per pixel as the two kernels above (sequential fma chain, v = g * (x / n) through the division sequence's own
+// refinement, the projection only where it can act): bit-identical results.
+template <int CC, bool EXACT>       // EXACT: C == CC, no per-channel test -- NOT instantiated: as one basic block the compiler schedules it into 255 registers + scratch
+__global__ void __launch_bounds__(64, CC > 32 ? 3 : 4) k_expmap0_project_regs(const float *__restrict__ x, double *__restrict__ y, long long outer, int Crt,
+                                                             long long inner, double ks, double rks, double maxnorm)
+{
+    const int C = EXACT ? CC : Crt;
+    // grid (pixel pairs, outer): the plane bases are block-uniform (scalar registers), a lane's offset inside a plane is ONE 32-bit
+    // register for all CC loads and stores (per-lane 64-bit pointers cost 2 x CC registers: 255 allocated, two waves per SIMD)
+    const unsigned i0 = (blockIdx.x * 64u + threadIdx.x) * 2u;
+    if ((long long)i0 >= inner) return;
+    const float *xp = x + (size_t)blockIdx.y * C * inner;
+    double *yp = y + (size_t)blockIdx.y * C * inner;
+    f2_t v[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        v[c] = (f2_t){0.f, 0.f};
+        if (c < C) v[c] = __builtin_nontemporal_load(reinterpret_cast<const f2_t *>(xp + (size_t)c * inner + i0));
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < CC; ++c)
+        if (c < C) {
+            const double a = (double)v[c].x, b = (double)v[c].y;
+            s0 = __builtin_fma(a, a, s0); s1 = __builtin_fma(b, b, s1);
+            if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    // keep the channels as the float32 values they are: without this the compiler holds their float64 conversions (made for the
+    // chain above) across to the write phase -- 2 x 2 x CC registers, 255 allocated at CC = 64
+#pragma unroll
+    for (int c = 0; c < CC; ++c) asm volatile("" : "+v"(v[c]));
+    double n[2] = {__builtin_sqrt(s0), __builtin_sqrt(s1)}, g[2], pr[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        n[k] = n[k] < 1e-15 ? 1e-15 : n[k];
+        double a = n[k] * ks;
+        a = a > 15.0 ? 15.0 : (a < -15.0 ? -15.0 : a);
+        g[k] = rks * tanh(a);
+        pr[k] = 0.0;
+        if (g[k] >= maxnorm * (1.0 - 1e-9)) {                   // rare: only here can project() act
+            double s2 = 0.0;
+#pragma unroll 1
+            for (int c = 0; c < C; ++c) {                      // rare: re-read the pixel's channels (no indexed access into v, and no
+                const double w = g[k] * ((double)xp[(size_t)c * inner + i0 + k] / n[k]);       // 2 x CC unrolled divisions kept live)
+                s2 = __builtin_fma(w, w, s2);
+            }
+            double ny = __builtin_sqrt(s2);
+            ny = ny < 1e-15 ? 1e-15 : ny;
+            pr[k] = ny > maxnorm ? ny : 0.0;
+        }
+    }
+    const double r0 = exact_rcp(n[0]), r1 = exact_rcp(n[1]);
+    if (!__any(pr[0] != 0.0 || pr[1] != 0.0)) {                 // (wave-uniform) nothing to project: the common case, from registers
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            if (c < C) {
+                const double w0 = g[0] * div_by(v[c].x, n[0], r0), w1 = g[1] * div_by(v[c].y, n[1], r1);
+                __builtin_nontemporal_store((d2_h){w0, w1}, reinterpret_cast<d2_h *>(yp + (size_t)c * inner + i0));
+                if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four channels' conversions live at a time, not CC
+            }
+        }
+    } else {                                                    // a projected pixel in the wave: rolled loop, channels re-read
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            const f2_t xv = *reinterpret_cast<const f2_t *>(xp + (size_t)c * inner + i0);
+            double w0 = g[0] * div_by(xv.x, n[0], r0), w1 = g[1] * div_by(xv.y, n[1], r1);
+            if (pr[0] != 0.0) w0 = w0 / pr[0] * maxnorm;
+            if (pr[1] != 0.0) w1 = w1 / pr[1] * maxnorm;
+            __builtin_nontemporal_store((d2_h){w0, w1}, reinterpret_cast<d2_h *>(yp + (size_t)c * inner + i0));
+        }
+    }
+}
+
 // ---------------------------------------------------------------- logmap0 + project  (hyperbolic.py:60)
 __global__ void __launch_bounds__(HTPB) k_logmap0_project(const double *__restrict__ x, double *__restrict__ y, long long outer,
                                                           int C, long long inner, double ks, double rks, double maxnorm)
@@ -481,6 +560,13 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr_mfma(const double *__restrict
 // Row stride of the weight image = C + pad doubles with (C + pad) mod 32 == 2: the 16 x 4 (row, channel) operand
 // fetch of a wave is then conflict-free on the 64 LDS banks.
 constexpr int MLRP_TPB = 512, MLRP_SK = 4, MLRP_RING = 4;
+#ifdef HALO_MLR_IEEE            // variant build for A/B (HALO_LIB_PATH): the round-4 epilogue, IEEE divisions
+#define MLR_RCP(x) (1.0 / (x))
+#define MLR_ASINH(x) asinh_det(x)
+#else
+#define MLR_RCP(x) fast_rcp(x)
+#define MLR_ASINH(x) asinh_fast(x)
+#endif
 
 template <typename TOUT, int NT>
 __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__restrict__ x, const double *__restrict__ consts,
@@ -611,26 +697,45 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
         const double Kxx = K * xx, KxxK = Kxx * K;
         const long long p_ = p_base + q;
         TOUT *outp = out + (size_t)b * O * hw + p_;
+        // EPI_IL classes per trip, evaluated side by side: one evaluation is a chain of ~150 DEPENDENT float64 instructions
+        // (reciprocal -> alpha, beta -> mob -> sqrt -> ... -> the log's Horner chain) and only two waves share a SIMD -- at the head's
+        // C = 64 the kernel ran at a third of the epilogue's issue bound.  A lane past its last class re-evaluates a valid one and
+        // does not store.
+        constexpr int EPI_IL = 2;
 #pragma unroll 1
-        for (int o = lane >> 5; o < O; o += 2) {
-            const int sl = o * 32 + ((q + o) & 31);
-            const double px = pxs[sl], xa = xas[sl];
-            const double ppo = pp[o], ano = anorm[o], pao = pa[o];
-            const double sqsq = KxxK * ppo;
-            const double base = 1.0 + (2.0 * K) * px;
-            const double Aa = base + Kxx;
-            const double Bb = 1.0 - K * ppo;
-            const double rD = 1.0 / clamp_min_nanprop(base + sqsq, 1e-12);   // one reciprocal for alpha and beta
-            const double al = Aa * rD, be = Bb * rD;
-            const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
-            const double sq = __builtin_sqrt(mob);
-            double pn = 1.0;
-            if (__any(sq > maxnorm)) pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;   // rare: beyond the ball
-            const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
-            const double md = (be * xa + al * pao) * pn;
-            const double lamb = 2.0 / clamp_min_nanprop(1.0 - K * mp, 1e-12);
-            const double sine = (sqK * md) * lamb;
-            if (p_ < hw) outp[(size_t)o * hw] = (TOUT)(((2.0 / sqK) * ano) * asinh_det(sine));
+        for (int o0 = lane >> 5; o0 < O; o0 += 2 * EPI_IL) {
+            int oc[EPI_IL];
+            double px[EPI_IL], xa[EPI_IL], ppo[EPI_IL], al[EPI_IL], be[EPI_IL], mob[EPI_IL], sq[EPI_IL];
+            bool beyond = false;
+#pragma unroll
+            for (int u = 0; u < EPI_IL; ++u) {
+                oc[u] = o0 + 2 * u < O ? o0 + 2 * u : o0;
+                const int sl = oc[u] * 32 + ((q + oc[u]) & 31);
+                px[u] = pxs[sl]; xa[u] = xas[sl];
+                ppo[u] = pp[oc[u]];
+                const double sqsq = KxxK * ppo[u];
+                const double base = 1.0 + (2.0 * K) * px[u];
+                const double Aa = base + Kxx;
+                const double Bb = 1.0 - K * ppo[u];
+                // (quotients through fast_rcp, halo_devmath.hpp: no bit-level contract on the logits; HALO_MLR_IEEE builds keep the IEEE forms)
+                const double rD = MLR_RCP(clamp_min_nanprop(base + sqsq, 1e-12));   // one reciprocal for alpha and beta
+                al[u] = Aa * rD; be[u] = Bb * rD;
+                mob[u] = ((al[u] * al[u]) * ppo[u] + (be[u] * be[u]) * xx) + ((2.0 * al[u]) * be[u]) * px[u];
+                sq[u] = __builtin_sqrt(mob[u]);
+                beyond = beyond || sq[u] > maxnorm;
+            }
+            const bool any_beyond = __any(beyond);                            // rare: a point beyond the ball somewhere in the wave
+#pragma unroll
+            for (int u = 0; u < EPI_IL; ++u) {
+                double pn = 1.0;
+                if (any_beyond) pn = sq[u] > maxnorm ? maxnorm / clamp_min_nanprop(sq[u], 1e-12) : 1.0;
+                const double mp = sq[u] < maxnorm ? mob[u] : maxnorm * maxnorm;
+                const double md = (be[u] * xa[u] + al[u] * pa[oc[u]]) * pn;
+                const double lamb = 2.0 * MLR_RCP(clamp_min_nanprop(1.0 - K * mp, 1e-12));
+                const double sine = (sqK * md) * lamb;
+                const double res = ((2.0 / sqK) * anorm[oc[u]]) * MLR_ASINH(sine);
+                if (p_ < hw && (u == 0 || o0 + 2 * u < O)) outp[(size_t)oc[u] * hw] = (TOUT)res;
+            }
         }
         __builtin_amdgcn_wave_barrier();      // the next tile's accumulators reuse the staging rows
         cur = nxt;
@@ -874,7 +979,18 @@ extern "C" int halo_expmap0_project(const void *x, int x_dtype, double *y, int64
         lds = ((size_t)C << pshift) * 4 + 3 * ((size_t)8 << pshift);
         if (lds > 96 * 1024) pshift = 0;
     }
-    if (pshift) {
+    // the head's channel counts (<= 64): every channel of a lane's pixel pair lives in registers -- no tile (HALO_EXPMAP_NOREGS=1:
+    // A/B switch, the LDS-tile kernel; same bits)
+    if (x_dtype == HALO_F32 && C <= 64 && inner % 2 == 0 && inner < (1ll << 31) && outer <= 65535 && ((uintptr_t)x % 8) == 0 &&
+        ((uintptr_t)y % 16) == 0 && !getenv("HALO_EXPMAP_NOREGS") && !getenv("HALO_EXPMAP_PLANES")) {
+        const dim3 gr((unsigned)cdiv(inner / 2, 64), (unsigned)outer);
+#define HALO_EXPR(CC_, EX_) hipLaunchKernelGGL((k_expmap0_project_regs<CC_, EX_>), gr, dim3(64), 0, st, (const float *)x, y, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm)
+        if (C <= 16) HALO_EXPR(16, false);
+        else if (C <= 32) HALO_EXPR(32, false);
+        else HALO_EXPR(64, false);
+#undef HALO_EXPR
+    }
+    else if (pshift) {
         static LdsLimitSeen seen;
         if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_expmap0_project_tile, 96 * 1024))
             return fail(HALO_E_LAUNCH, "halo_expmap0_project: cannot raise the dynamic LDS limit");
@@ -1036,7 +1152,13 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
             const int row = wave + 4 * rr, pl = row >> 1;
             if (p0 + pl < planes) {
                 const T *sp = src + ((size_t)(p0 + pl) * h + ((row & 1) ? y1 : y0)) * w + sx0;
-                for (int col = lane; col < ncol; col += 64) tile[row * span + col] = sp[col];
+                for (int c0 = lane; c0 < ncol; c0 += 64 * 8) {               // all loads of the segment first (see k_bilinear_lds_rows)
+                    T reg[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int col = c0 + 64 * u; reg[u] = sp[col < ncol ? col : ncol - 1]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int col = c0 + 64 * u; if (col < ncol) tile[row * span + col] = reg[u]; }
+                }
             }
         }
         __syncthreads();
@@ -1120,13 +1242,23 @@ __global__ void __launch_bounds__(HTPB, (sizeof(T) == 4 && VEC == 4) ? 2 : 4) k_
     const int plane_lds = nsr * span;
     for (int p0 = blockIdx.z * BL_PCR; p0 < planes; p0 += gridDim.z * BL_PCR) {
         __syncthreads();                                           // the previous chunk's taps have been read
-        // wave wv stages the (plane, source row) pairs wv, wv + 4, ...: one coalesced row segment each
+        // wave wv stages the (plane, source row) pairs wv, wv + 4, ...: one coalesced row segment each.  All loads of a pair are
+        // issued before its first LDS store (BL_ST in flight per lane; a segment of up to 64 * BL_ST columns): with one load per trip
+        // the staging was a chain of ~20 dependent round trips per chunk at the v2 head's x1.6 geometry (324-column segments, 16
+        // pairs), and the kernel ran at 0.43 of the HBM spec where the x4 geometry -- 9 trips -- reached 0.70
+        constexpr int BL_ST = 8;
         for (int pr = tid >> 6, pl = 0, rr = tid >> 6; pr < BL_PCR * nsr; pr += HTPB / 64, rr += HTPB / 64) {
             while (rr >= nsr) { rr -= nsr; ++pl; }
             if (p0 + pl < planes) {
                 const T *sp = src + ((size_t)(p0 + pl) * h + sy0 + rr) * w + sx0;
                 T *tq = tile + pl * plane_lds + rr * span;
-                for (int col = tid & 63; col < ncol; col += 64) tq[col] = sp[col];
+                for (int c0 = tid & 63; c0 < ncol; c0 += 64 * BL_ST) {
+                    T reg[BL_ST];
+#pragma unroll
+                    for (int u = 0; u < BL_ST; ++u) { const int col = c0 + 64 * u; reg[u] = sp[col < ncol ? col : ncol - 1]; }
+#pragma unroll
+                    for (int u = 0; u < BL_ST; ++u) { const int col = c0 + 64 * u; if (col < ncol) tq[col] = reg[u]; }
+                }
             }
         }
         __syncthreads();
@@ -1190,7 +1322,11 @@ static void launch_bilinear_rows(const void *src, void *dst, int64_t planes, int
         return;
     }
     const size_t lds = (size_t)BL_PC * 2 * span * sizeof(T);
-    if (lds <= 32 * 1024 && !getenv("HALO_BILINEAR_ROWS")) {      // A/B switch: taps gathered from global memory
+    // float32 planes magnified >= 3x: the taps of a row come from a few hundred bytes that stay in the vector cache -- gathering them
+    // from global memory measured FASTER than staging them (19 planes: 256x512 -> 1024x2048 29.9 against 35.2 us, 160x320 -> 640x1280
+    // 16.9 against 21.0; at x1.6 the staged kernel wins, 66 against 73).  HALO_BILINEAR_NOGATHER=1: A/B switch
+    const bool gather = sizeof(T) == 4 && (double)sw <= 1.0 / 3.0 && (double)sh <= 1.0 / 3.0 && !getenv("HALO_BILINEAR_NOGATHER");
+    if (lds <= 32 * 1024 && !getenv("HALO_BILINEAR_ROWS") && !gather) {      // A/B switch: taps gathered from global memory
         int64_t gzl = cdiv(8192, (int64_t)gx * H);
         const int64_t chunks = cdiv(planes, BL_PC);
         gzl = gzl < 1 ? 1 : (gzl > chunks ? chunks : gzl);
