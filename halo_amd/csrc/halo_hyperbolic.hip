@@ -697,45 +697,29 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
         const double Kxx = K * xx, KxxK = Kxx * K;
         const long long p_ = p_base + q;
         TOUT *outp = out + (size_t)b * O * hw + p_;
-        // EPI_IL classes per trip, evaluated side by side: one evaluation is a chain of ~150 DEPENDENT float64 instructions
-        // (reciprocal -> alpha, beta -> mob -> sqrt -> ... -> the log's Horner chain) and only two waves share a SIMD -- at the head's
-        // C = 64 the kernel ran at a third of the epilogue's issue bound.  A lane past its last class re-evaluates a valid one and
-        // does not store.
-        constexpr int EPI_IL = 2;
+        // (two classes per trip, evaluated side by side so that two dependent chains interleave, measured SLOWER: 256 against 238 us at
+        // the v2 head's shape, 1.63 against 1.53 ms at 1024x2048x256 -- gpurun_out/r05h)
 #pragma unroll 1
-        for (int o0 = lane >> 5; o0 < O; o0 += 2 * EPI_IL) {
-            int oc[EPI_IL];
-            double px[EPI_IL], xa[EPI_IL], ppo[EPI_IL], al[EPI_IL], be[EPI_IL], mob[EPI_IL], sq[EPI_IL];
-            bool beyond = false;
-#pragma unroll
-            for (int u = 0; u < EPI_IL; ++u) {
-                oc[u] = o0 + 2 * u < O ? o0 + 2 * u : o0;
-                const int sl = oc[u] * 32 + ((q + oc[u]) & 31);
-                px[u] = pxs[sl]; xa[u] = xas[sl];
-                ppo[u] = pp[oc[u]];
-                const double sqsq = KxxK * ppo[u];
-                const double base = 1.0 + (2.0 * K) * px[u];
-                const double Aa = base + Kxx;
-                const double Bb = 1.0 - K * ppo[u];
-                // (quotients through fast_rcp, halo_devmath.hpp: no bit-level contract on the logits; HALO_MLR_IEEE builds keep the IEEE forms)
-                const double rD = MLR_RCP(clamp_min_nanprop(base + sqsq, 1e-12));   // one reciprocal for alpha and beta
-                al[u] = Aa * rD; be[u] = Bb * rD;
-                mob[u] = ((al[u] * al[u]) * ppo[u] + (be[u] * be[u]) * xx) + ((2.0 * al[u]) * be[u]) * px[u];
-                sq[u] = __builtin_sqrt(mob[u]);
-                beyond = beyond || sq[u] > maxnorm;
-            }
-            const bool any_beyond = __any(beyond);                            // rare: a point beyond the ball somewhere in the wave
-#pragma unroll
-            for (int u = 0; u < EPI_IL; ++u) {
-                double pn = 1.0;
-                if (any_beyond) pn = sq[u] > maxnorm ? maxnorm / clamp_min_nanprop(sq[u], 1e-12) : 1.0;
-                const double mp = sq[u] < maxnorm ? mob[u] : maxnorm * maxnorm;
-                const double md = (be[u] * xa[u] + al[u] * pa[oc[u]]) * pn;
-                const double lamb = 2.0 * MLR_RCP(clamp_min_nanprop(1.0 - K * mp, 1e-12));
-                const double sine = (sqK * md) * lamb;
-                const double res = ((2.0 / sqK) * anorm[oc[u]]) * MLR_ASINH(sine);
-                if (p_ < hw && (u == 0 || o0 + 2 * u < O)) outp[(size_t)oc[u] * hw] = (TOUT)res;
-            }
+        for (int o = lane >> 5; o < O; o += 2) {
+            const int sl = o * 32 + ((q + o) & 31);
+            const double px = pxs[sl], xa = xas[sl];
+            const double ppo = pp[o], ano = anorm[o], pao = pa[o];
+            const double sqsq = KxxK * ppo;
+            const double base = 1.0 + (2.0 * K) * px;
+            const double Aa = base + Kxx;
+            const double Bb = 1.0 - K * ppo;
+            // (quotients through fast_rcp, halo_devmath.hpp: no bit-level contract on the logits; HALO_MLR_IEEE builds keep the IEEE forms)
+            const double rD = MLR_RCP(clamp_min_nanprop(base + sqsq, 1e-12));   // one reciprocal for alpha and beta
+            const double al = Aa * rD, be = Bb * rD;
+            const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
+            const double sq = __builtin_sqrt(mob);
+            double pn = 1.0;
+            if (__any(sq > maxnorm)) pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;   // rare: beyond the ball
+            const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
+            const double md = (be * xa + al * pao) * pn;
+            const double lamb = 2.0 * MLR_RCP(clamp_min_nanprop(1.0 - K * mp, 1e-12));
+            const double sine = (sqK * md) * lamb;
+            if (p_ < hw) outp[(size_t)o * hw] = (TOUT)(((2.0 / sqK) * ano) * MLR_ASINH(sine));
         }
         __builtin_amdgcn_wave_barrier();      // the next tile's accumulators reuse the staging rows
         cur = nxt;
