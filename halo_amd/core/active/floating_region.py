@@ -21,8 +21,35 @@ from ..utils.hyperbolic import HyperMapper
 _WS = {}
 
 
+import threading as _threading
+
+_ws_tls = _threading.local()
+
+
+class private_workspaces(object):
+    """While active (on this thread), every scratch request is served by a FRESH allocation that is appended to `.held` instead of
+    coming from the per-stream cache: a launch group recorded into a HIP graph must own the scratch it points to -- the cache
+    re-allocates a stream's buffer when a later, larger call needs more (and release_workspaces() drops it), which would leave the
+    recording with a dangling pointer (round 5: a memory access fault after a batch-4 group had grown the stream's workspace)."""
+
+    def __enter__(self):
+        self.held = []
+        self._prev = getattr(_ws_tls, "held", None)
+        _ws_tls.held = self.held
+        return self
+
+    def __exit__(self, *exc):
+        _ws_tls.held = self._prev
+        return False
+
+
 def _workspace(dev, nbytes, tag):
     """Stream-ordered scratch, cached per (device, stream, tag) and grown on demand."""
+    held = getattr(_ws_tls, "held", None)
+    if held is not None:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        held.append(buf)
+        return buf
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -388,13 +388,15 @@ extern "C" int halo_greedy_select_ex(void *score, int dtype, int64_t B, int64_t 
     // ---- serial tile-table kernel: the whole job, or only the images the sweep handed over
     const size_t lds = align_up((size_t)g.nt * 12, 16) + 2 * (SEL_TPB_MAIN / 64) * 12 + 64;
     // behind the sweep: a few workgroups walk the images (see the kernel), skipping the finished ones; HALO_SEL_RESUME_WGS
-    // overrides (tuning aid).  Eight: the 256-thread, 96-VGPR resume kernel fits beside the streaming kernel on any CU, so
-    // they are placed at once, and a degenerate round in which the sweep hands over EVERY image (NaN / +inf / constant maps,
-    // plateaus of ties) is continued eight images at a time instead of two.
+    // overrides (tuning aid).  The 256-thread, 96-VGPR resume kernel fits beside the streaming kernel on any CU, so its workgroups
+    // are placed at once, and a degenerate round in which the sweep hands over EVERY image (NaN / +inf / constant maps,
+    // plateaus of ties) is continued for all images at once.
     unsigned nwg = (unsigned)B;
     if (resume) {
         static const int wgs_env = [] { const char *e = getenv("HALO_SEL_RESUME_WGS"); return e ? atoi(e) : 0; }();
-        const unsigned want = wgs_env > 0 ? (unsigned)wgs_env : 8u;
+        // (round 5: one workgroup per image up to 64 -- they return at once for finished images, and a batch in which the sweep hands
+        // over EVERY image, bench.py --data plateau, took two rounds of eight: 39 ms per 16-image step)
+        const unsigned want = wgs_env > 0 ? (unsigned)wgs_env : 64u;
         nwg = want < (unsigned)B ? want : (unsigned)B;
     }
     dim3 grid(nwg);

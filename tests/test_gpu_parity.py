@@ -2468,3 +2468,66 @@ def test_sweep_hand_over_counters(dev):
                     assert 0 < hv[b, 1] < k, hv[b]          # everything above the plateau came from the sweep
                 if reason == "bad_values":
                     assert hv[b, 1] == 0
+
+
+def test_region_selection_replayed_launch_groups_survive_workspace_growth(dev):
+    """RegionSelection replays a (slot, shape)'s launch group from a HIP graph from its third use on.  The recording must own what it
+    points to: here a pool of ONE label size runs three rounds through one slot (eager, eager + record, replay), then a batch-3 round of
+    a LARGER size grows the stream's cached scratch buffers (round 5: the recording kept the old pointer -- a memory access fault),
+    the workspaces are dropped altogether, and the first pool runs again through the replayed group.  Every round's files equal the
+    oracle's; HALO_RS_GRAPH=0 gives the same files eagerly."""
+    import halo_amd
+    from PIL import Image
+    from halo_amd.core.active.build import RegionSelection
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(131)
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+    tmp = tempfile.mkdtemp(prefix="halo_rs_graph_")
+
+    def pool(n, H, W, tag, nb=1):
+        items, outs, oin = [], [], []
+        for i in range(n):
+            emb_lr = ho.expmap((rng.standard_normal((1, 8, H // 4, W // 4)) * 0.2).astype(np.float32), 1.0, dim=1)
+            logit_lr = rng.standard_normal((1, 19, H // 2, W // 2)).astype(np.float32)
+            gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+            act = rng.random((H, W)) < 0.02
+            items.append({"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [os.path.join(tmp, f"{tag}_m{i}.png")],
+                          "origin_mask": torch.full((1, H, W), 255, dtype=torch.int64), "origin_label": torch.from_numpy(gt)[None],
+                          "size": torch.tensor([[H, W]]), "active": torch.from_numpy(act)[None], "selected": torch.zeros(1, H, W, dtype=torch.bool),
+                          "path_to_indicator": [os.path.join(tmp, f"{tag}_i{i}.pth")], "name": [f"{tag}{i}"]})
+            outs.append((t(logit_lr, dev), t(emb_lr, dev)))
+            oin.append(dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act, selected=np.zeros((H, W), bool),
+                            origin_mask=np.full((H, W), 255, np.int64)))
+        if nb > 1:        # the same pool through a loader of batch size nb
+            bat = []
+            for k in range(0, n, nb):
+                grp = items[k:k + nb]
+                bat.append({key: (torch.cat([g_[key] for g_ in grp]) if torch.is_tensor(grp[0][key]) else sum((g_[key] for g_ in grp), []))
+                            for key in grp[0]})
+            outs = [(torch.cat([outs[k + j][0] for j in range(nb)]), torch.cat([outs[k + j][1] for j in range(nb)])) for k in range(0, n, nb)]
+            items = bat
+        return items, outs, oin
+
+    def check(tag, oin):
+        want = ho.region_selection(cfg, oin, lowres_mode=_lr_mode())
+        for i, (mask, act, sel, _) in enumerate(want):
+            assert np.array_equal(np.array(Image.open(os.path.join(tmp, f"{tag}_m{i}.png")), dtype=np.uint8), mask), (tag, i)
+            ind = torch.load(os.path.join(tmp, f"{tag}_i{i}.pth"))
+            assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), (tag, i)
+            os.remove(os.path.join(tmp, f"{tag}_m{i}.png")); os.remove(os.path.join(tmp, f"{tag}_i{i}.pth"))
+
+    small = pool(5, 48, 96, "s")
+    for rnd in range(3):                                              # five images through one slot: eager, record, replay x 3 -- three times
+        RegionSelection(cfg, _Fake(), _Fake(small[1]), small[0], 1, in_flight=1, writer_threads=2)
+        check("s", small[2])
+    big = pool(6, 96, 160, "b", nb=3)                                 # larger maps, three per launch group: the cached scratch grows
+    RegionSelection(cfg, _Fake(), _Fake(big[1]), big[0], 1, in_flight=1, writer_threads=2)
+    check("b", big[2])
+    halo_amd.release_workspaces()                                     # ... and is dropped
+    RegionSelection(cfg, _Fake(), _Fake(small[1]), small[0], 1, in_flight=1, writer_threads=2)
+    check("s", small[2])
+    _with_env({"HALO_RS_GRAPH": "0"}, lambda: RegionSelection(cfg, _Fake(), _Fake(small[1]), small[0], 1, in_flight=1, writer_threads=2))
+    check("s", small[2])
