@@ -2531,3 +2531,35 @@ def test_region_selection_replayed_launch_groups_survive_workspace_growth(dev):
     check("s", small[2])
     _with_env({"HALO_RS_GRAPH": "0"}, lambda: RegionSelection(cfg, _Fake(), _Fake(small[1]), small[0], 1, in_flight=1, writer_threads=2))
     check("s", small[2])
+
+
+def test_more_handed_over_images_than_resume_workgroups(dev):
+    """The serial kernel behind the sweep runs one workgroup per image up to 64; 70 maps that ALL hand over (plateaus of ties, NaN,
+    constant maps) make its workgroups walk more than one image each."""
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(5)
+    B, H, W, n, mrad = 70, 48, 64, 6, 3
+    maps = []
+    for b in range(B):
+        m = np.round(rng.standard_normal((H, W)) * 2) / 2                  # few distinct values: hundreds of exact ties per bin
+        if b % 3 == 1:
+            m[:] = 0.5
+        if b % 3 == 2:
+            m[b % H, b % W] = np.nan
+        maps.append(m)
+    s0 = np.ascontiguousarray(np.stack(maps))
+    gt = rng.integers(0, 19, (B, H, W)).astype(np.int64)
+    s = t(s0, dev).clone()
+    act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+    am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+    hov = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    picks, npk = greedy_select(s, n, 1, mrad, act, sel, am, t(gt, dev), handover=hov)
+    assert int((hov[:, 0] != 0).sum()) >= 60                                  # (a rounded map may by chance finish above its plateaus)
+    for b in range(B):
+        so = s0[b].copy()
+        a_o = np.zeros((H, W), bool); s_o = np.zeros((H, W), bool); m_o = np.full((H, W), 255, np.int64)
+        _, _, _, _, po = ho.select_pixels_to_label(so, n, 1, mrad, a_o, s_o, m_o, gt[b], True)
+        k = int(npk[b])
+        assert k == len(po) and bits_equal(picks[b, :k].cpu().numpy(), po), b
+        assert np.array_equal(act[b].cpu().numpy(), a_o) and np.array_equal(am[b].cpu().numpy(), m_o), b

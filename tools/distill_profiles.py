@@ -3,7 +3,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(ROOT, "gpurun_out", RND + "_profiles")
 DST = os.path.join(ROOT, "profiles")
 
@@ -66,7 +66,8 @@ def main():
     d = copy_json("bench_default.json", RND + "_bench_default.json")
     copy_json("bench_under_rocprof.json", RND + "_bench_under_rocprof.json")
     for v in ("f32", "lowres", "lowres_exact", "lowres_gram", "c512", "ripu", "hyper", "pool2975", "resets_kernel", "resets_fills",
-              "pool96_one_rank", "pool96_two_ranks_one_gpu", "r02_equivalent", "world8_one_gpu_tiny"):
+              "pool96_one_rank", "pool96_two_ranks_one_gpu", "r02_equivalent", "world8_one_gpu_tiny", "f32_selprio0", "hyper_inline_tail",
+              "data_late_round", "data_saturated", "data_peaked", "data_late_round+saturated+peaked", "data_plateau", "ripu_peaked"):
         copy_json("bench_%s.json" % v, RND + "_bench_%s.json" % v)
     stats_csv("trace/*/*_kernel_stats.csv", RND + "_kernel_stats.csv")
     stats_csv("trace_ripu/*/*_kernel_stats.csv", RND + "_kernel_stats_ripu.csv", 25)
@@ -76,6 +77,7 @@ def main():
     stats_csv("trace_lowres/*/*_kernel_stats.csv", RND + "_kernel_stats_lowres.csv", 25)
     stats_csv("trace_f32/*/*_kernel_stats.csv", RND + "_kernel_stats_f32.csv", 25)
     stats_csv("trace_lowres_gram/*/*_kernel_stats.csv", RND + "_kernel_stats_lowres_gram.csv", 25)
+    stats_csv("trace_head/*/*_kernel_stats.csv", RND + "_kernel_stats_head.csv", 25)
     lr = counters("pmc_lowres/*/*counter_collection.csv")
     if lr:
         clk = counters("pmc_lowres_clk/*/*counter_collection.csv")
@@ -106,7 +108,7 @@ def main():
     for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt", "tail_timeline.txt", "ab_lowres_dma.txt", "two_ranks_one_gpu.txt", "select_timing_ranged.txt",
               "select16_breakdown.txt", "bench_repeats.txt", "ab_feat_map.txt", "region_selection_timing_device_staging.txt",
               "region_selection_timing_python_writer.txt", "host_pieces.txt", "hw_queues.txt", "gram_ab.txt", "op_rate.txt",
-              "lowres_overlap_probe.txt"):
+              "lowres_overlap_probe.txt", "head_timing.txt", "region_selection_timing_eager_launches.txt", "FAILED"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]
