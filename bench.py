@@ -93,11 +93,11 @@ def parse():
                     help="split = the scorer's tail kernels on their own stream, forked behind the feature pass (halo_score_maps_split), "
                          "so that they overlap the next step's feature kernel; inline = on the scoring stream, between two feature "
                          "kernels; auto = split for the 'hyper' purity (0.95 ms of tail: +6 %%), inline otherwise (0.26 ms of tail: "
-                         "beside the next feature kernel it costs that kernel 0.5-0.9 ms, profiles/r03_tail_split.txt)")
+                         "beside the next feature kernel it costs that kernel 0.5-0.9 ms, profiles/archive/r03_tail_split.txt)")
     ap.add_argument("--settle", type=float, default=5.0,
                     help="seconds to wait before the GPU is touched when the resident pool is large (> 8 GiB): a run that starts "
                          "within a few seconds of the end of another large GPU process measures ~3 %% low -- the driver is still "
-                         "busy with the memory that process gave back (profiles/r03_process_alternation.txt); 0 = do not wait")
+                         "busy with the memory that process gave back (profiles/archive/r03_process_alternation.txt); 0 = do not wait")
     ap.add_argument("--sel-priority", type=int, default=-1, help="stream priority of the selection streams (-1 = high)")
     ap.add_argument("--data", default="gaussian",
                     help="synthetic value distribution, '+'-joined modifiers of the SURVEY 8(d) default ('gaussian'): late_round = half of the "
@@ -809,7 +809,7 @@ def main():
                                 float(np.mean(lr_ms["tail"])), HBM_PEAK_GBPS, "GB/s",
                                 "radius + entropy read (entropy twice: min/max pass and combine), active read, three maps written"))
             out["roofline_kernels"] = ks
-        for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r05_pmc_summary.json", "r04_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if out["roofline"] is None or lowres or not os.path.exists(pmc):
                 continue

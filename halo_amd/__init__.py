@@ -19,7 +19,7 @@ def configure(hw_queues=None):
     HIP runtime initialises.  The acquisition keeps up to six streams busy (RegionSelection: 4 side streams + the caller's;
     bench.py: 1 + 3 + 1) and measured fastest on TWO queues (kernels of different streams still overlap inside a queue; with
     three or more, the short kernels that follow a long one on the scoring stream start late: bench.py +1.4 %, --source lowres
-    +12 %, --branch ripu +9 %, profiles/r03_hw_queues.txt).  That was measured on the acquisition ALONE: the same setting also
+    +12 %, --branch ripu +9 %, profiles/archive/r03_hw_queues.txt).  That was measured on the acquisition ALONE: the same setting also
     governs the training iterations' streams (DDP / RCCL communication, H2D copies), which is why it is the caller's decision.
     Call this before the first HIP call of the process (bench.py and tools/ do); returns the value in force, or raises
     RuntimeError when the runtime is already up with a different one."""
