@@ -47,7 +47,7 @@ import torch
 import torch.distributed as dist
 from halo_amd import _lib as _halo_lib  # noqa: E402  (constants only; the library loads on first use)
 
-LOGIT_LR_VALU_PER_PX = 1104.0      # SQ_INSTS_VALU per output pixel at 19 classes, profiles/r04_pmc_lowres.json (1162 before the integer forms, 1411 in round 3)
+LOGIT_LR_VALU_PER_PX = 1104.0      # SQ_INSTS_VALU per output pixel at 19 classes, profiles/r05_pmc_lowres.json (578.8 M per 16 images) (1162 before the integer forms, 1411 in round 3)
 HBM_PEAK_GBPS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 H, W, O = 1024, 2048, 19
 
@@ -774,7 +774,7 @@ def main():
                 # and 8 pixels, ~3.9 per pixel at this geometry -- `valu_slot_frac` prices the slots
                 # it actually issues against the FP64 (FP32) vector issue rate, `frac` the reference-formula flops against the spec.
                 flops = 11.0 * B * Hh * Ww * C
-                slots = 3.9 * B * Hh * Ww * C          # 8 pixels per lane at this x4 geometry (SQ_INSTS_VALU, profiles/r04_pmc_lowres.json); 4.4 with 4
+                slots = 3.9 * B * Hh * Ww * C          # 8 pixels per lane at this x4 geometry (SQ_INSTS_VALU, profiles/archive/r04_pmc_lowres.json); 4.4 with 4
                 peak = 78.6 if fdtype == torch.float64 else 157.3
                 ach = flops / (t_feat * 1e-3) / 1e12
                 out["roofline"] = {"bound": "valu", "kernel": "k_feat_reduce_lr_dmaf" if fdtype == torch.float64 else "k_feat_reduce_lr", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -790,7 +790,7 @@ def main():
                         "avg_launch_ms": round(t_ms, 4), "work_per_launch": work, "what": what}
             ks = []
             if lr_ms["logit"]:
-                # VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/r04_pmc_lowres.json; 1162 before the
+                # VALU wave-instructions per output pixel at 19 classes (SQ_INSTS_VALU, profiles/archive/r04_pmc_lowres.json; 1162 before the
                 # integer forms of the exp / log cores): interpolation 6 + lean softmax / entropy ~52 per class; peak = 256 CUs x 4
                 # SIMDs x 32 lanes x 2.4 GHz (fma / mul / add issue in 2 cycles per wave, everything else in 4: tools/micro/op_rate.hip)
                 ks.append(entry("k_logit_maps_lr<%d>" % O, "valu", LOGIT_LR_VALU_PER_PX / 19 * O * B * Hh * Ww, float(np.mean(lr_ms["logit"])), 78.6, "T lane-ops/s",
@@ -809,7 +809,7 @@ def main():
                                 float(np.mean(lr_ms["tail"])), HBM_PEAK_GBPS, "GB/s",
                                 "radius + entropy read (entropy twice: min/max pass and combine), active read, three maps written"))
             out["roofline_kernels"] = ks
-        for name in ("r05_pmc_summary.json", "r04_pmc_summary.json"):
+        for name in ("r05_pmc_summary.json", os.path.join("archive", "r04_pmc_summary.json")):
             pmc = os.path.join(ROOT, "profiles", name)
             if out["roofline"] is None or lowres or not os.path.exists(pmc):
                 continue

@@ -1970,7 +1970,7 @@ __global__ void __launch_bounds__(TPB) k_gram_lr2(const double *__restrict__ fea
             }
     };
     // UCH channels ((R + 1) x 16 bytes each) in flight per lane.  NT (non-temporal loads) measured 20 % SLOWER: every row is read
-    // a second time, right away, as the neighbour row of the wave above -- an L2 hit that `nt` gives up (profiles/r04_gram_ab.txt)
+    // a second time, right away, as the neighbour row of the wave above -- an L2 hit that `nt` gives up (profiles/archive/r04_gram_ab.txt)
     auto ld2 = [](const double *q) -> d2_t {
         if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(q));
         else return *reinterpret_cast<const d2_t *>(q);
@@ -2413,7 +2413,7 @@ static int score_impl(const float *logit, int64_t logit_bstride, const void *fea
             const bool wide = lr->wf >= 2 && lr->wf % 2 == 0 && feat_bstride % 2 == 0 && aligned16(feat) && aligned16(gram) && getenv("HALO_GRAM_8B") == nullptr;
             if (wide) {
                 // rows per wave: every source row is loaded (R + 1) / R times (its own strip + as lower neighbour of the strip above),
-                // and that redundancy, not the bytes in flight, is what the kernel's time follows (profiles/r04_gram_ab.txt: R = 2 / 4 /
+                // and that redundancy, not the bytes in flight, is what the kernel's time follows (profiles/archive/r04_gram_ab.txt: R = 2 / 4 /
                 // 8 -> 788 / 745 / 705 us per 16 images; 2, 3 or 4 channels in flight: equal; non-temporal loads: 20 % slower).  The
                 // widest strip that still gives every SIMD of the chip a wave; HALO_GRAM_ROWS / _UCH / _NT are A/B switches (same bits)
                 const char *eu = getenv("HALO_GRAM_UCH"), *en = getenv("HALO_GRAM_NT"), *er = getenv("HALO_GRAM_ROWS");
