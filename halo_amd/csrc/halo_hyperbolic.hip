@@ -559,6 +559,52 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr_mfma(const double *__restrict
 //     in waves that hold a pixel beyond maxnorm.
 // Row stride of the weight image = C + pad doubles with (C + pad) mod 32 == 2: the 16 x 4 (row, channel) operand
 // fetch of a wave is then conflict-free on the 64 LDS banks.
+// ---- asinh / reciprocal for the matrix-core HyperMLR epilogue, where no bit-level contract exists (kept out of halo_devmath.hpp: that
+// header holds the bit-exact recipes and is also compiled on the host by tests/native/devmath_host_check.cpp)
+// -- no bit-level contract (the logits are within 1e-10 of the
+// reference's; the acquisition's parity starts FROM the logits): every quotient a / b is a * rcp(b) with the reciprocal refined by
+// two Newton steps from v_rcp_f64 (<= 1 ulp; 5 instructions where the IEEE division sequence takes 12-15: scaling, fixup), valid
+// for finite b of ordinary magnitude -- the epilogue's denominators are clamped to >= 1e-12 or lie in [1, 1e150].
+__device__ __forceinline__ double fast_rcp(double b)
+{
+    const double r0 = __builtin_amdgcn_rcp(b);
+    double r = __builtin_fma(__builtin_fma(-b, r0, 1.0), r0, r0);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return __builtin_fabs(b) == __builtin_inf() ? r0 : r;       // 1 / inf = 0 (the refinement would make it NaN); NaN stays NaN
+}
+// log of a double in [1, 1e300): log_core_ with its one quotient through fast_rcp
+__device__ __forceinline__ double log_ge1_fast(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    u = ((uint64_t)hx << 32) | (u & 0xffffffffull);
+    const double f = __longlong_as_double((long long)u) - 1.0;
+    const double hfsq = (0.5 * f) * f;
+    const double s = f * fast_rcp(2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1, dk = (double)k;
+    return __builtin_fma(dk, ln2_hi, (f - (hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo))));
+}
+__device__ __forceinline__ double asinh_fast(double x)
+{
+    const double a = __builtin_fabs(x), a2 = a * a;
+    const double t = a + a2 * fast_rcp(1.0 + __builtin_sqrt(1.0 + a2));
+    const double u = 1.0 + t;
+    // |x| beyond ~1e150 (a2 overflows) or NaN: the exact-order statement handles it
+    const double r = (a < 1e150) ? log_ge1_fast(u) + (t - (u - 1.0)) * fast_rcp(u) : __builtin_fabs(asinh_det(x));
+    return x != x ? x : __builtin_copysign(r, x);
+}
+
 constexpr int MLRP_TPB = 512, MLRP_SK = 4, MLRP_RING = 4;
 #ifdef HALO_MLR_IEEE            // variant build for A/B (HALO_LIB_PATH): the round-4 epilogue, IEEE divisions
 #define MLR_RCP(x) (1.0 / (x))
