@@ -995,23 +995,66 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
     // same (row-major) order as box3_row4 / k_box3_minmax
     const float *ep = ent + (size_t)b * hw;
     const int lane = threadIdx.x & 63;
-    auto load_row = [&](int yy, float (&r)[6]) {
-        const bool in = live && yy >= 0 && yy < H;
-        const float *row = ep + (size_t)(in ? yy : 0) * W;
-        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (in) q = *reinterpret_cast<const float4 *>(row + x);
-        float left = lane_prev(q.w), right = lane_next(q.x);
-        if (lane == 0) left = (in && x > 0) ? row[x - 1] : 0.0f;
-        if (lane == 63) right = (in && x + 4 < W) ? row[x + 4] : 0.0f;
-        r[0] = (in && x > 0) ? left : 0.0f;
-        r[1] = q.x; r[2] = q.y; r[3] = q.z; r[4] = q.w;
-        r[5] = (in && x + 4 < W) ? right : 0.0f;
+    // A row of taps in two steps, so that the loads of row y + 2 are in flight while row y is being combined (round 5: with load and
+    // lane shifts in one step every trip of the row loop began with a full memory round trip -- 16 of them per workgroup):
+    //   row_issue : the lane's float4 and, for the wave's first / last lane, the two neighbours beyond the wave's span
+    //   row_finish: the edge taps from the adjacent lanes' registers (full-wave DPP shifts), out-of-image taps = +0
+    struct RowRaw { float4 q; float el, er; bool in; };
+    auto row_issue = [&](int yy) {
+        RowRaw t;
+        t.in = live && yy >= 0 && yy < H;
+        const float *row = ep + (size_t)(t.in ? yy : 0) * W;
+        t.q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        t.el = 0.0f; t.er = 0.0f;
+        if (t.in) t.q = *reinterpret_cast<const float4 *>(row + x);
+        if (lane == 0 && t.in && x > 0) t.el = row[x - 1];
+        if (lane == 63 && t.in && x + 4 < W) t.er = row[x + 4];
+        return t;
+    };
+    auto row_finish = [&](const RowRaw &t, float (&r)[6]) {
+        float left = lane_prev(t.q.w), right = lane_next(t.q.x);
+        if (lane == 0) left = t.el;
+        if (lane == 63) right = t.er;
+        r[0] = (t.in && x > 0) ? left : 0.0f;
+        r[1] = t.q.x; r[2] = t.q.y; r[3] = t.q.z; r[4] = t.q.w;
+        r[5] = (t.in && x + 4 < W) ? right : 0.0f;
+    };
+    typedef double cb_d2 __attribute__((ext_vector_type(2)));
+    typedef float cb_f4 __attribute__((ext_vector_type(4)));
+    struct PixRaw { cb_d2 d0, d1; cb_f4 f; unsigned am; };
+    auto pix_issue = [&](int yy) {          // impurity and prior-pick mask of row yy (clamped: the values of a row past the group are not used)
+        PixRaw t;
+        t.d0 = (cb_d2){0.0, 0.0}; t.d1 = t.d0; t.f = (cb_f4){0.f, 0.f, 0.f, 0.f}; t.am = 0u;
+        if (!live || yy >= yend) return t;
+        const size_t o = (size_t)b * hw + (size_t)yy * W + x;
+        if constexpr (sizeof(TI) == 8) {
+            if constexpr (NTS) {
+                t.d0 = __builtin_nontemporal_load(reinterpret_cast<const cb_d2 *>(imp_raw + o));
+                t.d1 = __builtin_nontemporal_load(reinterpret_cast<const cb_d2 *>(imp_raw + o + 2));
+            } else {
+                t.d0 = *reinterpret_cast<const cb_d2 *>(imp_raw + o);
+                t.d1 = *reinterpret_cast<const cb_d2 *>(imp_raw + o + 2);
+            }
+        } else {
+            if constexpr (NTS) t.f = __builtin_nontemporal_load(reinterpret_cast<const cb_f4 *>(imp_raw + o));
+            else t.f = *reinterpret_cast<const cb_f4 *>(imp_raw + o);
+        }
+        if (active) t.am = *reinterpret_cast<const unsigned *>(active + o);
+        return t;
     };
     float r0[6], r1[6], r2[6];
-    load_row(ybeg - 1, r0);
-    load_row(ybeg, r1);
+    {
+        const RowRaw a0 = row_issue(ybeg - 1), a1 = row_issue(ybeg);
+        row_finish(a0, r0);
+        row_finish(a1, r1);
+    }
+    RowRaw nrow = row_issue(ybeg + 1);                            // in flight across a trip: the taps of row y + 1 ...
+    PixRaw npix = pix_issue(ybeg);                                // ... and the impurity / mask of row y
     for (int y = ybeg; y < yend; ++y) {
-        load_row(y + 1, r2);                                  // every lane of the wave: the lane shifts are wave-wide
+        row_finish(nrow, r2);                                     // every lane of the wave: the lane shifts are wave-wide
+        const PixRaw cpix = npix;
+        nrow = row_issue(y + 2);                                  // requested now, used in the next trip
+        npix = pix_issue(y + 1);
         float un[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1029,29 +1072,13 @@ __global__ void __launch_bounds__(TPB) k_combine_box3(const TI *__restrict__ imp
         if (!live) continue;
         const size_t o = (size_t)b * hw + (size_t)y * W + x;
         TI im[4];
-        typedef double cb_d2 __attribute__((ext_vector_type(2)));
-        typedef float cb_f4 __attribute__((ext_vector_type(4)));
-        if constexpr (sizeof(TI) == 8) {
-            cb_d2 q0, q1;
-            if constexpr (NTS) {
-                q0 = __builtin_nontemporal_load(reinterpret_cast<const cb_d2 *>(imp_raw + o));
-                q1 = __builtin_nontemporal_load(reinterpret_cast<const cb_d2 *>(imp_raw + o + 2));
-            } else {
-                q0 = *reinterpret_cast<const cb_d2 *>(imp_raw + o);
-                q1 = *reinterpret_cast<const cb_d2 *>(imp_raw + o + 2);
-            }
-            im[0] = q0.x; im[1] = q0.y; im[2] = q1.x; im[3] = q1.y;
-        } else {
-            cb_f4 q;
-            if constexpr (NTS) q = __builtin_nontemporal_load(reinterpret_cast<const cb_f4 *>(imp_raw + o));
-            else q = *reinterpret_cast<const cb_f4 *>(imp_raw + o);
-            im[0] = q.x; im[1] = q.y; im[2] = q.z; im[3] = q.w;
-        }
+        if constexpr (sizeof(TI) == 8) { im[0] = cpix.d0.x; im[1] = cpix.d0.y; im[2] = cpix.d1.x; im[3] = cpix.d1.y; }
+        else { im[0] = cpix.f.x; im[1] = cpix.f.y; im[2] = cpix.f.z; im[3] = cpix.f.w; }
         if (normalize) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { un[j] = (un[j] - umn) / uden; im[j] = (im[j] - imn) / iden; }
         }
-        const unsigned am = active ? *reinterpret_cast<const unsigned *>(active + o) : 0u;
+        const unsigned am = cpix.am;
         TI sc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
