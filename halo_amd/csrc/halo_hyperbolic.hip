@@ -1205,6 +1205,7 @@ __global__ void __launch_bounds__(HTPB) k_bilinear_lds(const T *__restrict__ src
                 T *q = dst + ((size_t)(p0 + pl) * H + y) * W + xb;
                 if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));
                 else if constexpr (sizeof(T) == 4 && VEC == 4) __builtin_nontemporal_store((f4_t){o[0], o[1], o[2], o[3]}, reinterpret_cast<f4_t *>(q));
+                else if constexpr (sizeof(T) == 4 && VEC == 2) __builtin_nontemporal_store((f2_t){o[0], o[1]}, reinterpret_cast<f2_t *>(q));
                 else {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) q[j] = o[j];
@@ -1224,10 +1225,10 @@ constexpr int BL_RO = 4, BL_SR = 6, BL_PCR = 4;     // output rows per block, so
 // kept that case on the one-row kernel, 0.40 of the HBM spec at the v2 head's 640x1280 -> 1024x2048)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(HTPB, (sizeof(T) == 4 && VEC == 4) ? 2 : 4) k_bilinear_lds_rows(const T *__restrict__ src, T *__restrict__ dst, int planes, int h, int w,
-                                                            int H, int W, T sh, T sw, int span)
+                                                            int H, int W, T sh, T sw, int span, int pcr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    T *tile = reinterpret_cast<T *>(smem_b);                       // [BL_PCR][nsr][span]
+    T *tile = reinterpret_cast<T *>(smem_b);                       // [pcr][nsr][span]: pcr <= BL_PCR planes per chunk
     const int tid = threadIdx.x;
     const int yb = blockIdx.y * BL_RO, xb0 = blockIdx.x * HTPB * VEC, xb = xb0 + tid * VEC;
     // source rows of this block's output rows: [sy0, sy0 + nsr)
@@ -1270,14 +1271,14 @@ __global__ void __launch_bounds__(HTPB, (sizeof(T) == 4 && VEC == 4) ? 2 : 4) k_
         lx0[j] = (T)1 - lx1[j];
     }
     const int plane_lds = nsr * span;
-    for (int p0 = blockIdx.z * BL_PCR; p0 < planes; p0 += gridDim.z * BL_PCR) {
+    for (int p0 = blockIdx.z * pcr; p0 < planes; p0 += gridDim.z * pcr) {
         __syncthreads();                                           // the previous chunk's taps have been read
         // wave wv stages the (plane, source row) pairs wv, wv + 4, ...: one coalesced row segment each.  All loads of a pair are
         // issued before its first LDS store (BL_ST in flight per lane; a segment of up to 64 * BL_ST columns): with one load per trip
         // the staging was a chain of ~20 dependent round trips per chunk at the v2 head's x1.6 geometry (324-column segments, 16
         // pairs), and the kernel ran at 0.43 of the HBM spec where the x4 geometry -- 9 trips -- reached 0.70
         constexpr int BL_ST = 8;
-        for (int pr = tid >> 6, pl = 0, rr = tid >> 6; pr < BL_PCR * nsr; pr += HTPB / 64, rr += HTPB / 64) {
+        for (int pr = tid >> 6, pl = 0, rr = tid >> 6; pr < pcr * nsr; pr += HTPB / 64, rr += HTPB / 64) {
             while (rr >= nsr) { rr -= nsr; ++pl; }
             if (p0 + pl < planes) {
                 const T *sp = src + ((size_t)(p0 + pl) * h + sy0 + rr) * w + sx0;
@@ -1294,7 +1295,7 @@ __global__ void __launch_bounds__(HTPB, (sizeof(T) == 4 && VEC == 4) ? 2 : 4) k_
         __syncthreads();
         if (xb < W) {
 #pragma unroll 1
-            for (int pl = 0; pl < BL_PCR; ++pl) {                   // one plane's taps and outputs live at a time
+            for (int pl = 0; pl < pcr; ++pl) {                      // one plane's taps and outputs live at a time
                 if (p0 + pl >= planes) break;
                 const T *tp = tile + pl * plane_lds;
 #pragma unroll
@@ -1312,6 +1313,7 @@ __global__ void __launch_bounds__(HTPB, (sizeof(T) == 4 && VEC == 4) ? 2 : 4) k_
                     T *q = dst + ((size_t)(p0 + pl) * H + yb + r) * W + xb;
                     if constexpr (sizeof(T) == 8 && VEC == 2) __builtin_nontemporal_store((d2_h){o[0], o[1]}, reinterpret_cast<d2_h *>(q));
                     else if constexpr (sizeof(T) == 4 && VEC == 4) __builtin_nontemporal_store((f4_t){o[0], o[1], o[2], o[3]}, reinterpret_cast<f4_t *>(q));
+                    else if constexpr (sizeof(T) == 4 && VEC == 2) __builtin_nontemporal_store((f2_t){o[0], o[1]}, reinterpret_cast<f2_t *>(q));
                     else {
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) q[j] = o[j];
@@ -1337,18 +1339,23 @@ static void launch_bilinear_rows(const void *src, void *dst, int64_t planes, int
     // BL_RO output rows per block where they touch at most BL_SR source rows (up-sampling by >= 0.8); HALO_BILINEAR_LDS1=1
     // keeps the one-row kernel (A/B switch, same bits)
     const int64_t srows = (int64_t)((double)sh * (double)(BL_RO - 1)) + 3;
-    const size_t lds_r = (size_t)BL_PCR * srows * span * sizeof(T);
+    // planes per chunk: BL_PCR where their taps fit 24 KiB of LDS (the x4 geometries: 6-7 blocks per CU), fewer for wide source
+    // windows (x1.6: 10 KiB per plane -> 2 planes) so that as many blocks stay resident; HALO_BILINEAR_PCR overrides (tuning aid)
+    int pcr = BL_PCR;
+    while (pcr > 1 && (size_t)pcr * srows * span * sizeof(T) > 24 * 1024) pcr >>= 1;
+    if (const char *e = getenv("HALO_BILINEAR_PCR")) { const int v = atoi(e); if (v >= 1 && v <= BL_PCR) pcr = v; }
+    const size_t lds_r = (size_t)pcr * srows * span * sizeof(T);
     // (float32 with 4 pixels per lane stays on the one-row kernel: on the four-row kernel it needs 178 registers -- two blocks per CU --
     // and measured no faster at the v2 head's 640x1280 -> 1024x2048, 0.066 against 0.069 ms, and slower at x4: 0.044 against 0.039)
     if (!(sizeof(T) == 4 && VEC == 4) && srows <= BL_SR && lds_r <= 48 * 1024 && cdiv(H, BL_RO) <= 65535 && !getenv("HALO_BILINEAR_ROWS") &&
         !getenv("HALO_BILINEAR_LDS1")) {
         const unsigned gyr = (unsigned)cdiv(H, BL_RO);
         int64_t gzl = cdiv(8192, (int64_t)gx * gyr);
-        const int64_t chunks = cdiv(planes, BL_PCR);
+        const int64_t chunks = cdiv(planes, pcr);
         gzl = gzl < 1 ? 1 : (gzl > chunks ? chunks : gzl);
         if (gzl > 65535) gzl = 65535;
         hipLaunchKernelGGL((k_bilinear_lds_rows<T, VEC>), dim3(gx, gyr, (unsigned)gzl), dim3(HTPB), lds_r, st, (const T *)src, (T *)dst,
-                           (int)planes, (int)h, (int)w, (int)H, (int)W, sh, sw, (int)span);
+                           (int)planes, (int)h, (int)w, (int)H, (int)W, sh, sw, (int)span, pcr);
         return;
     }
     const size_t lds = (size_t)BL_PC * 2 * span * sizeof(T);
@@ -1381,7 +1388,12 @@ extern "C" int halo_bilinear_upsample(const void *src, void *dst, int dtype, int
         if (W % 2 == 0 && a16) launch_bilinear_rows<double, 2>(src, dst, planes, h, w, H, W, st);
         else launch_bilinear_rows<double, 1>(src, dst, planes, h, w, H, W, st);
     } else if (rows) {
-        if (W % 4 == 0 && a16) launch_bilinear_rows<float, 4>(src, dst, planes, h, w, H, W, st);
+        // mild magnification (below x3: the v2 head's 640x1280 -> 1024x2048): two pixels per lane on the four-row kernel -- a source row
+        // is staged once per four output rows; the one-row kernel that serves float32 x 4 stages two source rows for EVERY output row,
+        // 3.2x the input at x1.6 (HALO_BILINEAR_F32V4=1: A/B switch)
+        const bool mild = H > 1 && W > 1 && (double)(h - 1) / (double)(H - 1) > 1.0 / 3.0 && (double)(w - 1) / (double)(W - 1) > 1.0 / 3.0;
+        if (W % 4 == 0 && a16 && !(mild && !getenv("HALO_BILINEAR_F32V4"))) launch_bilinear_rows<float, 4>(src, dst, planes, h, w, H, W, st);
+        else if (W % 2 == 0 && ((uintptr_t)dst % 8) == 0) launch_bilinear_rows<float, 2>(src, dst, planes, h, w, H, W, st);
         else launch_bilinear_rows<float, 1>(src, dst, planes, h, w, H, W, st);
     } else {
         const long long n = (long long)planes * H * W;
