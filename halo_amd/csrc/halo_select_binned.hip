@@ -58,6 +58,7 @@ struct BinWs {
     unsigned *fcur;                          // nfmax: candidates placed in each fine bin
     unsigned long long *ckey;                // nfmax * BIN_CAP: bin f owns slots [f * BIN_CAP, (f + 1) * BIN_CAP)
     unsigned *cpos;                          // nfmax * BIN_CAP
+    unsigned long long *okmin_inv, *okmax;   // nfmax each: max of ~key / of key over the candidates that found their bin full (zero = none)
     unsigned *plist;                         // n_regions: picks as (w << 16) | h
     int *handover;                           // optional (B, 2): {HALO_SWEEP_* reason, picks the sweep made}; NULL = not reported
 };
@@ -251,6 +252,7 @@ __global__ void __launch_bounds__(256) k_sel_place(const T *__restrict__ score, 
     unsigned *fcur = ws.fcur + (size_t)b * g.nfmax;
     unsigned long long *ckey = ws.ckey + (size_t)b * g.nfmax * BIN_CAP;
     unsigned *cpos = ws.cpos + (size_t)b * g.nfmax * BIN_CAP;
+    unsigned long long *okmin_inv = ws.okmin_inv + (size_t)b * g.nfmax, *okmax = ws.okmax + (size_t)b * g.nfmax;
     bool overflow = false;
     // PL_U row segments per iteration: their loads and their returned atomics are in flight together (beside a
     // bandwidth-bound kernel each dependent round trip costs microseconds)
@@ -280,17 +282,45 @@ __global__ void __launch_bounds__(256) k_sel_place(const T *__restrict__ score, 
                     f[u] = s_base[j] + (mj - 1 - sb);
                 }
             }
+            // One returned atomic per candidate -- or, where every candidate of the wave goes to the SAME bin (a plateau of ties:
+            // half a million atomics on one counter otherwise), one per wave: the first candidate lane adds the wave's count and the
+            // lanes take consecutive slots behind its return value.
+            unsigned long long cm[PL_U];
+            bool agg[PL_U];
+            int lead[PL_U];
 #pragma unroll
-            for (int u = 0; u < PL_U; ++u) slot[u] = cand[u] ? atomicAdd(&fcur[f[u]], 1u) : 0u;      // PL_U returns in flight
+            for (int u = 0; u < PL_U; ++u) {
+                cm[u] = __ballot(cand[u]);
+                lead[u] = cm[u] ? (int)__builtin_ctzll(cm[u]) : 0;
+                const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)f[u], lead[u]);
+                agg[u] = cm[u] != 0ull && (cm[u] & (cm[u] - 1ull)) != 0ull && __ballot(cand[u] && f[u] == f0) == cm[u];
+                const bool mine = cand[u] && (!agg[u] || (tid & 63) == lead[u]);
+                slot[u] = mine ? atomicAdd(&fcur[f[u]], agg[u] ? (unsigned)__builtin_popcountll(cm[u]) : 1u) : 0u;      // PL_U returns in flight
+            }
 #pragma unroll
             for (int u = 0; u < PL_U; ++u)
-                if (cand[u]) {
-                    if (slot[u] < (unsigned)BIN_CAP) {
-                        const size_t sl = (size_t)f[u] * BIN_CAP + slot[u];
-                        ckey[sl] = k[u];
-                        cpos[sl] = ((unsigned)(x0 + u * 256 + tid) << 16) | (unsigned)y;
-                    } else overflow = true;
+                if (agg[u]) {
+                    const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)slot[u], lead[u]);
+                    slot[u] = base + __builtin_amdgcn_mbcnt_hi((unsigned)(cm[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm[u], 0u));
                 }
+#pragma unroll
+            for (int u = 0; u < PL_U; ++u) {
+                const bool full = cand[u] && slot[u] >= (unsigned)BIN_CAP;
+                if (cand[u] && !full) {
+                    const size_t sl = (size_t)f[u] * BIN_CAP + slot[u];
+                    ckey[sl] = k[u];
+                    cpos[sl] = ((unsigned)(x0 + u * 256 + tid) << 16) | (unsigned)y;
+                }
+                overflow = overflow || full;
+                // a candidate that found its bin full is dropped, but its key is remembered in the bin's extrema: a full bin whose
+                // candidates ALL carry one key is a plateau of exact ties, which the sweep walks through the map itself
+                if (__any(full)) {
+                    if (agg[u]) {
+                        const unsigned long long kx = wave_max_u64(full ? k[u] : 0ull), kn = wave_max_u64(full ? ~k[u] : 0ull);
+                        if ((tid & 63) == lead[u]) { atomicMax(&okmax[f[u]], kx); atomicMax(&okmin_inv[f[u]], kn); }
+                    } else if (full) { atomicMax(&okmax[f[u]], k[u]); atomicMax(&okmin_inv[f[u]], ~k[u]); }
+                }
+            }
         }
     if (__any(overflow) && (tid & 63) == 0) atomicOr(&hdr->flags, (unsigned)SEL_F_OVERFLOW);
 }
@@ -415,7 +445,8 @@ __device__ __forceinline__ int resolve_bin_parallel(const unsigned long long *sk
 }
 
 // ------------------------------------------------------------------ the sweep
-__global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *__restrict__ n_picked)
+__global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *__restrict__ n_picked, const void *__restrict__ score_maps,
+                                                      int score_f64)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *grid = smem;                                               // pick grid, one byte per cell (+ border)
@@ -434,6 +465,9 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     const unsigned long long *ckey = ws.ckey + (size_t)b * g.nfmax * BIN_CAP;
     const unsigned *cpos = ws.cpos + (size_t)b * g.nfmax * BIN_CAP;
     unsigned *plist = ws.plist + (size_t)b * g.n_regions;
+    const unsigned long long *okmin_inv = ws.okmin_inv + (size_t)b * g.nfmax, *okmax = ws.okmax + (size_t)b * g.nfmax;
+    const double *map64 = score_f64 ? (const double *)score_maps + (size_t)b * g.H * g.W : nullptr;
+    const float *map32 = score_f64 ? nullptr : (const float *)score_maps + (size_t)b * g.H * g.W;
 
     for (unsigned i = tid * 16; i < g.grid_bytes; i += SW_TPB * 16) *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
@@ -453,19 +487,20 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     // SW_TPB / 2 of them, so it is never split).  Nothing depends on the order inside a chunk -- the resolve step takes its
     // survivors in exact priority order -- and chunks are still monotone in the value, so merging bins changes no pick; it
     // halves the number of filter / resolve rounds (two barriers and a serial resolve each) for the same candidates.
-    struct Chunk { unsigned start[SW_MB], cnt[SW_MB], total; bool last, valid; };
+    struct Chunk { unsigned start[SW_MB], cnt[SW_MB], total; bool last, valid, plateau; unsigned pbin; };
     unsigned fw0 = 0, fwn = 0;                   // fwin holds the candidate counts of bins fw0 .. fw0 + fwn - 1
     unsigned it_f = 0;                           // next bin to look at
-    bool hit_full = false;                       // the iterator reached a bin that ran out of slots (a plateau of ties): the stream ends
-                                                 // in front of it -- everything above it is swept, the serial kernel continues from there
-                                                 // (round 4 handed such an image over untouched, wherever the full bin lay)
+    // A bin that ran out of slots (more than BIN_CAP candidates in one sub-slice of the value range: a plateau of ties) becomes a
+    // chunk of its own kind, in its place in the stream: when the walk REACHES it -- everything above it has been swept -- the
+    // plateau is walked through the map itself if all its candidates carry one key (plateau_scan below), and handed to the serial
+    // kernel from there otherwise (round 4 handed such an image over untouched, wherever the full bin lay).
     auto next_chunk = [&]() {
         Chunk c;
 #pragma unroll
         for (int i = 0; i < SW_MB; ++i) { c.start[i] = 0; c.cnt[i] = 0; }
-        c.total = 0; c.last = true; c.valid = false;
+        c.total = 0; c.last = true; c.valid = false; c.plateau = false; c.pbin = 0;
         int nb = 0;
-        while (it_f < nf && !hit_full) {
+        while (it_f < nf) {
             if (fwn == 0 || it_f >= fw0 + fwn) {             // stage the next window of bin counts (uniform: every thread gets here together)
                 lds_barrier();
                 fw0 = it_f;
@@ -475,7 +510,10 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
             }
             const unsigned n = fwin[it_f - fw0];
             if (n == 0) { ++it_f; continue; }
-            if (n > (unsigned)BIN_CAP) { hit_full = true; break; }
+            if (n > (unsigned)BIN_CAP) {
+                if (nb == 0) { c.plateau = true; c.pbin = it_f; ++it_f; nb = 1; }      // (behind an open chunk: it opens the next one)
+                break;
+            }
             if (nb == SW_MB || c.total + n > (unsigned)SW_TPB) break;        // this bin opens the next chunk
 #pragma unroll
             for (int i = 0; i < SW_MB; ++i)
@@ -508,14 +546,12 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
 #else
 #define STAMP(acc)
 #endif
-    // one chunk: filter against the pick grid, survivors -> LDS list; at the end of a bin wave 0 resolves the survivors
-    auto step = [&](const Chunk &c, const Regs &d) {
-        const unsigned long long key = d.key;
-        const unsigned pos = d.pos;
+    // is the pixel (w << 16 | h) outside the window of every pick made so far?  (the 3 x 3 cells around it, three 8-byte LDS reads)
+    auto grid_alive = [&](unsigned pos) {
         const int x = (int)(pos >> 16), y = (int)(pos & 0xffffu);
         const int cx = (int)__umulhi((unsigned)x, g.cmul), cy = (int)__umulhi((unsigned)y, g.cmul);
         const int lx = x - cx * cs, ly = y - cy * cs;
-        bool alive = (unsigned)tid < c.total;
+        bool alive = true;
         const int cell0 = cy * g.gstride + cx;                               // padded address of cell (cy-1, cx-1)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -532,6 +568,10 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
                 alive = alive && !hit;
             }
         }
+        return alive;
+    };
+    // survivors -> the LDS list (one wave-level atomic per wave; entries past the list's capacity are counted, not stored)
+    auto push = [&](bool alive, unsigned long long key, unsigned pos) {
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             unsigned base = 0;
@@ -540,7 +580,9 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
             const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
             if (alive && slot < (unsigned)SW_SURV) { skey[slot] = key; spos[slot] = pos; }
         }
-        if (!c.last) return;
+    };
+    // wave 0 takes the listed survivors in exact priority order (every thread calls it: two barriers); fin follows
+    auto resolve_listed = [&]() {
         STAMP(t_f)
         lds_barrier();
         STAMP(t_a)
@@ -567,6 +609,70 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
         ++nb;
 #endif
     };
+    // ---- a plateau of exact ties, walked through the map itself.  Bin `fb` received more candidates than it has slots.  If they all
+    // carry ONE key V (its stored candidates and the extrema of the dropped ones agree), their priority order is the order of
+    // their positions -- smallest w, then smallest h: the reference's tie-break (build.py:38-43) -- so the bin's candidates in
+    // priority order are the pixels with key V in column-major order, and the map says which those are: no list of them is needed.
+    // The workgroup walks the columns, PL_PP positions per thread and trip (a column of 1024 rows per trip at 1024 x 2048), tests the
+    // members against the pick grid and lists the survivors; the list is resolved when it holds 32 or the trip's survivors do not
+    // fit it (then the trip is redone piece by piece behind a resolve: a piece is at most SW_TPB <= SW_SURV positions).  Listing
+    // survivors of several trips before resolving them changes no pick, exactly as merging bins does not.  Mixed keys in a full bin
+    // (near-ties denser than 128 per sub-slice) are not handled: the image is handed over from here.
+    constexpr int PL_PP = 4;
+    auto plateau_scan = [&](unsigned fb) {
+        const unsigned long long V = ckey[(size_t)fb * BIN_CAP];
+        bool pure = okmax[fb] == V && ~okmin_inv[fb] == V;
+        pure = pure && ckey[(size_t)fb * BIN_CAP + lane] == V && ckey[(size_t)fb * BIN_CAP + 64 + lane] == V;      // BIN_CAP = 128 stored candidates
+        if (!__all(pure)) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; return; }      // (every wave sees the same data: the same verdict)
+        const unsigned P = (unsigned)g.H * (unsigned)g.W, GP = SW_TPB * PL_PP;
+        unsigned listed = 0;                                                       // survivors in the list (uniform)
+        auto fetch = [&](unsigned g0, unsigned long long (&kk)[PL_PP], unsigned (&pp)[PL_PP]) {
+#pragma unroll
+            for (int i = 0; i < PL_PP; ++i) {
+                const unsigned pidx = g0 + (unsigned)i * SW_TPB + (unsigned)tid;
+                const unsigned pc = pidx < P ? pidx : P - 1u;
+                const unsigned w_ = pc / (unsigned)g.H, h_ = pc - w_ * (unsigned)g.H;
+                const size_t o = (size_t)h_ * g.W + w_;
+                const double v = map64 ? map64[o] : (double)map32[o];
+                kk[i] = pidx < P ? order_key(v) : 0ull;                            // 0: below every real key, never V
+                pp[i] = (w_ << 16) | h_;
+            }
+        };
+        unsigned long long kc[PL_PP], kn[PL_PP];
+        unsigned pc_[PL_PP], pn[PL_PP];
+        fetch(0u, kc, pc_);
+        for (unsigned g0 = 0; g0 < P && !fin; g0 += GP) {
+            fetch(g0 + GP < P ? g0 + GP : g0, kn, pn);                             // the next trip's keys are in flight during this one
+#pragma unroll
+            for (int i = 0; i < PL_PP; ++i) push(kc[i] == V && grid_alive(pc_[i]), kc[i], pc_[i]);
+            lds_barrier();
+            const unsigned total = ctl[0];
+            if (total > (unsigned)SW_SURV) {
+                lds_barrier();                                                     // everybody has read the count
+                if (tid == 0) ctl[0] = listed;                                     // forget this trip's survivors ...
+                resolve_listed();                                                  // ... take the ones listed before it ...
+#pragma unroll 1
+                for (int i = 0; i < PL_PP && !fin; ++i) {                          // ... and redo the trip one piece at a time
+                    push(kc[i] == V && grid_alive(pc_[i]), kc[i], pc_[i]);
+                    resolve_listed();
+                }
+                listed = 0;
+            } else {
+                listed = total;
+                if (listed >= 32u) { resolve_listed(); listed = 0; }
+            }
+#pragma unroll
+            for (int i = 0; i < PL_PP; ++i) { kc[i] = kn[i]; pc_[i] = pn[i]; }
+        }
+        if (!fin && listed) resolve_listed();
+    };
+    // one chunk: filter against the pick grid, survivors -> LDS list; at the end of a bin wave 0 resolves the survivors
+    auto step = [&](const Chunk &c, const Regs &d) {
+        if (c.plateau) { plateau_scan(c.pbin); return; }
+        push((unsigned)tid < c.total && grid_alive(d.pos), d.key, d.pos);
+        if (!c.last) return;
+        resolve_listed();
+    };
     Chunk c0 = next_chunk(), c1, c2;
     Regs d0, d1, d2;
     issue(c0, d0);
@@ -590,7 +696,6 @@ __global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *
     }
 #endif
     if (tid == 0) {
-        if (fin == 0 && hit_full) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; }
         if (fin == 0) {                          // candidates exhausted: final unless the threshold bin was dropped
             fin = truncated ? 2 : 1;
             if (truncated) why = hdr->t1 >= (unsigned)NB1 ? HALO_SWEEP_BAD_VALUES : HALO_SWEEP_EXHAUSTED;
@@ -700,6 +805,8 @@ BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t 
     p.off_hdr = take(sizeof(SelHdr));
     p.off_hist1 = take((size_t)NB1 * 4);
     p.off_fcur = take((size_t)g.nfmax * 4);
+    p.off_okmin = take((size_t)g.nfmax * 8);
+    p.off_okmax = take((size_t)g.nfmax * 8);
     p.zero_bytes = o;                                       // everything above is cleared at the start of a call
     p.off_cbase = take((size_t)NB1 * 4);
     p.off_cm = take((size_t)NB1 * 4);
@@ -739,6 +846,8 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     ws.rng_hist = score_range ? (const unsigned *)((const char *)score_range + range_hist_offset(B)) : nullptr;
     ws.hist1 = (unsigned *)(base + p.off_hist1);
     ws.fcur = (unsigned *)(base + p.off_fcur);
+    ws.okmin_inv = (unsigned long long *)(base + p.off_okmin);
+    ws.okmax = (unsigned long long *)(base + p.off_okmax);
     ws.cbase = (unsigned *)(base + p.off_cbase);
     ws.cm = (unsigned *)(base + p.off_cm);
     ws.ckey = (unsigned long long *)(base + p.off_ckey);
@@ -772,7 +881,7 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     static LdsLimitSeen seen;      // the pick grid may need more than the default 64 KiB of dynamic LDS
     if (!raise_lds_limit(seen, (const void *)k_sel_sweep, 160 * 1024))
         return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(k_sel_sweep, dim3((unsigned)B), dim3(SW_TPB), p.lds_bytes, st, ws, g, n_picked);
+    hipLaunchKernelGGL(k_sel_sweep, dim3((unsigned)B), dim3(SW_TPB), p.lds_bytes, st, ws, g, n_picked, (const void *)score, dtype == HALO_F64 ? 1 : 0);
     const dim3 ga((unsigned)(cdiv(g.n_regions, 4) < APPLY_WGS ? cdiv(g.n_regions, 4) : APPLY_WGS), (unsigned)B);
     if (dtype == HALO_F64)
         hipLaunchKernelGGL(k_sel_apply<double>, ga, blk, 0, st, (double *)score, active, selected, (long long *)active_mask, (const long long *)gt, picks, ws, g);

@@ -18,7 +18,7 @@ struct BinPlan {
     bool ok;                     // false: the sweep does not serve this geometry (serial kernel only)
     BinGeom g;
     size_t zero_bytes, total_bytes, lds_bytes;
-    size_t off_hdr, off_hist1, off_fcur, off_cbase, off_cm, off_ckey, off_cpos, off_plist;
+    size_t off_hdr, off_hist1, off_fcur, off_okmin, off_okmax, off_cbase, off_cm, off_ckey, off_cpos, off_plist;
 };
 
 BinPlan binned_plan(int64_t B, int64_t H, int64_t W, int64_t n_regions, int64_t arad, int64_t mrad);

@@ -9,7 +9,8 @@ import numpy as np
 
 NB1 = 2048
 SW_SURV = 256
-BIN_CAP = 128     # slots per fine bin (k_sel_place): the sweep stops IN FRONT of a fuller bin and hands the image over from there
+BIN_CAP = 128     # slots per fine bin (k_sel_place): a fuller bin is a plateau of ties -- walked in position order if its candidates
+                  # all carry one key, otherwise the sweep stops in front of it and hands the image over from there
 
 
 def order_key(v):
@@ -26,6 +27,16 @@ def order_key(v):
 
 KEY_NEG_INF = np.uint64(0x000fffffffffffff)
 KEY_POS_INF = np.uint64(0xfff0000000000000)
+
+
+def _hit(grid, y, x, cs, mrad):
+    cy, cx = y // cs, x // cs
+    for a in (-1, 0, 1):
+        for b in (-1, 0, 1):
+            p = grid.get((cy + a, cx + b))
+            if p is not None and abs(p[0] - y) <= mrad and abs(p[1] - x) <= mrad:
+                return True
+    return False
 
 
 def binned_select(score, n_regions, mrad, target=64, captot=None):
@@ -88,9 +99,27 @@ def binned_select(score, n_regions, mrad, target=64, captot=None):
         e = i
         while e < N and f[e] == f[i]:
             e += 1
-        if int(f[i]) in full:                        # a bin that ran out of slots: everything above it is done, the rest is handed over
-            stats["reason"] = "overflow"
-            return "bail", picks, stats
+        if int(f[i]) in full:
+            if len(set(int(q) for q in kk[i:e])) > 1:    # mixed keys in a full bin: everything above it is done, the rest is handed over
+                stats["reason"] = "overflow"
+                return "bail", picks, stats
+            # a plateau of exact ties: priority = position order (smallest w, then smallest h); the kernel walks the map's columns,
+            # here the bin's candidates are sorted by position and taken a piece at a time
+            stats["plateaus"] = stats.get("plateaus", 0) + 1
+            by_pos = sorted(range(i, e), key=lambda q: int(pos[q]))
+            for c0 in range(0, len(by_pos), SW_SURV):
+                piece = by_pos[c0:c0 + SW_SURV]
+                alive = [q for q in piece if not _hit(grid, int(ys[q]), int(xs[q]), cs, mrad)]
+                while alive:
+                    best = min(alive, key=lambda q: int(pos[q]))
+                    y, x = int(ys[best]), int(xs[best])
+                    grid[(y // cs, x // cs)] = (y, x)
+                    picks.append((y, x))
+                    if len(picks) >= n:
+                        return "done", picks, stats
+                    alive = [q for q in alive if not (abs(int(ys[q]) - y) <= mrad and abs(int(xs[q]) - x) <= mrad)]
+            i = e
+            continue
         stats["bins"] += 1
         surv = []
         for q in range(i, e):

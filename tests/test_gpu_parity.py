@@ -2425,8 +2425,9 @@ def test_headline_launch_shape_lowres_sources_batched_vs_oracle(dev):
 
 def test_sweep_hand_over_counters(dev):
     """halo_greedy_select_ex's cost counters: which images the value-binned sweep finished, which it handed to the serial kernel,
-    why, and after how many of its own picks -- with the picks identical to the oracle's either way.  A plateau of exact ties
-    BELOW the values the picks need no longer hands the image over (round 4: any full bin did, from pick 0)."""
+    why, and after how many of its own picks -- with the picks identical to the oracle's either way.  A plateau of exact ties no
+    longer hands the image over (round 4: any full bin did, from pick 0): below the values the picks need it is never reached, and
+    reached it is walked in position order through the map itself."""
     from halo_amd import _lib
     from halo_amd.core.active.build import greedy_select
     from oracle import halo_oracle as ho
@@ -2436,13 +2437,19 @@ def test_sweep_hand_over_counters(dev):
     floor, cap = np.quantile(smooth, 0.5), np.quantile(smooth, 0.997)
     low = smooth.copy(); low[low < floor] = floor                                   # half the map one value, never reached
     mid = smooth.copy(); mid[(mid > floor) & (mid < cap)] = 0.5 * (floor + cap)      # a plateau the picks must cross
+    near = smooth.copy()                                                             # near-ties: distinct keys in one sub-slice of the range
+    m_ = (near > floor) & (near < cap)
+    near[m_] = 0.5 * (floor + cap) + 1e-13 * rng.standard_normal(int(m_.sum()))
+    top = smooth.copy(); top[smooth > np.quantile(smooth, 0.6)] = 7.0                # the plateau IS the top: every pick a tie-break by position
     nan = smooth.copy(); nan[5, 7] = np.nan
     const = np.full((H, W), 0.25)
-    maps = [smooth, low, mid, nan, const]
+    maps = [smooth, low, mid, near, top, nan, const]
     B = len(maps)
     s0 = np.ascontiguousarray(np.stack(maps))
     gt = rng.integers(0, 19, (B, H, W)).astype(np.int64)
-    want_reason = ["done", "done", "bin_overflow", "bad_values", "bad_values"]
+    # a plateau of exact ties reached by the walk is taken in position order by the sweep itself (round 5); only a full bin of MIXED
+    # keys still hands over
+    want_reason = ["done", "done", "done", "bin_overflow", "done", "bad_values", "bad_values"]
     for method in ("auto", "serial"):
         s = t(s0, dev).clone()
         act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
@@ -2562,3 +2569,41 @@ def test_more_handed_over_images_than_resume_workgroups(dev):
         k = int(npk[b])
         assert k == len(po) and bits_equal(picks[b, :k].cpu().numpy(), po), b
         assert np.array_equal(act[b].cpu().numpy(), a_o) and np.array_equal(am[b].cpu().numpy(), m_o), b
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_plateaus_of_exact_ties_are_walked_by_the_sweep(dev, dt):
+    """Exact-tie plateaus at full width: quantised maps (a dozen plateaus, each thousands of pixels, the picks crossing several),
+    a map whose top 40 % is one value, plateaus beside -inf regions and image borders, a batch of them -- picks, masks and the
+    mutated map bit for bit the oracle's, every image finished by the sweep (hand-over reason 'done')."""
+    from halo_amd import _lib
+    from halo_amd.core.active.build import greedy_select
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(77)
+    H, W, mrad = 200, 328, 5
+    base = ho.bilinear(rng.standard_normal((1, H // 8, W // 8)), (H, W))[0]
+    quant = np.round(base * 3) / 3                                                   # ~12 levels
+    top = base.copy(); top[base > np.quantile(base, 0.6)] = 2.5
+    holes = quant.copy(); holes[rng.random((H, W)) < 0.3] = -np.inf                  # ragged plateaus
+    edge = np.full((H, W), -1.0); edge[:, :7] = 1.0; edge[:9, :] = 1.0; edge[-3:, :] = 1.0; edge[:, -4:] = 1.0      # plateaus along the borders
+    edge += 1e-9 * 0
+    maps = [quant, top, holes, edge, np.where(base > 0, 1.0, base)]
+    B = len(maps)
+    s0 = np.ascontiguousarray(np.stack(maps).astype(dt))
+    gt = rng.integers(0, 19, (B, H, W)).astype(np.int64)
+    for n in (40, 700):
+        s = t(s0, dev).clone()
+        act = torch.zeros((B, H, W), dtype=torch.bool, device=dev); sel = torch.zeros_like(act)
+        am = torch.full((B, H, W), 255, dtype=torch.int64, device=dev)
+        hov = torch.full((B, 2), -1, dtype=torch.int32, device=dev)
+        picks, npk = greedy_select(s, n, 1, mrad, act, sel, am, t(gt, dev), handover=hov)
+        hv = hov.cpu().numpy()
+        for b in range(B):
+            so = s0[b].copy()
+            a_o = np.zeros((H, W), bool); s_o = np.zeros((H, W), bool); m_o = np.full((H, W), 255, np.int64)
+            _, _, _, _, po = ho.select_pixels_to_label(so, n, 1, mrad, a_o, s_o, m_o, gt[b], True)
+            k = int(npk[b])
+            assert k == len(po) and bits_equal(picks[b, :k].cpu().numpy(), po), (n, b, k, len(po))
+            assert np.array_equal(act[b].cpu().numpy(), a_o) and np.array_equal(am[b].cpu().numpy(), m_o), (n, b)
+            assert bits_equal(s[b].cpu().numpy(), so), (n, b)
+            assert _lib.SWEEP_REASONS[int(hv[b, 0])] == "done" and hv[b, 1] == k, (n, b, hv[b])

@@ -88,8 +88,9 @@ def test_degenerate_maps_bail_or_finish_correctly():
 
 def test_a_full_bin_only_matters_when_the_sweep_reaches_it():
     """A plateau of exact ties overfills its fine bin.  Below the values the n picks need it is never visited (round 4 handed the
-    whole image over untouched as soon as ANY bin from the threshold bin up was full); in the middle of them the sweep keeps every
-    pick above the plateau and hands over from there."""
+    whole image over untouched as soon as ANY bin from the threshold bin up was full); reached by the walk it is taken in position
+    order -- the reference's tie-break -- and the walk goes on below it; only a full bin of MIXED keys (near-ties denser than the
+    bins resolve) hands the image over, from there."""
     rng = np.random.default_rng(11)
     H, W, mrad = 96, 160, 3
     sc = _smooth(rng, H, W, np.float64) + 1e-3 * rng.standard_normal((H, W))
@@ -98,10 +99,21 @@ def test_a_full_bin_only_matters_when_the_sweep_reaches_it():
     n = 12
     want = _oracle(low, n, mrad)
     status, picks, st = binned_select(low, n, mrad, captot=H * W)      # the plateau's bin is inside the threshold bin's range
-    assert status == "done" and picks == want, st
+    assert status == "done" and picks == want and "plateaus" not in st, st
     cap = np.quantile(sc, 0.97)
     mid = sc.copy(); mid[(mid > floor) & (mid < cap)] = 0.5 * (floor + cap)      # a plateau the picks must cross
-    n = 120
-    want = _oracle(mid, n, mrad)
-    status, picks, st = binned_select(mid, n, mrad, captot=H * W)
-    assert status == "bail" and st["reason"] == "overflow" and 0 < len(picks) < n and picks == want[:len(picks)], (status, st, len(picks))
+    for n in (120, 400):                                       # ends inside the plateau / goes on below it
+        want = _oracle(mid, n, mrad)
+        status, picks, st = binned_select(mid, n, mrad, captot=H * W)
+        assert status == "done" and st.get("plateaus") == 1 and picks == want, (n, status, st, len(picks))
+    top = sc.copy(); top[sc > np.quantile(sc, 0.6)] = 7.0      # the plateau IS the top of the map: every pick a tie-break by position
+    want = _oracle(top, 150, mrad)
+    status, picks, st = binned_select(top, 150, mrad, captot=H * W)
+    assert status == "done" and st.get("plateaus") == 1 and picks == want
+    # near-ties: distinct keys packed into one sub-slice of the value range -> a full bin of mixed keys
+    near = sc.copy()
+    m = (near > floor) & (near < cap)
+    near[m] = 0.5 * (floor + cap) + 1e-13 * rng.standard_normal(int(m.sum()))
+    want = _oracle(near, 120, mrad)
+    status, picks, st = binned_select(near, 120, mrad, captot=H * W)
+    assert status == "bail" and st["reason"] == "overflow" and 0 < len(picks) < 120 and picks == want[:len(picks)], (status, st, len(picks))
