@@ -445,7 +445,10 @@ __device__ __forceinline__ int resolve_bin_parallel(const unsigned long long *sk
 }
 
 // ------------------------------------------------------------------ the sweep
-__global__ void __launch_bounds__(SW_TPB) k_sel_sweep(BinWs ws, BinGeom g, int *__restrict__ n_picked, const void *__restrict__ score_maps,
+// (at most 96 registers: k_feat_reduce's cap leaves 512 - 4 x 104 = 96 per SIMD free, and a sweep workgroup that needs more waits
+// for a CU to drain -- with plateau_scan inlined the compiler took 97, and 16 selections beside the streaming kernel went from 2.5
+// to 3.0 ms)
+__global__ void __launch_bounds__(SW_TPB, 5) k_sel_sweep(BinWs ws, BinGeom g, int *__restrict__ n_picked, const void *__restrict__ score_maps,
                                                       int score_f64)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
