@@ -448,7 +448,7 @@ def parity_slots(R, B, n_rows, want):
     return slots
 
 
-def cpu_baseline(feat, logit, gt, prior, slots, n_regions, branch):
+def cpu_baseline(feat, logit, gt, prior, slots, n_regions, branch, lowres=False, lr_mode="exact"):
     """The CPU oracle (kind 'port': C restatement, OpenMP over all host cores) on ring images `slots` (after one untimed
     warm-up pass over the first of them): score + mask + select, median s/image -> images/s.  Returns every
     image's pick table so the caller can compare them with the rows the TIMED pipeline wrote for the same images."""
@@ -469,7 +469,15 @@ def cpu_baseline(feat, logit, gt, prior, slots, n_regions, branch):
         Hh, Ww = g.shape
         act0 = prior[i].cpu().numpy() if prior is not None else np.zeros((Hh, Ww), bool)
         t0 = time.perf_counter()
-        s, _, _ = ho.floating_region_score(lg, ft, unc, pur, norm, g, size=3, purity_type=pur, K=K)
+        raw = None
+        if lowres:      # the RegionSelection boundary: the reference resizes both head outputs first (build.py:122-135) -- part of the unit
+            lg = ho.bilinear(lg[None], (Hh, Ww))
+            if lr_mode == "gram" and ft.dtype == np.float64:
+                raw = ho.gram_radius(ft[None], (Hh, Ww), "euc_norm" if pur == "euc_norm" else "radius", 1.0)
+                ft = None
+            else:
+                ft = ho.bilinear(ft[None], (Hh, Ww))
+        s, _, _ = ho.floating_region_score(lg, ft, unc, pur, norm, g, size=3, purity_type=pur, K=K, **({"impurity_raw": raw} if raw is not None else {}))
         act = act0.copy(); sel = np.zeros((Hh, Ww), bool); am = np.full((Hh, Ww), 255, np.int64)
         s[act] = -np.inf
         _, _, _, _, pk = ho.select_pixels_to_label(s, n_regions, 1, mrad, act, sel, am, g, True)
@@ -564,7 +572,7 @@ def main():
 
     lowres = a.source == "lowres"
     if lowres:
-        a.cpu_images = 0
+        a.cpu_images = min(a.cpu_images, 2)          # the oracle also resizes (4.3 GB per image at C = 256): a smaller sample
     data = tuple(a.data.split("+"))
     for m_ in data:
         if m_ not in DATA_MODS:
@@ -825,7 +833,7 @@ def main():
                 pass
         if a.cpu_images > 0 and world == 1:
             slots = parity_slots(R, B, n_local, a.cpu_images)
-            s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, prior, slots, n_regions, a.branch)
+            s_img, cores, picks_cpu = cpu_baseline(feat, logit, gt, prior, slots, n_regions, a.branch, lowres, a.lr_mode)
             out["cpu_baseline"] = {"value": round(1.0 / s_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
                                    "sample": "1 warm-up + %d timed ring images (slots %s), oracle/halo_oracle.c (OpenMP, %d threads = usable "
                                              "host cores of %d visible), median s/image = %.2f"

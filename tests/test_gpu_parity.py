@@ -1433,7 +1433,23 @@ def test_bench_contract_on_a_small_shape(dev):
     assert d["roofline"]["traffic"] is None and "12 image evaluations" in d["config"]["workload"]
 
 
-@pytest.mark.parametrize("data", ["late_round", "saturated", "peaked", "late_round+saturated+peaked"])
+@pytest.mark.parametrize("mode", ["exact", "gram"])
+def test_bench_lowres_source_is_oracle_checked_too(dev, mode):
+    """bench.py --source lowres: the timed launches' pick tables against the oracle's upsample-then-score (exact) / Gram twin."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--height", "128", "--width", "256", "--channels", "16",
+                        "--steps", "3", "--warmup", "1", "--batch", "4", "--ring", "8", "--cpu-images", "2", "--source", "lowres",
+                        "--lr-mode", mode], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["parity_vs_cpu"] is True and d["parity_images_checked"] == 2 and d["config"]["lowres_mode"] == mode
+    assert d["cpu_baseline"]["kind"] == "port"
+
+
+@pytest.mark.parametrize("data", ["late_round", "saturated", "peaked", "late_round+saturated+peaked", "plateau"])
 def test_bench_data_variants_on_a_small_shape(dev, data):
     """bench.py --data: the value distributions that stress the selector (half the map already active, projected radii,
     saturated softmax) -- the timed tables still equal the oracle's and the hand-over counters are reported."""
