@@ -612,23 +612,25 @@ __global__ void __launch_bounds__(SW_TPB, 5) k_sel_sweep(BinWs ws, BinGeom g, in
         ++nb;
 #endif
     };
-    // ---- a plateau of exact ties, walked through the map itself.  Bin `fb` received more candidates than it has slots.  If they all
-    // carry ONE key V (its stored candidates and the extrema of the dropped ones agree), their priority order is the order of
-    // their positions -- smallest w, then smallest h: the reference's tie-break (build.py:38-43) -- so the bin's candidates in
-    // priority order are the pixels with key V in column-major order, and the map says which those are: no list of them is needed.
-    // The workgroup walks the columns, PL_PP positions per thread and trip (a column of 1024 rows per trip at 1024 x 2048), tests the
-    // members against the pick grid and lists the survivors; the list is resolved when it holds 32 or the trip's survivors do not
-    // fit it (then the trip is redone piece by piece behind a resolve: a piece is at most SW_TPB <= SW_SURV positions).  Listing
-    // survivors of several trips before resolving them changes no pick, exactly as merging bins does not.  Mixed keys in a full bin
-    // (near-ties denser than 128 per sub-slice) are not handled: the image is handed over from here.
-    constexpr int PL_PP = 4;
+    // ---- a plateau of exact ties, walked through the map itself.  Bin `fb` received more candidates than it has slots.  Candidates
+    // that carry ONE key are ordered by their positions -- smallest w, then smallest h: the reference's tie-break (build.py:38-43)
+    // -- so in priority order they are simply the pixels of the map with that key in column-major order, and the map says which
+    // those are: no list of them is needed.  The bin's keys lie between the extrema of its stored and its dropped candidates, and
+    // every pixel whose key lies in that range belongs to the bin (binning is monotone in the value).  So: starting with the bin's
+    // largest key K, the workgroup walks the map's columns -- PL_PP positions per thread and trip (half a column of 1024 rows per trip at
+    // 1024 x 2048), the next trip's loads in flight --, tests the pixels with key K against the pick grid and lists the survivors
+    // (resolved when the list holds 32, or when a trip's survivors do not fit it: the trip is then redone piece by piece behind a
+    // resolve, a piece being at most SW_TPB <= SW_SURV positions), and notes the largest key below K it meets in the bin's range:
+    // the next K.  Listing survivors of several trips before resolving them changes no pick, exactly as merging bins does not.
+    // A plateau and a few stragglers in its sub-slice of the value range take PL_KEYS passes at most; a bin with more distinct keys
+    // than that (dense near-ties) hands the image over from where the walk stands.
+    constexpr int PL_PP = 2, PL_KEYS = 4;      // (PL_PP = 4 pushes the kernel past its 96 registers: 76 bytes of scratch in the main path)
     auto plateau_scan = [&](unsigned fb) {
-        const unsigned long long V = ckey[(size_t)fb * BIN_CAP];
-        bool pure = okmax[fb] == V && ~okmin_inv[fb] == V;
-        pure = pure && ckey[(size_t)fb * BIN_CAP + lane] == V && ckey[(size_t)fb * BIN_CAP + 64 + lane] == V;      // BIN_CAP = 128 stored candidates
-        if (!__all(pure)) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; return; }      // (every wave sees the same data: the same verdict)
+        // key range of the bin: its BIN_CAP = 128 stored candidates (two per lane; every wave computes the same) and the dropped ones
+        const unsigned long long s0 = ckey[(size_t)fb * BIN_CAP + lane], s1 = ckey[(size_t)fb * BIN_CAP + 64 + lane];
+        unsigned long long kmax_b = wave_max_u64(s0 > s1 ? s0 : s1), kmin_b = ~wave_max_u64(~(s0 < s1 ? s0 : s1));
+        { const unsigned long long a = okmax[fb], bmin = ~okmin_inv[fb]; kmax_b = a > kmax_b ? a : kmax_b; kmin_b = bmin < kmin_b ? bmin : kmin_b; }
         const unsigned P = (unsigned)g.H * (unsigned)g.W, GP = SW_TPB * PL_PP;
-        unsigned listed = 0;                                                       // survivors in the list (uniform)
         auto fetch = [&](unsigned g0, unsigned long long (&kk)[PL_PP], unsigned (&pp)[PL_PP]) {
 #pragma unroll
             for (int i = 0; i < PL_PP; ++i) {
@@ -637,37 +639,60 @@ __global__ void __launch_bounds__(SW_TPB, 5) k_sel_sweep(BinWs ws, BinGeom g, in
                 const unsigned w_ = pc / (unsigned)g.H, h_ = pc - w_ * (unsigned)g.H;
                 const size_t o = (size_t)h_ * g.W + w_;
                 const double v = map64 ? map64[o] : (double)map32[o];
-                kk[i] = pidx < P ? order_key(v) : 0ull;                            // 0: below every real key, never V
+                kk[i] = pidx < P ? order_key(v) : 0ull;                            // 0: below every real key
                 pp[i] = (w_ << 16) | h_;
             }
         };
-        unsigned long long kc[PL_PP], kn[PL_PP];
-        unsigned pc_[PL_PP], pn[PL_PP];
-        fetch(0u, kc, pc_);
-        for (unsigned g0 = 0; g0 < P && !fin; g0 += GP) {
-            fetch(g0 + GP < P ? g0 + GP : g0, kn, pn);                             // the next trip's keys are in flight during this one
-#pragma unroll
-            for (int i = 0; i < PL_PP; ++i) push(kc[i] == V && grid_alive(pc_[i]), kc[i], pc_[i]);
-            lds_barrier();
-            const unsigned total = ctl[0];
-            if (total > (unsigned)SW_SURV) {
-                lds_barrier();                                                     // everybody has read the count
-                if (tid == 0) ctl[0] = listed;                                     // forget this trip's survivors ...
-                resolve_listed();                                                  // ... take the ones listed before it ...
+        unsigned long long K = kmax_b;
 #pragma unroll 1
-                for (int i = 0; i < PL_PP && !fin; ++i) {                          // ... and redo the trip one piece at a time
-                    push(kc[i] == V && grid_alive(pc_[i]), kc[i], pc_[i]);
-                    resolve_listed();
-                }
-                listed = 0;
-            } else {
-                listed = total;
-                if (listed >= 32u) { resolve_listed(); listed = 0; }
-            }
+        for (int pass = 0; !fin; ++pass) {
+            if (pass == PL_KEYS) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; break; }       // more distinct keys than passes: hand over
+            unsigned listed = 0;                                                       // survivors in the list (uniform)
+            unsigned long long knext = 0ull;                                           // largest key of the bin below K seen by this thread
+            unsigned long long kc[PL_PP], kn[PL_PP];
+            unsigned pc_[PL_PP], pn[PL_PP];
+            fetch(0u, kc, pc_);
+            for (unsigned g0 = 0; g0 < P && !fin; g0 += GP) {
+                fetch(g0 + GP < P ? g0 + GP : g0, kn, pn);                             // the next trip's keys are in flight during this one
 #pragma unroll
-            for (int i = 0; i < PL_PP; ++i) { kc[i] = kn[i]; pc_[i] = pn[i]; }
+                for (int i = 0; i < PL_PP; ++i) {
+                    push(kc[i] == K && grid_alive(pc_[i]), kc[i], pc_[i]);
+                    knext = (kc[i] < K && kc[i] >= kmin_b && kc[i] > knext) ? kc[i] : knext;
+                }
+                lds_barrier();
+                const unsigned total = ctl[0];
+                if (total > (unsigned)SW_SURV) {
+                    lds_barrier();                                                     // everybody has read the count
+                    if (tid == 0) ctl[0] = listed;                                     // forget this trip's survivors ...
+                    resolve_listed();                                                  // ... take the ones listed before it ...
+#pragma unroll 1
+                    for (int i = 0; i < PL_PP && !fin; ++i) {                          // ... and redo the trip one piece at a time
+                        push(kc[i] == K && grid_alive(pc_[i]), kc[i], pc_[i]);
+                        resolve_listed();
+                    }
+                    listed = 0;
+                } else {
+                    listed = total;
+                    if (listed >= 32u) { resolve_listed(); listed = 0; }
+                }
+#pragma unroll
+                for (int i = 0; i < PL_PP; ++i) { kc[i] = kn[i]; pc_[i] = pn[i]; }
+            }
+            if (fin) break;
+            if (listed) resolve_listed();
+            if (fin) break;
+            // the next key of the bin: the block's maximum of what its threads met (the survivor list is empty: its first words carry it)
+            knext = wave_max_u64(knext);
+            lds_barrier();
+            if (lane == 0) skey[wave] = knext;
+            lds_barrier();
+            knext = skey[0];
+#pragma unroll
+            for (int i = 1; i < SW_TPB / 64; ++i) knext = skey[i] > knext ? skey[i] : knext;
+            lds_barrier();                                                             // read before the next pass lists survivors there
+            if (knext == 0ull) break;                                                  // the bin is exhausted: on with the bins below it
+            K = knext;
         }
-        if (!fin && listed) resolve_listed();
     };
     // one chunk: filter against the pick grid, survivors -> LDS list; at the end of a bin wave 0 resolves the survivors
     auto step = [&](const Chunk &c, const Regs &d) {

@@ -9,6 +9,7 @@ import numpy as np
 
 NB1 = 2048
 SW_SURV = 256
+PL_KEYS = 4       # distinct keys of a full bin the sweep walks before it hands over
 BIN_CAP = 128     # slots per fine bin (k_sel_place): a fuller bin is a plateau of ties -- walked in position order if its candidates
                   # all carry one key, otherwise the sweep stops in front of it and hands the image over from there
 
@@ -100,24 +101,27 @@ def binned_select(score, n_regions, mrad, target=64, captot=None):
         while e < N and f[e] == f[i]:
             e += 1
         if int(f[i]) in full:
-            if len(set(int(q) for q in kk[i:e])) > 1:    # mixed keys in a full bin: everything above it is done, the rest is handed over
-                stats["reason"] = "overflow"
-                return "bail", picks, stats
-            # a plateau of exact ties: priority = position order (smallest w, then smallest h); the kernel walks the map's columns,
-            # here the bin's candidates are sorted by position and taken a piece at a time
+            # a bin that ran out of slots: its distinct keys in descending order, each one's candidates in POSITION order (smallest
+            # w, then smallest h: ties) -- the kernel walks the map's columns once per key, here the bin's candidates are sorted; more
+            # than PL_KEYS distinct keys (dense near-ties) hand the image over from where the walk stands
             stats["plateaus"] = stats.get("plateaus", 0) + 1
-            by_pos = sorted(range(i, e), key=lambda q: int(pos[q]))
-            for c0 in range(0, len(by_pos), SW_SURV):
-                piece = by_pos[c0:c0 + SW_SURV]
-                alive = [q for q in piece if not _hit(grid, int(ys[q]), int(xs[q]), cs, mrad)]
-                while alive:
-                    best = min(alive, key=lambda q: int(pos[q]))
-                    y, x = int(ys[best]), int(xs[best])
-                    grid[(y // cs, x // cs)] = (y, x)
-                    picks.append((y, x))
-                    if len(picks) >= n:
-                        return "done", picks, stats
-                    alive = [q for q in alive if not (abs(int(ys[q]) - y) <= mrad and abs(int(xs[q]) - x) <= mrad)]
+            keys_desc = sorted(set(int(q) for q in kk[i:e]), reverse=True)
+            for npass, kval in enumerate(keys_desc):
+                if npass == PL_KEYS:
+                    stats["reason"] = "overflow"
+                    return "bail", picks, stats
+                by_pos = sorted((q for q in range(i, e) if int(kk[q]) == kval), key=lambda q: int(pos[q]))
+                for c0 in range(0, len(by_pos), SW_SURV):
+                    piece = by_pos[c0:c0 + SW_SURV]
+                    alive = [q for q in piece if not _hit(grid, int(ys[q]), int(xs[q]), cs, mrad)]
+                    while alive:
+                        best = min(alive, key=lambda q: int(pos[q]))
+                        y, x = int(ys[best]), int(xs[best])
+                        grid[(y // cs, x // cs)] = (y, x)
+                        picks.append((y, x))
+                        if len(picks) >= n:
+                            return "done", picks, stats
+                        alive = [q for q in alive if not (abs(int(ys[q]) - y) <= mrad and abs(int(xs[q]) - x) <= mrad)]
             i = e
             continue
         stats["bins"] += 1
