@@ -58,7 +58,7 @@ struct BinWs {
     unsigned *fcur;                          // nfmax: candidates placed in each fine bin
     unsigned long long *ckey;                // nfmax * BIN_CAP: bin f owns slots [f * BIN_CAP, (f + 1) * BIN_CAP)
     unsigned *cpos;                          // nfmax * BIN_CAP
-    unsigned long long *okmin_inv, *okmax;   // nfmax each: max of ~key / of key over the candidates that found their bin full (zero = none)
+    unsigned long long *okmin_inv, *okmax;   // nfmax each: max of ~key / of key over the candidates of the bins that ran out of slots (zero = none)
     unsigned *plist;                         // n_regions: picks as (w << 16) | h
     int *handover;                           // optional (B, 2): {HALO_SWEEP_* reason, picks the sweep made}; NULL = not reported
 };
@@ -252,7 +252,6 @@ __global__ void __launch_bounds__(256) k_sel_place(const T *__restrict__ score, 
     unsigned *fcur = ws.fcur + (size_t)b * g.nfmax;
     unsigned long long *ckey = ws.ckey + (size_t)b * g.nfmax * BIN_CAP;
     unsigned *cpos = ws.cpos + (size_t)b * g.nfmax * BIN_CAP;
-    unsigned long long *okmin_inv = ws.okmin_inv + (size_t)b * g.nfmax, *okmax = ws.okmax + (size_t)b * g.nfmax;
     bool overflow = false;
     // PL_U row segments per iteration: their loads and their returned atomics are in flight together (beside a
     // bandwidth-bound kernel each dependent round trip costs microseconds)
@@ -282,47 +281,97 @@ __global__ void __launch_bounds__(256) k_sel_place(const T *__restrict__ score, 
                     f[u] = s_base[j] + (mj - 1 - sb);
                 }
             }
-            // One returned atomic per candidate -- or, where every candidate of the wave goes to the SAME bin (a plateau of ties:
-            // half a million atomics on one counter otherwise), one per wave: the first candidate lane adds the wave's count and the
-            // lanes take consecutive slots behind its return value.
+            // One returned atomic per candidate -- unless ALL candidates of the wave in this trip go to one bin (a plateau of ties: half a
+            // million atomics on one counter otherwise, 18 ms per 16 such images): then one atomic for the wave's count, checked once
+            // per trip with scalar bookkeeping only (a per-candidate version of this test cost 10-20 registers and with them the
+            // second wave per SIMD beside the feature kernel: 850 -> 1340 us per 16 ordinary images).
             unsigned long long cm[PL_U];
-            bool agg[PL_U];
-            int lead[PL_U];
+            unsigned f_first = 0u, tot = 0u;
+            cm[0] = __ballot(cand[0]);
+            bool uni = __builtin_popcountll(cm[0]) >= 32;                       // ordinary maps leave here: one ballot, one count
+            if (uni) {
+                f_first = (unsigned)__builtin_amdgcn_readlane((int)f[0], (int)__builtin_ctzll(cm[0]));
+                tot = (unsigned)__builtin_popcountll(cm[0]);
 #pragma unroll
-            for (int u = 0; u < PL_U; ++u) {
-                cm[u] = __ballot(cand[u]);
-                lead[u] = cm[u] ? (int)__builtin_ctzll(cm[u]) : 0;
-                const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)f[u], lead[u]);
-                agg[u] = cm[u] != 0ull && (cm[u] & (cm[u] - 1ull)) != 0ull && __ballot(cand[u] && f[u] == f0) == cm[u];
-                const bool mine = cand[u] && (!agg[u] || (tid & 63) == lead[u]);
-                slot[u] = mine ? atomicAdd(&fcur[f[u]], agg[u] ? (unsigned)__builtin_popcountll(cm[u]) : 1u) : 0u;      // PL_U returns in flight
+                for (int u = 1; u < PL_U; ++u) { cm[u] = __ballot(cand[u]); tot += (unsigned)__builtin_popcountll(cm[u]); }
+#pragma unroll
+                for (int u = 0; u < PL_U; ++u) uni = uni && __ballot(cand[u] && f[u] != f_first) == 0ull;
+            }
+            if (uni) {
+                unsigned base = 0u;
+                if ((tid & 63) == 0) base = atomicAdd(&fcur[f_first], tot);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+                for (int u = 0; u < PL_U; ++u) {
+                    slot[u] = base + __builtin_amdgcn_mbcnt_hi((unsigned)(cm[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm[u], 0u));
+                    base += (unsigned)__builtin_popcountll(cm[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < PL_U; ++u) slot[u] = cand[u] ? atomicAdd(&fcur[f[u]], 1u) : 0u;      // PL_U returns in flight
             }
 #pragma unroll
             for (int u = 0; u < PL_U; ++u)
-                if (agg[u]) {
-                    const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)slot[u], lead[u]);
-                    slot[u] = base + __builtin_amdgcn_mbcnt_hi((unsigned)(cm[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm[u], 0u));
+                if (cand[u]) {
+                    if (slot[u] < (unsigned)BIN_CAP) {
+                        const size_t sl = (size_t)f[u] * BIN_CAP + slot[u];
+                        ckey[sl] = k[u];
+                        cpos[sl] = ((unsigned)(x0 + u * 256 + tid) << 16) | (unsigned)y;
+                    } else overflow = true;
                 }
-#pragma unroll
-            for (int u = 0; u < PL_U; ++u) {
-                const bool full = cand[u] && slot[u] >= (unsigned)BIN_CAP;
-                if (cand[u] && !full) {
-                    const size_t sl = (size_t)f[u] * BIN_CAP + slot[u];
-                    ckey[sl] = k[u];
-                    cpos[sl] = ((unsigned)(x0 + u * 256 + tid) << 16) | (unsigned)y;
-                }
-                overflow = overflow || full;
-                // a candidate that found its bin full is dropped, but its key is remembered in the bin's extrema: a full bin whose
-                // candidates ALL carry one key is a plateau of exact ties, which the sweep walks through the map itself
-                if (__any(full)) {
-                    if (agg[u]) {
-                        const unsigned long long kx = wave_max_u64(full ? k[u] : 0ull), kn = wave_max_u64(full ? ~k[u] : 0ull);
-                        if ((tid & 63) == lead[u]) { atomicMax(&okmax[f[u]], kx); atomicMax(&okmin_inv[f[u]], kn); }
-                    } else if (full) { atomicMax(&okmax[f[u]], k[u]); atomicMax(&okmin_inv[f[u]], ~k[u]); }
-                }
-            }
         }
     if (__any(overflow) && (tid & 63) == 0) atomicOr(&hdr->flags, (unsigned)SEL_F_OVERFLOW);
+}
+
+// ------------------------------------------------------------------ key extrema of the bins that ran out of slots
+// Only for images in which k_sel_place dropped a candidate (SEL_F_OVERFLOW: a plateau of ties; the launch returns at once otherwise):
+// one more pass over the map with the same binning arithmetic, and every candidate whose bin is full adds its key to the bin's
+// extrema -- the lanes of a wave that share a bin reduce their keys first and send ONE pair of atomics (a plateau: all 64 lanes, one
+// bin).  The sweep walks such a bin through the map itself, key by key, between those extrema.  (A first version kept the extrema in
+// k_sel_place itself, with one slot atomic per wave for plateaus: 48 -> 58-70 registers, one wave per SIMD instead of two beside
+// the feature kernel, 850 -> 1340 us per 16 ordinary images.)
+template <typename T>
+__global__ void __launch_bounds__(256) k_sel_full_extrema(const T *__restrict__ score, BinWs ws, BinGeom g)
+{
+    __shared__ unsigned s_base[NB1], s_m[NB1];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const SelHdr *hdr = ws.hdr + b;
+    if (!(hdr->flags & SEL_F_OVERFLOW)) return;
+    const ValRange r = sel_range(ws.rng[b]);
+    const unsigned t1 = hdr->t1;
+    if (!r.ok || t1 >= NB1) return;
+    for (int j = tid; j < NB1; j += 256) { s_base[j] = ws.cbase[(size_t)b * NB1 + j]; s_m[j] = ws.cm[(size_t)b * NB1 + j]; }
+    __syncthreads();
+    const T *sc = score + (size_t)b * g.H * g.W;
+    const unsigned *fcur = ws.fcur + (size_t)b * g.nfmax;
+    unsigned long long *okmin_inv = ws.okmin_inv + (size_t)b * g.nfmax, *okmax = ws.okmax + (size_t)b * g.nfmax;
+    for (int y = blockIdx.x; y < g.H; y += gridDim.x)
+        for (int x0 = 0; x0 < g.W; x0 += 256) {
+            const int x = x0 + tid;
+            const double v = x < g.W ? (double)sc[(size_t)y * g.W + x] : __longlong_as_double(0xfff0000000000000ll);
+            const unsigned long long k = order_key(v);
+            bool cand = k < KEY_POS_INF && k != KEY_NEG_INF;
+            double t = 0.0;
+            const int j = cand ? coarse_bin(v, r, t) : 0;
+            cand = cand && (unsigned)j >= t1;
+            unsigned f = 0;
+            if (cand) {
+                const unsigned mj = s_m[j];
+                unsigned sb = (unsigned)((t - (double)j) * (double)mj);
+                sb = sb > mj - 1 ? mj - 1 : sb;
+                f = s_base[j] + (mj - 1 - sb);
+            }
+            const bool full = cand && fcur[f] > (unsigned)BIN_CAP;
+            unsigned long long todo = __ballot(full);
+            while (todo) {
+                const int l0 = (int)__builtin_ctzll(todo);
+                const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)f, l0);
+                const bool mine = full && f == f0;
+                const unsigned long long kx = wave_max_u64(mine ? k : 0ull), kn = wave_max_u64(mine ? ~k : 0ull);
+                if ((tid & 63) == l0) { atomicMax(&okmax[f0], kx); atomicMax(&okmin_inv[f0], kn); }
+                todo &= ~__ballot(mine);
+            }
+        }
 }
 
 // ------------------------------------------------------------------ resolve one bin (one wave)
@@ -626,10 +675,9 @@ __global__ void __launch_bounds__(SW_TPB, 5) k_sel_sweep(BinWs ws, BinGeom g, in
     // than that (dense near-ties) hands the image over from where the walk stands.
     constexpr int PL_PP = 2, PL_KEYS = 4;      // (PL_PP = 4 pushes the kernel past its 96 registers: 76 bytes of scratch in the main path)
     auto plateau_scan = [&](unsigned fb) {
-        // key range of the bin: its BIN_CAP = 128 stored candidates (two per lane; every wave computes the same) and the dropped ones
-        const unsigned long long s0 = ckey[(size_t)fb * BIN_CAP + lane], s1 = ckey[(size_t)fb * BIN_CAP + 64 + lane];
-        unsigned long long kmax_b = wave_max_u64(s0 > s1 ? s0 : s1), kmin_b = ~wave_max_u64(~(s0 < s1 ? s0 : s1));
-        { const unsigned long long a = okmax[fb], bmin = ~okmin_inv[fb]; kmax_b = a > kmax_b ? a : kmax_b; kmin_b = bmin < kmin_b ? bmin : kmin_b; }
+        // key range of the bin (k_sel_full_extrema: over ALL its candidates, stored or dropped)
+        const unsigned long long kmax_b = okmax[fb], kmin_b = ~okmin_inv[fb];
+        if (kmax_b == 0ull) { fin = 2; why = HALO_SWEEP_BIN_OVERFLOW; return; }      // (no extrema recorded: cannot happen for a full bin)
         const unsigned P = (unsigned)g.H * (unsigned)g.W, GP = SW_TPB * PL_PP;
         auto fetch = [&](unsigned g0, unsigned long long (&kk)[PL_PP], unsigned (&pp)[PL_PP]) {
 #pragma unroll
@@ -906,6 +954,11 @@ int binned_select(void *score, int dtype, int64_t B, const BinPlan &p, uint8_t *
     hipLaunchKernelGGL(k_sel_scan1, dim3((unsigned)B), blk, 0, st, ws, g);
     if (dtype == HALO_F64) hipLaunchKernelGGL(k_sel_place<double>, dim3(gy, (unsigned)B), blk, 0, st, (const double *)score, ws, g);
     else hipLaunchKernelGGL(k_sel_place<float>, dim3(gy, (unsigned)B), blk, 0, st, (const float *)score, ws, g);
+    {   // rare: the extrema of bins that ran out of slots (returns at once unless k_sel_place flagged the image)
+        const dim3 ge((unsigned)(g.H < 64 ? g.H : 64), (unsigned)B);
+        if (dtype == HALO_F64) hipLaunchKernelGGL(k_sel_full_extrema<double>, ge, blk, 0, st, (const double *)score, ws, g);
+        else hipLaunchKernelGGL(k_sel_full_extrema<float>, ge, blk, 0, st, (const float *)score, ws, g);
+    }
     static LdsLimitSeen seen;      // the pick grid may need more than the default 64 KiB of dynamic LDS
     if (!raise_lds_limit(seen, (const void *)k_sel_sweep, 160 * 1024))
         return fail(HALO_E_LAUNCH, "halo_greedy_select: cannot raise the dynamic LDS limit");
