@@ -613,11 +613,70 @@ constexpr int MLRP_TPB = 512, MLRP_SK = 4, MLRP_RING = 4;
 #define MLR_RCP(x) fast_rcp(x)
 #define MLR_ASINH(x) asinh_fast(x)
 #endif
+// hyperbolic.py:146-181 in the reference's own order (alpha, beta, the norm of the Mobius sum, its projection, lambda) for one
+// (pixel, class): returns asinh(sineterm).  The matrix-core kernel's epilogue until round 5; now its rare arm and its A/B twin.
+__device__ __forceinline__ double mlr_epilogue_ref(double px, double xa, double ppo, double pao, double xx, double Kxx, double KxxK,
+                                                   double K, double sqK, double maxnorm)
+{
+    const double sqsq = KxxK * ppo;
+    const double base = 1.0 + (2.0 * K) * px;
+    const double Aa = base + Kxx;
+    const double Bb = 1.0 - K * ppo;
+    const double rD = MLR_RCP(clamp_min_nanprop(base + sqsq, 1e-12));   // one reciprocal for alpha and beta
+    const double al = Aa * rD, be = Bb * rD;
+    const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
+    const double sq = __builtin_sqrt(mob);
+    const double pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;
+    const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
+    const double md = (be * xa + al * pao) * pn;
+    const double lamb = 2.0 * MLR_RCP(clamp_min_nanprop(1.0 - K * mp, 1e-12));
+    return MLR_ASINH((sqK * md) * lamb);
+}
+// 1/b, 1/sqrt(b), sqrt(b) for b finite, positive and of ordinary magnitude (no specials: the callers test their operands): the
+// hardware estimate (v_rcp_f64 / v_rsq_f64, relative error e0 <= 2^-23) corrected through the SECOND-order term of its own
+// residual -- r0 (1 + e + e^2), y0 (1 + e/2 + 3 e^2 / 8) -- so that ONE step leaves O(e0^3) < 2^-64 and the result is the rounding
+// of the last fma (<= 1 ulp); the IEEE sequences hipcc emits (scaling, two steps, fix-up) are 12-15 instructions each.
+__device__ __forceinline__ double rcp_q(double b)
+{
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e = __builtin_fma(-b, r0, 1.0);
+    return __builtin_fma(__builtin_fma(e, e, e), r0, r0);
+}
+__device__ __forceinline__ double rsqrt_q(double b)
+{
+    const double y0 = __builtin_amdgcn_rsq(b);
+    const double e = __builtin_fma(-(b * y0), y0, 1.0);
+    return __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
+}
+__device__ __forceinline__ double sqrt_q(double b) { return b * rsqrt_q(b); }
+// log_ge1_fast with its quotient through rcp_q (2 + f in [2.41, 3.42))
+__device__ __forceinline__ double log_ge1_q(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    u = ((uint64_t)hx << 32) | (u & 0xffffffffull);
+    const double f = __longlong_as_double((long long)u) - 1.0;
+    const double hfsq = (0.5 * f) * f;
+    const double s = f * rcp_q(2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1, dk = (double)k;
+    return __builtin_fma(dk, ln2_hi, (f - (hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo))));
+}
 
 template <typename TOUT, int NT>
 __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__restrict__ x, const double *__restrict__ consts,
                                                                 int O, int C, int wstride, long long hw, long long tiles_per_img,
-                                                                long long ntiles, double K, TOUT *__restrict__ out)
+                                                                long long ntiles, double K, TOUT *__restrict__ out, int force_ref)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
     double *wts = reinterpret_cast<double *>(smem_m);                                        // [2*O][wstride]: rows -P 0..O-1, then A^ 0..O-1
@@ -646,6 +705,8 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
         wrow[n] = ((isA ? O : 0) + (cls < O ? cls : 0)) * wstride;
     }
     const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
+    const double K2 = 2.0 * K, maxn2 = maxnorm * maxnorm, c_in = 2.0 * sqK, oscale = 2.0 / sqK,
+                 c_out = (sqK * maxnorm) * (2.0 / (1.0 - K * maxn2));      // sqrt(K) maxnorm lamb(maxnorm^2)
     double *pxs = stage + (size_t)wave * (2 * O * 32 + 32), *xas = pxs + O * 32, *xs = xas + O * 32;
     // x operands travel through a register ring of MLRP_RING stages of MLRP_SK k-steps (16 channels) each: the loads
     // of stage s + RING - 1 are issued before the MFMAs of stage s, and the stream of stages runs ACROSS tile
@@ -750,22 +811,33 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
             const int sl = o * 32 + ((q + o) & 31);
             const double px = pxs[sl], xa = xas[sl];
             const double ppo = pp[o], ano = anorm[o], pao = pa[o];
-            const double sqsq = KxxK * ppo;
-            const double base = 1.0 + (2.0 * K) * px;
+            // ---- ONE quotient per logit (round 5).  With A = 1 + 2K px + K xx, B = 1 - K pp, D = 1 + 2K px + K^2 xx pp the reference's
+            // alpha = A/D, beta = B/D give  mob = N / D^2,  N = A^2 pp + B^2 xx + 2AB px,  and  mobdota = M / D,  M = B xa + A pa:
+            //   inside the ball (N < maxnorm^2 D^2):  sine = sqrt(K) (M/D) 2 / (1 - K N/D^2)           = 2 sqrt(K) M D / (D^2 - K N)
+            //   beyond it (projected onto maxnorm):   sine = sqrt(K) (M/D) (maxnorm D / sqrt(N)) lamb_max = sqrt(K) lamb_max maxnorm M / sqrt(N)
+            // -- the same real-number function as hyperbolic.py:146-181 (both arms are continuous across the boundary, so WHICH side a
+            // pixel within an ulp of it lands on moves the logit by an ulp), evaluated with one refined reciprocal (or reciprocal
+            // square root) instead of two reciprocals, a square root and a comparison of roots.  The clamps of the reference cannot
+            // act here: D >= 1e-12 is tested (anything else -- NaN included -- takes the reference-order statement below), and
+            // 1 - K mob > 1 - K maxnorm^2 = 2e-3 inside the ball.  asinh(s) = log(|s| + sqrt(1 + s^2)): absolute error <= 2 ulp(1)
+            // (the logits carry no relative contract near zero: tolerance 1e-10 absolute, tests/test_gpu_parity.py).
+            const double base = __builtin_fma(K2, px, 1.0);
             const double Aa = base + Kxx;
-            const double Bb = 1.0 - K * ppo;
-            // (quotients through fast_rcp, halo_devmath.hpp: no bit-level contract on the logits; HALO_MLR_IEEE builds keep the IEEE forms)
-            const double rD = MLR_RCP(clamp_min_nanprop(base + sqsq, 1e-12));   // one reciprocal for alpha and beta
-            const double al = Aa * rD, be = Bb * rD;
-            const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
-            const double sq = __builtin_sqrt(mob);
-            double pn = 1.0;
-            if (__any(sq > maxnorm)) pn = sq > maxnorm ? maxnorm / clamp_min_nanprop(sq, 1e-12) : 1.0;   // rare: beyond the ball
-            const double mp = sq < maxnorm ? mob : maxnorm * maxnorm;
-            const double md = (be * xa + al * pao) * pn;
-            const double lamb = 2.0 * MLR_RCP(clamp_min_nanprop(1.0 - K * mp, 1e-12));
-            const double sine = (sqK * md) * lamb;
-            if (p_ < hw) outp[(size_t)o * hw] = (TOUT)(((2.0 / sqK) * ano) * MLR_ASINH(sine));
+            const double D = __builtin_fma(KxxK, ppo, base);
+            const double Bb = __builtin_fma(-K, ppo, 1.0);
+            const double N = __builtin_fma(Aa * Aa, ppo, __builtin_fma(Bb * Bb, xx, ((2.0 * Aa) * Bb) * px));
+            const double M = __builtin_fma(Bb, xa, Aa * pao);
+            const double D2 = D * D;
+            const bool inside = N < maxn2 * D2;
+            double G = (c_in * D) * rcp_q(__builtin_fma(-K, N, D2));
+            if (__any(!inside)) G = inside ? G : c_out * rsqrt_q(N);                    // wave-uniform skip: no pixel of the wave beyond the ball
+            const double sine = M * G, a = __builtin_fabs(sine);
+            double res = __builtin_copysign(log_ge1_q(a + sqrt_q(__builtin_fma(a, a, 1.0))), sine);
+            if (force_ref || __any(!(D >= 1e-12 && a < 1e150))) {                       // never in a trained head: clamped D, NaN / inf, |sine| ~ 1e150
+                const double ref = mlr_epilogue_ref(px, xa, ppo, pao, xx, Kxx, KxxK, K, sqK, maxnorm);
+                res = (force_ref || !(D >= 1e-12 && a < 1e150)) ? ref : res;
+            }
+            if (p_ < hw) outp[(size_t)o * hw] = (TOUT)((oscale * ano) * res);
         }
         __builtin_amdgcn_wave_barrier();      // the next tile's accumulators reuse the staging rows
         cur = nxt;
@@ -1103,13 +1175,14 @@ extern "C" int halo_hypermlr_logits(const double *x, const double *P, const doub
             const long long tiles_per_img = cdiv(hw, 32), ntiles = tiles_per_img * B;
             long long gx = cdiv(ntiles, MLRP_TPB / 64);
             gx = gx > 256 ? 256 : gx;                                              // one resident workgroup per CU, persistent over tiles
+            const int force_ref = getenv("HALO_MLR_EPI_REF") != nullptr;        // A/B and test switch: the reference-order epilogue for every logit
 #define HALO_MLRP(T, NT_)                                                                                                          \
     {                                                                                                                             \
         static LdsLimitSeen seen;                                                                                                 \
         if (!raise_lds_limit(seen, (const void *)k_hypermlr_mfma_res<T, NT_>, 160 * 1024))                                        \
             return fail(HALO_E_LAUNCH, "halo_hypermlr_logits: cannot raise the dynamic LDS limit");                               \
         hipLaunchKernelGGL((k_hypermlr_mfma_res<T, NT_>), dim3((unsigned)gx), dim3(MLRP_TPB), lds, st, x, (const double *)consts, (int)O, \
-                           (int)C, wstride, (long long)hw, tiles_per_img, ntiles, c, (T *)out);                                   \
+                           (int)C, wstride, (long long)hw, tiles_per_img, ntiles, c, (T *)out, force_ref);                        \
     }
             if (out_dtype == HALO_F32) { if (NT == 2) HALO_MLRP(float, 2) else if (NT == 3) HALO_MLRP(float, 3) else HALO_MLRP(float, 4) }
             else { if (NT == 2) HALO_MLRP(double, 2) else if (NT == 3) HALO_MLRP(double, 3) else HALO_MLRP(double, 4) }

@@ -48,22 +48,27 @@ def line(tag, nbytes, fn):
     print(f"{tag:78s} eager {e * 1e3:7.1f} us   graph {g * 1e3:7.1f} us   {nbytes / g / 1e6:6.0f} GB/s   frac {nbytes / g / 1e6 / 8000:.2f}", flush=True)
 
 
-m = HyperMapper(1.0)
-O = 19
-for (tag, C, h, w, up) in (("v3+ head", 64, 160, 320, (640, 1280)), ("v2 head", 64, 640, 1280, (1024, 2048)), ("bench pool", 256, 256, 512, (1024, 2048))):
-    z = torch.randn((1, C, h, w), device=dev) * 0.1
-    mlr = HyperMLR(C, O).to(dev)
-    x = m.expmap(z, dim=1)
-    lg = mlr._hyper_logits(x, out_dtype=torch.float32)
-    n = C * h * w
-    line(f"{tag}: expmap f32->f64 C={C} {h}x{w}", n * 12, lambda: m.expmap(z, dim=1))
-    line(f"{tag}: hypermlr (prep + contraction + epilogue) -> f32 logits", n * 8 + O * h * w * 4, lambda: mlr._hyper_logits(x, out_dtype=torch.float32))
-    line(f"{tag}: bilinear f32 {O}x{h}x{w} -> {up}", (O * h * w + O * up[0] * up[1]) * 4, lambda: bilinear_align_corners(lg, up))
-    if tag == "v2 head":
-        line(f"{tag}: bilinear f64 {C}x{h}x{w} -> {up} (the embedding, classifier.py:375-377)", (n + C * up[0] * up[1]) * 8, lambda: bilinear_align_corners(x, up))
+def main():
+    m = HyperMapper(1.0)
+    O = 19
+    for (tag, C, h, w, up) in (("v3+ head", 64, 160, 320, (640, 1280)), ("v2 head", 64, 640, 1280, (1024, 2048)), ("bench pool", 256, 256, 512, (1024, 2048))):
+        z = torch.randn((1, C, h, w), device=dev) * 0.1
+        mlr = HyperMLR(C, O).to(dev)
+        x = m.expmap(z, dim=1)
+        lg = mlr._hyper_logits(x, out_dtype=torch.float32)
+        n = C * h * w
+        line(f"{tag}: expmap f32->f64 C={C} {h}x{w}", n * 12, lambda: m.expmap(z, dim=1))
+        line(f"{tag}: hypermlr (prep + contraction + epilogue) -> f32 logits", n * 8 + O * h * w * 4, lambda: mlr._hyper_logits(x, out_dtype=torch.float32))
+        line(f"{tag}: bilinear f32 {O}x{h}x{w} -> {up}", (O * h * w + O * up[0] * up[1]) * 4, lambda: bilinear_align_corners(lg, up))
+        if tag == "v2 head":
+            line(f"{tag}: bilinear f64 {C}x{h}x{w} -> {up} (the embedding, classifier.py:375-377)", (n + C * up[0] * up[1]) * 8, lambda: bilinear_align_corners(x, up))
 
-    def tail():
-        e = m.expmap(z, dim=1)
-        o = mlr._hyper_logits(e, out_dtype=torch.float32)
-        return bilinear_align_corners(o, up), e
-    line(f"{tag}: whole tail (expmap -> HyperMLR -> .float() -> resize of the logits)", n * 12 + n * 8 + O * h * w * 8 + O * up[0] * up[1] * 4, tail)
+        def tail():
+            e = m.expmap(z, dim=1)
+            o = mlr._hyper_logits(e, out_dtype=torch.float32)
+            return bilinear_align_corners(o, up), e
+        line(f"{tag}: whole tail (expmap -> HyperMLR -> .float() -> resize of the logits)", n * 12 + n * 8 + O * h * w * 8 + O * up[0] * up[1] * 4, tail)
+
+
+if __name__ == "__main__":
+    main()

@@ -107,3 +107,44 @@ for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
         print(f"backbone stand-in {MODE:5s} {busy:4.0f} ms: {tag:48s} {dt / N * 1e3:7.2f} ms/image  ({N / dt:6.1f} images/s){rng}")
         print(fmt(st), flush=True)
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def writers_alone(n_threads):
+    """The host side's own floor: halo_retire_image (mask composed from the pick table, PNG, indicator maps composed, CRC-32,
+    4.3 MB written) for the same N images from n_threads threads, with NO GPU work, launching thread or slot logic around it."""
+    import threading
+    import numpy as np
+    from halo_amd import _hostlib
+    from halo_amd.core.active.build import _IndicatorTemplate
+    tmp = tempfile.mkdtemp(prefix="halo_rs_w_")
+    rng = np.random.default_rng(0)
+    om = np.full((H, W), 255, np.int64); gt = rng.integers(0, O, (H, W)).astype(np.int64)
+    act = np.zeros((H, W), np.bool_); sel = np.zeros((H, W), np.bool_)
+    k = 2331
+    picks = np.stack([rng.integers(0, H, k), rng.integers(0, W, k), rng.random(k)], 1).astype(np.float64)
+    tpl = _IndicatorTemplate.get((H, W))
+    nxt = [0]
+    lock = threading.Lock()
+
+    def work():
+        while True:
+            with lock:
+                i = nxt[0]; nxt[0] += 1
+            if i >= N:
+                return
+            _hostlib.retire_image(os.path.join(tmp, f"m{i}.png"), os.path.join(tmp, f"i{i}.pth"), om, gt, picks, k, 1, act, sel, tpl, compose_mask_radius=5)
+    runs = []
+    for _ in range(REPEATS + 1):
+        nxt[0] = 0
+        th = [threading.Thread(target=work) for _ in range(n_threads)]
+        t0 = time.perf_counter()
+        [x.start() for x in th]; [x.join() for x in th]
+        runs.append(time.perf_counter() - t0)
+    shutil.rmtree(tmp, ignore_errors=True)
+    runs = sorted(runs[1:])
+    return runs[len(runs) // 2] / N * 1e3
+
+
+if not os.environ.get("HALO_RS_SWEEP"):
+    for nt in (1, 4, 8, 16):
+        print(f"host floor: {nt:2d} writer thread(s) alone, no GPU in the loop (halo_retire_image x {N}): {writers_alone(nt):6.2f} ms/image", flush=True)
