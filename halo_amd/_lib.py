@@ -39,6 +39,8 @@ SIGNATURES = {
     "halo_expmap0_project_bwd": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _dbl, _vp]),
     "halo_hypermlr_bwd_terms": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _sz, _vp]),
+    "halo_hypermlr_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "halo_hypermlr_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_bilinear_upsample": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp]),
     "halo_score_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "halo_score_maps": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,
@@ -84,7 +86,7 @@ SIGNATURES = {
 
 # must equal HALO_ABI_VERSION of include/halo_hip.h; bumped whenever an exported signature changes, so a stale
 # library with the same symbol names but older argument lists is refused instead of being called with shifted arguments
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lock = threading.Lock()
 _handle = None

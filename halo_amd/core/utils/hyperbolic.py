@@ -13,6 +13,7 @@ device-side statement of the same formulas; bilinear_align_corners is inference-
 if a gradient is requested instead of silently detaching.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -181,10 +182,11 @@ def _pixel_contraction(D, X, chunk=512):
 class _HyperMLRFn(torch.autograd.Function):
     """HyperMLR._hyper_logits (hyperbolic.py:120-184), float64, with gradients for x, P_MLR and A_MLR.
 
-    backward = one HIP kernel for everything that is not a GEMM (the reverse sweep through the Moebius /
-    projection / asinh algebra per pixel and class) + the two dense contractions
-        d x = W^T D + 2 x dxx      and      d W = D x^T        (W = [-P ; A/||A||],  D = [dpx ; dxa])
-    which are plain library GEMMs (torch.einsum -> rocBLAS)."""
+    backward, at the heads' shapes (<= 20 classes, 64 | C <= 256): ONE native call (halo_hypermlr_backward: the reverse sweep
+    through the Moebius / projection / asinh algebra per pixel and class, d x = W^T D + 2 x dxx, d W = D x^T and the
+    parameter algebra, three kernels, fixed summation order).  Any other shape (and HALO_MLR_BWD_TERMS=1, the cross-check):
+    one HIP kernel for the reverse sweep + the two dense contractions as library GEMMs (torch.einsum -> rocBLAS),
+        W = [-P ; A/||A||],  D = [dpx ; dxa]."""
 
     @staticmethod
     def forward(ctx, x, P, A, c):
@@ -201,9 +203,19 @@ class _HyperMLRFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         O, hw = P.shape[0], H * W
         gout = gout.double().contiguous()
+        L = _lib.lib()
+        nfused = 0 if os.environ.get("HALO_MLR_BWD_TERMS") else L.halo_hypermlr_backward_workspace_bytes(B, Cc, O, hw)
+        if nfused:
+            # the heads' shapes (<= 20 classes, 64 | C <= 256): the whole backward on the device in one call (three kernels)
+            gx = torch.empty((B, Cc, H, W), dtype=torch.float64, device=dev)
+            gP, gA = torch.empty_like(P), torch.empty_like(A)
+            ws = torch.empty(nfused, dtype=torch.uint8, device=dev)
+            _lib.check(L.halo_hypermlr_backward(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(gout), B, Cc, O, hw, float(ctx.c),
+                                                _lib.ptr(gx), _lib.ptr(gP), _lib.ptr(gA), _lib.ptr(ws), nfused, _lib.stream_ptr(dev)),
+                       "halo_hypermlr_backward")
+            return gx, gP, gA, None
         terms = torch.empty((5, B, O, hw), dtype=torch.float64, device=dev)       # dpx, dxa, dpp, dpa, dan
         dxx = torch.empty((B, hw), dtype=torch.float64, device=dev)
-        L = _lib.lib()
         nws = L.halo_hypermlr_workspace_bytes(O, Cc)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         _lib.check(L.halo_hypermlr_bwd_terms(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(gout), B, Cc, O, hw,

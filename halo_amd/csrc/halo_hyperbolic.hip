@@ -606,6 +606,10 @@ __device__ __forceinline__ double asinh_fast(double x)
 }
 
 constexpr int MLRP_TPB = 512, MLRP_SK = 4, MLRP_RING = 4;
+#ifndef HALO_MLR_EP
+#define HALO_MLR_EP 2
+#endif
+constexpr int MLR_EP = HALO_MLR_EP;       // classes per epilogue trip.  v2 head / 1024x2048x256, same box: 1 -> 193 us / 1.156 ms, 2 -> 180 / 1.128, 3 -> 190 / 1.152 (256 VGPRs + scratch)
 #ifdef HALO_MLR_IEEE            // variant build for A/B (HALO_LIB_PATH): the round-4 epilogue, IEEE divisions
 #define MLR_RCP(x) (1.0 / (x))
 #define MLR_ASINH(x) asinh_det(x)
@@ -804,13 +808,10 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
         const double Kxx = K * xx, KxxK = Kxx * K;
         const long long p_ = p_base + q;
         TOUT *outp = out + (size_t)b * O * hw + p_;
-        // (two classes per trip, evaluated side by side so that two dependent chains interleave, measured SLOWER: 256 against 238 us at
-        // the v2 head's shape, 1.63 against 1.53 ms at 1024x2048x256 -- gpurun_out/r05h)
+        // MLR_EP classes per trip (o, o + 2, ...: a half-wave owns every other class), each phase written for all of them before
+        // the next so that their dependent chains interleave inside one basic block; the wave-uniform tests sit between phases.
 #pragma unroll 1
-        for (int o = lane >> 5; o < O; o += 2) {
-            const int sl = o * 32 + ((q + o) & 31);
-            const double px = pxs[sl], xa = xas[sl];
-            const double ppo = pp[o], ano = anorm[o], pao = pa[o];
+        for (int o0 = lane >> 5; o0 < O; o0 += 2 * MLR_EP) {
             // ---- ONE quotient per logit (round 5).  With A = 1 + 2K px + K xx, B = 1 - K pp, D = 1 + 2K px + K^2 xx pp the reference's
             // alpha = A/D, beta = B/D give  mob = N / D^2,  N = A^2 pp + B^2 xx + 2AB px,  and  mobdota = M / D,  M = B xa + A pa:
             //   inside the ball (N < maxnorm^2 D^2):  sine = sqrt(K) (M/D) 2 / (1 - K N/D^2)           = 2 sqrt(K) M D / (D^2 - K N)
@@ -821,23 +822,48 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
             // act here: D >= 1e-12 is tested (anything else -- NaN included -- takes the reference-order statement below), and
             // 1 - K mob > 1 - K maxnorm^2 = 2e-3 inside the ball.  asinh(s) = log(|s| + sqrt(1 + s^2)): absolute error <= 2 ulp(1)
             // (the logits carry no relative contract near zero: tolerance 1e-10 absolute, tests/test_gpu_parity.py).
-            const double base = __builtin_fma(K2, px, 1.0);
-            const double Aa = base + Kxx;
-            const double D = __builtin_fma(KxxK, ppo, base);
-            const double Bb = __builtin_fma(-K, ppo, 1.0);
-            const double N = __builtin_fma(Aa * Aa, ppo, __builtin_fma(Bb * Bb, xx, ((2.0 * Aa) * Bb) * px));
-            const double M = __builtin_fma(Bb, xa, Aa * pao);
-            const double D2 = D * D;
-            const bool inside = N < maxn2 * D2;
-            double G = (c_in * D) * rcp_q(__builtin_fma(-K, N, D2));
-            if (__any(!inside)) G = inside ? G : c_out * rsqrt_q(N);                    // wave-uniform skip: no pixel of the wave beyond the ball
-            const double sine = M * G, a = __builtin_fabs(sine);
-            double res = __builtin_copysign(log_ge1_q(a + sqrt_q(__builtin_fma(a, a, 1.0))), sine);
-            if (force_ref || __any(!(D >= 1e-12 && a < 1e150))) {                       // never in a trained head: clamped D, NaN / inf, |sine| ~ 1e150
-                const double ref = mlr_epilogue_ref(px, xa, ppo, pao, xx, Kxx, KxxK, K, sqK, maxnorm);
-                res = (force_ref || !(D >= 1e-12 && a < 1e150)) ? ref : res;
+            double px[MLR_EP], xa[MLR_EP], ppo[MLR_EP], ano[MLR_EP], pao[MLR_EP], N[MLR_EP], M[MLR_EP], D[MLR_EP], G[MLR_EP], res[MLR_EP], a[MLR_EP], sine[MLR_EP];
+            bool inside[MLR_EP], all_in = true, all_ok = !force_ref;
+#pragma unroll
+            for (int j = 0; j < MLR_EP; ++j) {
+                const int o = o0 + 2 * j < O ? o0 + 2 * j : o0;               // a trip's surplus slots repeat its first class (never stored)
+                const int sl = o * 32 + ((q + o) & 31);
+                px[j] = pxs[sl]; xa[j] = xas[sl];
+                ppo[j] = pp[o]; ano[j] = anorm[o]; pao[j] = pa[o];
             }
-            if (p_ < hw) outp[(size_t)o * hw] = (TOUT)((oscale * ano) * res);
+#pragma unroll
+            for (int j = 0; j < MLR_EP; ++j) {
+                const double base = __builtin_fma(K2, px[j], 1.0);
+                const double Aa = base + Kxx;
+                D[j] = __builtin_fma(KxxK, ppo[j], base);
+                const double Bb = __builtin_fma(-K, ppo[j], 1.0);
+                N[j] = __builtin_fma(Aa * Aa, ppo[j], __builtin_fma(Bb * Bb, xx, ((2.0 * Aa) * Bb) * px[j]));
+                M[j] = __builtin_fma(Bb, xa[j], Aa * pao[j]);
+                const double D2 = D[j] * D[j];
+                inside[j] = N[j] < maxn2 * D2;
+                all_in = all_in && inside[j];
+                G[j] = (c_in * D[j]) * rcp_q(__builtin_fma(-K, N[j], D2));
+            }
+            if (__any(!all_in)) {                                             // wave-uniform skip: no pixel of the wave beyond the ball
+#pragma unroll
+                for (int j = 0; j < MLR_EP; ++j) G[j] = inside[j] ? G[j] : c_out * rsqrt_q(N[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < MLR_EP; ++j) {
+                sine[j] = M[j] * G[j]; a[j] = __builtin_fabs(sine[j]);
+                all_ok = all_ok && (D[j] >= 1e-12 && a[j] < 1e150);
+                res[j] = __builtin_copysign(log_ge1_q(a[j] + sqrt_q(__builtin_fma(a[j], a[j], 1.0))), sine[j]);
+            }
+            if (__any(!all_ok)) {                                             // never in a trained head: clamped D, NaN / inf, |sine| ~ 1e150
+#pragma unroll
+                for (int j = 0; j < MLR_EP; ++j) {
+                    const double ref = mlr_epilogue_ref(px[j], xa[j], ppo[j], pao[j], xx, Kxx, KxxK, K, sqK, maxnorm);
+                    res[j] = (force_ref || !(D[j] >= 1e-12 && a[j] < 1e150)) ? ref : res[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MLR_EP; ++j)
+                if (p_ < hw && o0 + 2 * j < O) outp[(size_t)(o0 + 2 * j) * hw] = (TOUT)((oscale * ano[j]) * res[j]);
         }
         __builtin_amdgcn_wave_barrier();      // the next tile's accumulators reuse the staging rows
         cur = nxt;
@@ -926,7 +952,11 @@ __global__ void __launch_bounds__(HTPB) k_expmap0_project_bwd(const TIN *__restr
     if (idx >= outer * inner) return;
     const long long o = idx / inner, i = idx % inner;
     const size_t base = (size_t)o * C * inner + i;
+    // (round 5: eight channels' loads in flight per trip -- the kernel was one dependent load pair per trip, 77 us for 105 MB at
+    //  the training shape --, and the forward's own rule for the second norm: project() can only act when g is within 1e-9 of
+    //  maxnorm, k_expmap0_project_tile, so the pass over x that recomputes ||y0|| runs for such pixels only)
     double ssq = 0.0, d = 0.0;
+#pragma unroll 8
     for (int ch = 0; ch < C; ++ch) {
         const double u = ld_as_f64(x + base + (size_t)ch * inner);
         ssq = __builtin_fma(u, u, ssq);
@@ -940,10 +970,14 @@ __global__ void __launch_bounds__(HTPB) k_expmap0_project_bwd(const TIN *__restr
     const double g = rks * th, phi = g / n;
     const double gprime = a_raw < 15.0 ? (1.0 - th * th) : 0.0;   // d tan_k / d n (0 beyond the tanh clamp)
     // forward's own projection decision: ||y0|| from the same element-wise values
-    double s2 = 0.0;
-    for (int ch = 0; ch < C; ++ch) { const double v = g * (ld_as_f64(x + base + (size_t)ch * inner) / n); s2 = __builtin_fma(v, v, s2); }
-    double ny = __builtin_sqrt(s2);
-    ny = ny < 1e-15 ? 1e-15 : ny;
+    double ny = 0.0;
+    if (g >= maxnorm * (1.0 - 1e-9)) {
+        double s2 = 0.0;
+#pragma unroll 8
+        for (int ch = 0; ch < C; ++ch) { const double v = g * (ld_as_f64(x + base + (size_t)ch * inner) / n); s2 = __builtin_fma(v, v, s2); }
+        ny = __builtin_sqrt(s2);
+        ny = ny < 1e-15 ? 1e-15 : ny;
+    }
     const double radial = clamped ? 0.0 : (gprime - phi) / (n * n);
     double alpha, beta;
     if (ny > maxnorm) {
@@ -956,10 +990,83 @@ __global__ void __launch_bounds__(HTPB) k_expmap0_project_bwd(const TIN *__restr
         alpha = phi;
         beta = radial * d;
     }
+#pragma unroll 8
     for (int ch = 0; ch < C; ++ch) {
         const size_t a = base + (size_t)ch * inner;
         gx[a] = (TIN)(alpha * gy[a] + beta * ld_as_f64(x + a));
     }
+}
+
+// One (pixel, class) of the reverse sweep through _hyper_logits' scalar algebra (hyperbolic.py:146-183): the forward values are
+// recomputed from px = <x,-P>, xa = <x,A^>, xx = ||x||^2 and the class constants, then differentiated statement by statement
+// (clamps and the projection's where() pass no gradient on their inactive side, as autograd has it).
+struct MlrGrad { double d_px, d_xa, d_pp, d_pa, d_an, d_xx; };
+// FAST (the fused backward): the two reciprocals the sweep needs (1/D, 1/(1 - K mob)) and 1/sqrt(1 + s^2) through the corrected
+// hardware estimates (rcp_q / rsqrt_q, <= 1 ulp), every other quotient as a product with them, asinh as log(|s| + sqrt(1 + s^2));
+// the projection arm (pixels beyond the ball: rare) keeps its IEEE quotients.  !FAST: IEEE division / sqrt / asinh throughout.
+template <bool FAST>
+__device__ __forceinline__ MlrGrad mlr_reverse(double px, double xa, double gF, double ppo, double pao, double ano, double xx, double K,
+                                               double sqK, double maxnorm)
+{
+    // ---- forward
+    const double t = 1.0 + (2.0 * K) * px;
+    const double Aa = t + K * xx, Bb = 1.0 - K * ppo;
+    const double D0 = t + ((K * xx) * K) * ppo;
+    const bool Dlive = D0 >= 1e-12;
+    const double D = Dlive ? D0 : 1e-12;
+    const double rD = FAST ? rcp_q(D) : 1.0 / D;
+    const double al = FAST ? Aa * rD : Aa / D, be = FAST ? Bb * rD : Bb / D;
+    const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
+    const double sq = (FAST && mob > 1e-300 && mob < 1e300) ? sqrt_q(mob) : __builtin_sqrt(mob);
+    const bool over = sq > maxnorm, under = sq < maxnorm;
+    const double pn = over ? maxnorm / (sq < 1e-12 ? 1e-12 : sq) : 1.0;
+    const double mp = under ? mob : maxnorm * maxnorm;
+    const double inner = be * xa + al * pao;
+    const double md = inner * pn;
+    const double den = 1.0 - K * mp;
+    const bool denlive = den >= 1e-12;
+    const double denc = denlive ? den : 1e-12;
+    const double rden = FAST ? rcp_q(denc) : 1.0 / denc;
+    const double lam = FAST ? 2.0 * rden : 2.0 / denc;
+    const double s = (sqK * md) * lam;
+    // ---- reverse
+    const double two_sqK = 2.0 / sqK;
+    double asinh_s, rsq1;                                                // asinh(s), 1 / sqrt(1 + s^2)
+    const double a_ = __builtin_fabs(s);
+    if (FAST && a_ < 1e150) {
+        const double u = __builtin_fma(a_, a_, 1.0);
+        rsq1 = rsqrt_q(u);
+        asinh_s = __builtin_copysign(log_ge1_q(__builtin_fma(u, rsq1, a_)), s);
+    } else {
+        asinh_s = asinh(s);
+        rsq1 = 1.0 / __builtin_sqrt(1.0 + s * s);
+    }
+    const double d_an = gF * two_sqK * asinh_s;
+    const double d_s = FAST ? gF * two_sqK * ano * rsq1 : gF * two_sqK * ano / __builtin_sqrt(1.0 + s * s);
+    const double d_md = d_s * sqK * lam;
+    const double d_lam = d_s * sqK * md;
+    const double d_den = denlive ? (FAST ? -d_lam * 2.0 * (rden * rden) : -d_lam * 2.0 / (denc * denc)) : 0.0;
+    double d_mob = under ? -K * d_den : 0.0;
+    const double d_inner = d_md * pn, d_pn = d_md * inner;
+    double d_be = d_inner * xa, d_al = d_inner * pao;
+    const double d_xa = d_inner * be, d_pa = d_inner * al;
+    if (over) {                                                          // d pn / d sq (zero on the other side of the where())
+        const double d_sq = -d_pn * maxnorm / (sq * sq);
+        if (sq > 0.0) d_mob += d_sq / (2.0 * sq);
+    }
+    d_al += d_mob * (2.0 * al * ppo + 2.0 * be * px);
+    d_be += d_mob * (2.0 * be * xx + 2.0 * al * px);
+    double d_pp = d_mob * al * al, d_xx = d_mob * be * be, d_px = d_mob * 2.0 * al * be;
+    const double d_Aa = FAST ? d_al * rD : d_al / D, d_Bb = FAST ? d_be * rD : d_be / D;
+    const double d_D0 = Dlive ? (FAST ? -(d_al * Aa + d_be * Bb) * (rD * rD) : -(d_al * Aa + d_be * Bb) / (D * D)) : 0.0;
+    double d_t = d_D0;
+    d_xx += d_D0 * K * K * ppo;
+    d_pp += d_D0 * K * K * xx;
+    d_pp += -K * d_Bb;
+    d_t += d_Aa;
+    d_xx += K * d_Aa;
+    d_px += 2.0 * K * d_t;
+    return MlrGrad{d_px, d_xa, d_pp, d_pa, d_an, d_xx};
 }
 
 // Reverse sweep through _hyper_logits' scalar algebra (hyperbolic.py:146-183) for every (pixel, class):
@@ -1000,58 +1107,349 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr_bwd_terms(const double *__res
             const int o = o0 + q;
             if (o < O) {
             const size_t oi = ((size_t)b * O + o) * hw + i;
-            const double gF = gout[oi];
-            const double ppo = pp[o], pao = pa[o], ano = anorm[o];
-            // ---- forward
-            const double t = 1.0 + (2.0 * K) * px[q];
-            const double Aa = t + K * xx, Bb = 1.0 - K * ppo;
-            const double D0 = t + ((K * xx) * K) * ppo;
-            const bool Dlive = D0 >= 1e-12;
-            const double D = Dlive ? D0 : 1e-12;
-            const double al = Aa / D, be = Bb / D;
-            const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px[q];
-            const double sq = __builtin_sqrt(mob);
-            const bool over = sq > maxnorm, under = sq < maxnorm;
-            const double pn = over ? maxnorm / (sq < 1e-12 ? 1e-12 : sq) : 1.0;
-            const double mp = under ? mob : maxnorm * maxnorm;
-            const double inner = be * xa[q] + al * pao;
-            const double md = inner * pn;
-            const double den = 1.0 - K * mp;
-            const bool denlive = den >= 1e-12;
-            const double denc = denlive ? den : 1e-12;
-            const double lam = 2.0 / denc;
-            const double s = (sqK * md) * lam;
-            // ---- reverse
-            const double two_sqK = 2.0 / sqK;
-            const double d_an = gF * two_sqK * asinh(s);
-            const double d_s = gF * two_sqK * ano / __builtin_sqrt(1.0 + s * s);
-            const double d_md = d_s * sqK * lam;
-            const double d_lam = d_s * sqK * md;
-            const double d_den = denlive ? -d_lam * 2.0 / (denc * denc) : 0.0;
-            double d_mob = under ? -K * d_den : 0.0;
-            const double d_inner = d_md * pn, d_pn = d_md * inner;
-            double d_be = d_inner * xa[q], d_al = d_inner * pao;
-            const double d_xa = d_inner * be, d_pa = d_inner * al;
-            const double d_sq = over ? -d_pn * maxnorm / (sq * sq) : 0.0;
-            if (sq > 0.0) d_mob += d_sq / (2.0 * sq);
-            d_al += d_mob * (2.0 * al * ppo + 2.0 * be * px[q]);
-            d_be += d_mob * (2.0 * be * xx + 2.0 * al * px[q]);
-            double d_pp = d_mob * al * al, d_xx = d_mob * be * be, d_px = d_mob * 2.0 * al * be;
-            const double d_Aa = d_al / D, d_Bb = d_be / D;
-            const double d_D0 = Dlive ? -(d_al * Aa + d_be * Bb) / (D * D) : 0.0;
-            double d_t = d_D0;
-            d_xx += d_D0 * K * K * ppo;
-            d_pp += d_D0 * K * K * xx;
-            d_pp += -K * d_Bb;
-            d_t += d_Aa;
-            d_xx += K * d_Aa;
-            d_px += 2.0 * K * d_t;
-            dpx[oi] = d_px; dxa[oi] = d_xa; dpp[oi] = d_pp; dpa[oi] = d_pa; dan[oi] = d_an;
-            dxx_acc += d_xx;
+            const MlrGrad g_ = mlr_reverse<false>(px[q], xa[q], gout[oi], pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
+            dpx[oi] = g_.d_px; dxa[oi] = g_.d_xa; dpp[oi] = g_.d_pp; dpa[oi] = g_.d_pa; dan[oi] = g_.d_an;
+            dxx_acc += g_.d_xx;
             }
         }
     }
     dxx[(size_t)b * hw + i] = dxx_acc;
+}
+
+
+// ---------------------------------------------------------------- HyperMLR backward, fused (round 5)
+// Until round 5 the backward was k_hypermlr_bwd_terms (five (B,O,hw) term maps written to HBM) followed by ~45 library launches
+// in halo_amd/core/utils/hyperbolic.py: three full-map sums, two einsums with their permuted copies, a padded / permuted batched
+// GEMM for d W, and a dozen (O,C)-sized element-wise kernels -- 0.56 ms of the 0.81 ms the head tail's forward + backward took at
+// the training shape (2 x 64 x 160 x 320; profiles/r05_head_bwd_kernels.txt), against 0.03 ms for the forward.  Four kernels now:
+//   k_mlr_bwd_pixels   one lane per pixel: ||x||^2 and the two contractions px / xa in ONE walk over the channels (weights broadcast
+//                      from an LDS image of [-P | A^] laid out channel-major), the reverse sweep for every class; dpx / dxa (the
+//                      matrix D, 2O x pixels) and dxx go to the workspace, the three per-class sums (dpp, dpa, d||A||) leave as one
+//                      partial per workgroup (fixed shuffle tree, fixed order afterwards: deterministic);
+//   k_mlr_bwd_dx       gx = W^T D + 2 x dxx on the f64 matrix cores;
+//   k_mlr_bwd_weights  d W = D x^T on the f64 matrix cores, one (2O x C) partial per persistent workgroup;
+//   k_mlr_bwd_final    sums the partials in a fixed order and applies the (O,C)-sized algebra (||P||^2, <-P,A^>, F.normalize).
+// Serves O <= MLRB_OP classes and C a multiple of 64 up to 256 (the heads: 19 classes, 64 channels); anything else keeps the
+// term-map path above.
+constexpr int MLRB_OP = 20, MLRB_WS = 2 * MLRB_OP, MLRB_TPB = 256, MLRB_NWG = 256;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
+    return v;
+}
+
+__global__ void __launch_bounds__(MLRB_TPB) k_mlr_bwd_pixels(const double *__restrict__ x, const double *__restrict__ consts,
+                                                             const double *__restrict__ gout, int O, int C, long long hw, double K,
+                                                             double *__restrict__ Dws, double *__restrict__ dxx_out,
+                                                             double *__restrict__ cls_part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    double *Wt = reinterpret_cast<double *>(smem_b);                      // [C][MLRB_WS]: -P of classes 0..OP-1 | A^ of classes 0..OP-1 (zero beyond O)
+    __shared__ double s_red[MLRB_TPB / 64][3 * MLRB_OP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    for (int e0 = 0; e0 < C * MLRB_WS; e0 += 5 * MLRB_TPB) {              // rows of [-P | A^] read along the channels, five independent loads per
+        double v[5];                                                     // thread in flight (C * WS is a multiple of 5 * 256: 64 | C, WS = 40)
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int e = e0 + u * MLRB_TPB + tid, r = e / C, j = e - r * C, o = r % MLRB_OP;
+            v[u] = o < O ? (r < MLRB_OP ? nP : An)[(size_t)o * C + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int e = e0 + u * MLRB_TPB + tid, r = e / C, j = e - r * C;
+            Wt[j * MLRB_WS + r] = v[u];
+        }
+    }
+    __syncthreads();
+    const long long i_raw = (long long)blockIdx.x * MLRB_TPB + tid;
+    const bool live = i_raw < hw;
+    const long long i = live ? i_raw : hw - 1;                           // idle lanes repeat the last pixel (loads stay valid, nothing stored, zero summed)
+    const double *xb = x + (size_t)b * C * hw + i;
+    // ONE walk over the pixel's channels: ||x||^2 and all 2 x OP contraction chains together, eight channels per trip, the next
+    // trip's eight loads issued before this trip's arithmetic.  (The first version walked x four times -- norm, two class passes
+    // with dpx / dxa parked in 80 registers, d x -- at 252 registers and 1.5 waves per SIMD: every trip was an exposed L2 round trip.)
+    constexpr int UN = 8;                                                // C % 64 == 0
+    auto load8 = [&](double (&d)[UN], int j0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) d[u] = xb[(size_t)(j0 + u) * hw];
+    };
+    double ssq = 0.0, px[MLRB_OP], xa[MLRB_OP];
+#pragma unroll
+    for (int q = 0; q < MLRB_OP; ++q) { px[q] = 0.0; xa[q] = 0.0; }
+    {
+        double cur[UN], nxt[UN];
+        load8(cur, 0);
+        for (int j0 = 0; j0 < C; j0 += UN) {
+            if (j0 + UN < C) load8(nxt, j0 + UN);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const double *wr = Wt + (j0 + u) * MLRB_WS;
+                ssq = __builtin_fma(cur[u], cur[u], ssq);
+#pragma unroll
+                for (int q = 0; q < MLRB_OP; ++q) {
+                    px[q] = __builtin_fma(cur[u], wr[q], px[q]);
+                    xa[q] = __builtin_fma(cur[u], wr[MLRB_OP + q], xa[q]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) cur[u] = nxt[u];
+        }
+    }
+    const double nx = __builtin_sqrt(ssq), xx = nx * nx;                  // torch.norm(x)**2, hyperbolic.py:136
+    const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
+    double dxx_acc = 0.0;
+    double *d0 = Dws + (size_t)b * 2 * O * hw + i;
+#pragma unroll
+    for (int o = 0; o < MLRB_OP; ++o) {
+        if (o < O) {                                                     // wave-uniform
+            const MlrGrad g_ = mlr_reverse<true>(px[o], xa[o], gout[((size_t)b * O + o) * hw + i], pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
+            if (live) { d0[(size_t)o * hw] = g_.d_px; d0[(size_t)(O + o) * hw] = g_.d_xa; }
+            dxx_acc += g_.d_xx;
+            // the three per-class sums: fixed shuffle trees (their ds_bpermute latency hides behind the other waves of the SIMD now)
+            const double s0 = wave_sum(live ? g_.d_pp : 0.0), s1 = wave_sum(live ? g_.d_pa : 0.0), s2 = wave_sum(live ? g_.d_an : 0.0);
+            if (lane == 0) { s_red[wave][o] = s0; s_red[wave][MLRB_OP + o] = s1; s_red[wave][2 * MLRB_OP + o] = s2; }
+        }
+    }
+    if (live) dxx_out[(size_t)b * hw + i] = dxx_acc;
+    __syncthreads();
+    if (tid < 3 * MLRB_OP) {                                             // the workgroup's partial: waves added in wave order
+        const int k = tid / MLRB_OP, o = tid % MLRB_OP;
+        if (o < O) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < MLRB_TPB / 64; ++w) t += s_red[w][tid];
+            cls_part[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3 + k) * O + o] = t;
+        }
+    }
+}
+
+// d x = W^T D + 2 x dxx on the f64 matrix cores: out[channel][pixel] = sum_k W^T[channel][k] D[k][pixel], k over the 2O rows of D.
+// A operand (16 channels x 4 rows of D) = weights, constant over the launch: all of them sit in registers (KS x 4 doubles per lane);
+// B operand (4 rows of D x 16 pixels): lane (col = lane & 15, k = lane >> 4) loads D[4 ks + k][p0 + col] -- 128 contiguous bytes per
+// row; the result lane holds pixel (lane & 15) of channels (lane >> 4) + 4 q of each 16-channel tile, so x is read and d x written
+// in 128-byte row segments as well.  A wave walks 16-pixel tiles; blockIdx.y is the 64-channel block.
+constexpr int MLRX_KS = (2 * MLRB_OP + 3) / 4;                           // k steps covering 2O <= 40 rows
+__global__ void __launch_bounds__(256) k_mlr_bwd_dx(const double *__restrict__ x, const double *__restrict__ consts, const double *__restrict__ Dws,
+                                                    const double *__restrict__ dxx, int O, int C, long long hw, int Bn, double *__restrict__ gx)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, k = lane >> 4, cb = blockIdx.y;
+    const double *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    double aw[MLRX_KS][4];
+#pragma unroll
+    for (int ks = 0; ks < MLRX_KS; ++ks) {
+        const int kk = 4 * ks + k;                                       // row of D: dpx of class kk (< O), dxa of class kk - O
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int c = cb * 64 + ct * 16 + col;
+            aw[ks][ct] = kk < O ? nP[(size_t)kk * C + c] : (kk < 2 * O ? An[(size_t)(kk - O) * C + c] : 0.0);
+        }
+    }
+    const long long tpi = (hw + 15) / 16, ntiles = tpi * Bn, tstride = (long long)gridDim.x * 4;
+    // the D operand of the wave's NEXT tile is requested before this tile's MFMAs (a tile's 40 MFMAs last about as long as an HBM
+    // round trip under load: unpipelined, two waves per SIMD left the matrix pipe idle half the time)
+    auto load_d = [&](long long t_, double (&d)[MLRX_KS]) {
+        const long long tl = t_ < ntiles ? t_ : ntiles - 1;
+        const int b = (int)(tl / tpi);
+        const long long p = (tl % tpi) * 16 + col, pc = p < hw ? p : hw - 1;
+#pragma unroll
+        for (int ks = 0; ks < MLRX_KS; ++ks) {
+            const int kk = 4 * ks + k;
+            d[ks] = kk < 2 * O ? Dws[((size_t)b * 2 * O + kk) * hw + pc] : 0.0;
+        }
+    };
+    double bd[MLRX_KS], bn[MLRX_KS];
+    long long t_ = (long long)blockIdx.x * 4 + wave;
+    load_d(t_, bd);
+    for (; t_ < ntiles; t_ += tstride) {
+        const int b = (int)(t_ / tpi);
+        const long long p = (t_ % tpi) * 16 + col;
+        const bool in = p < hw;
+        const long long pc = in ? p : hw - 1;
+        load_d(t_ + tstride, bn);
+        const double two_dxx = 2.0 * dxx[(size_t)b * hw + pc];
+        double xv[4][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[ct][q] = x[((size_t)b * C + cb * 64 + ct * 16 + k + 4 * q) * hw + pc];
+        v4d_t acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (v4d_t){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < MLRX_KS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[ks][ct], bd[ks], acc[ct], 0, 0, 0);
+        if (in)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    gx[((size_t)b * C + cb * 64 + ct * 16 + k + 4 * q) * hw + p] = __builtin_fma(two_dxx, xv[ct][q], acc[ct][q]);
+#pragma unroll
+        for (int ks = 0; ks < MLRX_KS; ++ks) bd[ks] = bn[ks];
+    }
+}
+
+// d W = D x^T on the f64 matrix cores (2O x C outputs, contraction over ALL pixels): a wave walks 16-pixel steps s, s + S, ...; in a
+// step lane (r = lane & 15, k = lane >> 4) loads pixels 4k .. 4k+3 of D rows r, 16 + r, 32 + r and of x rows r, 16 + r
+// (the two 16-column tiles of column block blockIdx.y) -- 32 contiguous bytes per lane, 128 per row -- and issues 4 x 6 v_mfma_f64_16x16x4_f64
+// (the k slot of an MFMA is ANY pixel as long as both operands agree on it).  48 x 32 accumulators stay in registers over the
+// wave's steps; the workgroup's four waves are added through LDS as (0 + 1) + (2 + 3) and leave ONE partial per workgroup and
+// column block.  (First version, VALU over LDS-staged chunks: 205 us at the training shape, latency-bound in its staging loop.)
+__global__ void __launch_bounds__(256) k_mlr_bwd_weights(const double *__restrict__ x, const double *__restrict__ Dws, int O, int C,
+                                                         long long hw, int Bn, double *__restrict__ w_part)
+{
+    constexpr int NCT = 2;                                               // 16-column tiles per workgroup (blockIdx.y = 32-column block): 24 accumulators,
+    __shared__ double s_acc[2][48 * 16 * NCT];                           // several waves per SIMD to cover the operand loads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, k = lane >> 4, cb = blockIdx.y;
+    const long long spi = (hw + 15) / 16, nsteps = spi * Bn;             // steps per image
+    const bool vec = (hw & 3) == 0;                                      // 32-byte aligned pixel quads
+    v4d_t acc[3][NCT];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = (v4d_t){0, 0, 0, 0};
+    auto load_ops = [&](long long s_, double (&av)[3][4], double (&bv)[NCT][4]) {
+        const long long sl = s_ < nsteps ? s_ : nsteps - 1;              // the look-ahead past the wave's last step re-reads it (never used)
+        const int b = (int)(sl / spi);
+        const long long p = (sl % spi) * 16 + 4 * k;
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) {
+            const int j = rt * 16 + r;
+            const double *src = Dws + ((size_t)b * 2 * O + (j < 2 * O ? j : 0)) * hw + p;
+            if (vec && p < hw && j < 2 * O) {
+                const d2_h v0 = *reinterpret_cast<const d2_h *>(src), v1 = *reinterpret_cast<const d2_h *>(src + 2);
+                av[rt][0] = v0.x; av[rt][1] = v0.y; av[rt][2] = v1.x; av[rt][3] = v1.y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[rt][e] = (j < 2 * O && p + e < hw) ? src[e] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const double *src = x + ((size_t)b * C + cb * (16 * NCT) + ct * 16 + r) * hw + p;
+            if (vec && p < hw) {
+                const d2_h v0 = *reinterpret_cast<const d2_h *>(src), v1 = *reinterpret_cast<const d2_h *>(src + 2);
+                bv[ct][0] = v0.x; bv[ct][1] = v0.y; bv[ct][2] = v1.x; bv[ct][3] = v1.y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[ct][e] = p + e < hw ? src[e] : 0.0;      // a zero on either side drops the pixel
+            }
+        }
+    };
+    double av[3][4], bv[NCT][4], an_[3][4], bn_[NCT][4];
+    const long long sstride = (long long)gridDim.x * 4;
+    long long s_ = (long long)blockIdx.x * 4 + wave;
+    load_ops(s_, av, bv);
+    for (; s_ < nsteps; s_ += sstride) {
+        load_ops(s_ + sstride, an_, bn_);                                // the next step's operands travel during this step's 24 MFMAs
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][e], bv[ct][e], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) av[rt][e] = an_[rt][e];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bv[ct][e] = bn_[ct][e];
+        }
+    }
+    // accumulator layout: lane holds column (lane & 15), rows (lane >> 4) + 4 q.  Waves 1 and 3 publish, 0 and 2 add; then 2 publishes, 0 adds.
+    auto publish = [&](double *dst) {
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[(rt * 16 + k + 4 * q) * (16 * NCT) + ct * 16 + r] = acc[rt][ct][q];
+    };
+    auto absorb = [&](const double *src) {
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][ct][q] += src[(rt * 16 + k + 4 * q) * (16 * NCT) + ct * 16 + r];
+    };
+    if (wave & 1) publish(s_acc[wave >> 1]);
+    __syncthreads();
+    if (!(wave & 1)) absorb(s_acc[wave >> 1]);
+    __syncthreads();
+    if (wave == 2) publish(s_acc[0]);
+    __syncthreads();
+    if (wave == 0) {
+        absorb(s_acc[0]);
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = rt * 16 + k + 4 * q;
+                    if (j < 2 * O) w_part[((size_t)blockIdx.x * 2 * O + j) * C + cb * (16 * NCT) + ct * 16 + r] = acc[rt][ct][q];
+                }
+    }
+}
+
+// One workgroup per class: the partial sums in a fixed order, then hyperbolic.py's own parameter algebra differentiated --
+//   pp = ||P||^2 -> 2 P dpp;  pa = <-P, A^> -> -A^ dpa (to P), -P dpa (to A^);  A^ = A / max(||A||, 1e-12) (F.normalize);  ||A|| -> A / ||A|| dan.
+constexpr int MLRF_TPB = 1024, MLRF_NW = MLRF_TPB / 64;
+__global__ void __launch_bounds__(MLRF_TPB) k_mlr_bwd_final(const double *__restrict__ A, const double *__restrict__ consts,
+                                                            const double *__restrict__ w_part, int n_wpart, const double *__restrict__ cls_part,
+                                                            int n_cpart, int O, int C, double *__restrict__ gP, double *__restrict__ gA)
+{
+    __shared__ double s_red[MLRF_NW][3], s_dot, s_w[MLRF_NW][2][64], s_gan[256];          // C <= 256
+    const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *anorm = consts + O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    // the three class sums: thread t adds workgroup partials t, t + 1024, ...; then the fixed shuffle tree and the waves in order
+    double c3[3] = {0.0, 0.0, 0.0};
+    for (int g = tid; g < n_cpart; g += MLRF_TPB)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c3[k] += cls_part[((size_t)g * 3 + k) * O + o];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double t = wave_sum(c3[k]); if (lane == 0) s_red[wave][k] = t; }
+    __syncthreads();
+    double dpp = 0.0, dpa = 0.0, dan = 0.0;
+#pragma unroll
+    for (int w = 0; w < MLRF_NW; ++w) { dpp += s_red[w][0]; dpa += s_red[w][1]; dan += s_red[w][2]; }
+    const double an = anorm[o], dn = an < 1e-12 ? 1e-12 : an;
+    double dot_acc = 0.0;
+    for (int c0 = 0; c0 < C; c0 += 64) {                                  // 64 columns at a time: wave w adds weight partials w, w + 16, ...
+        const int c = c0 + lane;
+        double gp = 0.0, ga = 0.0;
+        if (c < C)
+#pragma unroll 4
+            for (int g = wave; g < n_wpart; g += MLRF_NW) {
+                gp += w_part[((size_t)g * 2 * O + o) * C + c];
+                ga += w_part[((size_t)g * 2 * O + O + o) * C + c];
+            }
+        s_w[wave][0][lane] = gp; s_w[wave][1][lane] = ga;
+        __syncthreads();
+        if (wave == 0 && c < C) {
+            double g_negP = 0.0, g_xa = 0.0;
+#pragma unroll
+            for (int w = 0; w < MLRF_NW; ++w) { g_negP += s_w[w][0][lane]; g_xa += s_w[w][1][lane]; }
+            const double np_ = nP[(size_t)o * C + c], ah = An[(size_t)o * C + c];
+            const double g_An = g_xa + dpa * np_;                        // through xa and pa = <-P, A^>
+            gP[(size_t)o * C + c] = (-g_negP + dpp * (2.0 * -np_)) - dpa * ah;
+            s_gan[c] = g_An;                                              // finished below, once <g_An, A^> is known
+            dot_acc = __builtin_fma(g_An, ah, dot_acc);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) { const double t = wave_sum(dot_acc); if (lane == 0) s_dot = t; }
+    __syncthreads();
+    const double dot = s_dot;
+    for (int c = tid; c < C; c += MLRF_TPB) {
+        const double ah = An[(size_t)o * C + c];
+        gA[(size_t)o * C + c] = (s_gan[c] - dot * ah) / dn + dan * A[(size_t)o * C + c] / an;
+    }
 }
 
 }  // namespace halo
@@ -1494,6 +1892,61 @@ extern "C" int halo_expmap0_project_bwd(const void *x, int x_dtype, const double
         hipLaunchKernelGGL((k_expmap0_project_bwd<double>), dim3(nblocks(outer * inner)), dim3(HTPB), 0, st, (const double *)x, gy, (double *)gx, (long long)outer, (int)C, (long long)inner, ks, rks, maxnorm);
     else return fail(HALO_E_ARG, "halo_expmap0_project_bwd: bad dtype");
     return check_launch("halo_expmap0_project_bwd");
+}
+
+// ---- fused HyperMLR backward (k_mlr_bwd_pixels / _dx / _weights / _final).  Workspace: consts | D (B,2O,hw) | dxx (B,hw) | class partials | weight partials.
+static inline bool mlr_bwd_fused_ok(int64_t C, int64_t O) { return O >= 1 && O <= MLRB_OP && C % 64 == 0 && C >= 64 && C <= 256; }
+static inline int64_t mlr_bwd_pix_blocks(int64_t B, int64_t hw) { return cdiv(hw, MLRB_TPB) * B; }
+extern "C" size_t halo_hypermlr_backward_workspace_bytes(int64_t B, int64_t C, int64_t O, int64_t hw)
+{
+    if (B <= 0 || C <= 0 || O <= 0 || hw <= 0 || !mlr_bwd_fused_ok(C, O)) return 0;       // 0: shape not served (use halo_hypermlr_bwd_terms)
+    return halo_hypermlr_workspace_bytes(O, C) + 256 + ((size_t)B * (2 * O + 1) * hw + (size_t)mlr_bwd_pix_blocks(B, hw) * 3 * O +
+                                                       (size_t)MLRB_NWG * 2 * O * C) * sizeof(double) + 4 * 256;
+}
+
+extern "C" int halo_hypermlr_backward(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
+                                      int64_t O, int64_t hw, double c, double *gx, double *gP, double *gA, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    if (!x || !P || !A || !gout || !gx || !gP || !gA || B <= 0 || C <= 0 || O <= 0 || hw <= 0)
+        return fail(HALO_E_ARG, "halo_hypermlr_backward: null/empty argument");
+    if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_hypermlr_backward: curvature must be > 0");
+    if (!mlr_bwd_fused_ok(C, O))
+        return fail(HALO_E_UNSUPPORTED, "halo_hypermlr_backward: serves at most %d classes and 64 | C <= 256 (got O = %lld, C = %lld): use halo_hypermlr_bwd_terms",
+                    MLRB_OP, (long long)O, (long long)C);
+    if (!workspace || workspace_bytes < halo_hypermlr_backward_workspace_bytes(B, C, O, hw)) return fail(HALO_E_WORKSPACE, "halo_hypermlr_backward: workspace too small");
+    if (B > 65535) return fail(HALO_E_UNSUPPORTED, "halo_hypermlr_backward: more than 65535 images per call");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(workspace, workspace_bytes);
+    double *consts = ar.take<double>((size_t)(3 * O + 2 * O * C));
+    double *Dws = ar.take<double>((size_t)B * 2 * O * hw);
+    double *dxx = ar.take<double>((size_t)B * hw);
+    const int64_t npb = mlr_bwd_pix_blocks(B, hw);
+    double *cls_part = ar.take<double>((size_t)npb * 3 * O);
+    double *w_part = ar.take<double>((size_t)MLRB_NWG * 2 * O * C);
+    if (!ar.ok() || !consts || !Dws || !dxx || !cls_part || !w_part) return fail(HALO_E_WORKSPACE, "halo_hypermlr_backward: workspace too small");
+    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)O), dim3(64), (size_t)2 * C * sizeof(double), st, P, A, (int)O, (int)C, consts);
+    {
+        const size_t lds = (size_t)C * MLRB_WS * sizeof(double);         // 80 KiB at C = 256
+        static LdsLimitSeen seen;
+        if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_mlr_bwd_pixels, 96 * 1024))
+            return fail(HALO_E_LAUNCH, "halo_hypermlr_backward: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(k_mlr_bwd_pixels, dim3((unsigned)cdiv(hw, MLRB_TPB), (unsigned)B), dim3(MLRB_TPB), lds, st, x, (const double *)consts, gout,
+                           (int)O, (int)C, (long long)hw, c, Dws, dxx, cls_part);
+        const long long ntiles = cdiv(hw, 16) * B;
+        const unsigned gdx = (unsigned)(cdiv(ntiles, 4) < 512 ? cdiv(ntiles, 4) : 512);
+        hipLaunchKernelGGL(k_mlr_bwd_dx, dim3(gdx, (unsigned)(C / 64)), dim3(256), 0, st, x, (const double *)consts, (const double *)Dws, (const double *)dxx,
+                           (int)O, (int)C, (long long)hw, (int)B, gx);
+    }
+    {
+        const long long nsteps = cdiv(hw, 16) * B;
+        const unsigned g = (unsigned)(cdiv(nsteps, 4) < MLRB_NWG ? cdiv(nsteps, 4) : MLRB_NWG);
+        hipLaunchKernelGGL(k_mlr_bwd_weights, dim3(g, (unsigned)(C / 32)), dim3(256), 0, st, x, (const double *)Dws, (int)O, (int)C, (long long)hw,
+                           (int)B, w_part);
+        hipLaunchKernelGGL(k_mlr_bwd_final, dim3((unsigned)O), dim3(MLRF_TPB), 0, st, A, (const double *)consts, (const double *)w_part, (int)g,
+                           (const double *)cls_part, (int)npb, (int)O, (int)C, gP, gA);
+    }
+    return check_launch("halo_hypermlr_backward");
 }
 
 extern "C" int halo_hypermlr_bwd_terms(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 6
+#define HALO_ABI_VERSION 7
 
 enum { HALO_F32 = 0, HALO_F64 = 1 };
 
@@ -94,6 +94,17 @@ int halo_expmap0_project_bwd(const void *x, int x_dtype, const double *gy, void 
 int halo_hypermlr_bwd_terms(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
                             int64_t O, int64_t hw, double c, double *dpx, double *dxa, double *dxx, double *dpp,
                             double *dpa, double *dan, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The whole backward of HyperMLR._hyper_logits in one call (ABI 7): from gout = dL/dlogit (B,O,hw) f64 it writes
+ * gx = dL/dx (B,C,hw), gP = dL/dP_MLR and gA = dL/dA_MLR (O,C), all f64 -- the reverse sweep above, d x = W^T D + 2 x dxx,
+ * d W = D x^T and the parameter algebra (||P||^2, <-P,A^>, F.normalize, ||A||; hyperbolic.py:137-174) on the device, every sum
+ * in a fixed order (run-to-run identical).  Serves O <= 20 classes and C a multiple of 64 up to 256 (the heads' 19 x 64):
+ * halo_hypermlr_backward_workspace_bytes returns 0 for any other shape, and the caller then composes the backward from
+ * halo_hypermlr_bwd_terms and its own GEMMs (halo_amd/core/utils/hyperbolic.py does). */
+size_t halo_hypermlr_backward_workspace_bytes(int64_t B, int64_t C, int64_t O, int64_t hw);
+int halo_hypermlr_backward(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
+                           int64_t O, int64_t hw, double c, double *gx, double *gP, double *gA, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* F.interpolate(mode="bilinear", align_corners=True) (core/active/build.py:123-125,133-135;
  * classifier.py:375-377,556-557): planes x (h,w) -> planes x (H,W), dtype F32|F64.  ATen's order (columns first, rows second,

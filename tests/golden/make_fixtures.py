@@ -271,7 +271,9 @@ def gen_grads(hyp):
     """Autograd of the reference head tail (classifier.py:553-554): d loss / d {feat, P_MLR, A_MLR} for
     loss = <out, Wt> + <embed, Ve>, with far-out (projected / tanh-clamped) and exact-origin pixels."""
     out = {}
-    for tag, (C, O, h, w, c) in {"c8_o19": (8, 19, 9, 13, 1.0), "c16_o16_k07": (16, 16, 6, 10, 0.7)}.items():
+    # (c64_o19: the head's own 64 channels x 19 classes -- the shape the fused native backward serves; every case draws from its own
+    #  generator, so adding one leaves the other arrays' bits alone)
+    for tag, (C, O, h, w, c) in {"c8_o19": (8, 19, 9, 13, 1.0), "c16_o16_k07": (16, 16, 6, 10, 0.7), "c64_o19": (64, 19, 10, 14, 1.0)}.items():
         g = torch.Generator().manual_seed(5 + C)
         z = torch.randn(2, C, h, w, generator=g, dtype=torch.float32) * 0.3
         z[0, :, 0, 0] *= 300.0            # tanh clamp + project

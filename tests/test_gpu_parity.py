@@ -36,6 +36,26 @@ def t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+class _env_set:
+    """context manager: os.environ entries set for the block, restored after"""
+    def __init__(self, env):
+        self.env, self.old = env, {}
+
+    def __enter__(self):
+        import os
+        for k, v in self.env.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _with_env(env, fn):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -1354,31 +1374,71 @@ def test_head_tail_gradients_match_reference_autograd(golden, dev):
     tanh-clamped / projected pixels and an exact-origin pixel."""
     from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
     d = golden("grads")
-    for tag in ("c8_o19", "c16_o16_k07"):
-        c = float(d[tag + "__c"][0])
-        z = t(d[tag + "__z"], dev).requires_grad_(True)
-        O, C = d[tag + "__P"].shape
-        mlr = HyperMLR(C, O, c=c).to(dev)
-        with torch.no_grad():
-            mlr.P_MLR.copy_(t(d[tag + "__P"], dev)); mlr.A_MLR.copy_(t(d[tag + "__A"], dev))
-        embed = HyperMapper(c=c).expmap(z, dim=1)
-        embed.retain_grad()
-        logits = mlr(embed.double()).float()
-        assert max_abs_diff(embed.detach().cpu().numpy(), d[tag + "__embed"]) < 1e-14
-        assert np.abs(logits.detach().cpu().numpy() - d[tag + "__logits"]).max() < 1e-5
-        loss = (logits * t(d[tag + "__Wt"], dev)).sum() + (embed * t(d[tag + "__Ve"], dev)).sum()
-        loss.backward()
+    # c64_o19 is the head's own 64 x 19: the fused native backward (halo_hypermlr_backward); the same vectors once more through the
+    # term-map path (HALO_MLR_BWD_TERMS=1), which is what the two smaller cases take anyway
+    for tag, env in (("c8_o19", {}), ("c16_o16_k07", {}), ("c64_o19", {}), ("c64_o19", {"HALO_MLR_BWD_TERMS": "1"})):
+      with _env_set(env):
+          c = float(d[tag + "__c"][0])
+          z = t(d[tag + "__z"], dev).requires_grad_(True)
+          O, C = d[tag + "__P"].shape
+          mlr = HyperMLR(C, O, c=c).to(dev)
+          with torch.no_grad():
+              mlr.P_MLR.copy_(t(d[tag + "__P"], dev)); mlr.A_MLR.copy_(t(d[tag + "__A"], dev))
+          embed = HyperMapper(c=c).expmap(z, dim=1)
+          embed.retain_grad()
+          logits = mlr(embed.double()).float()
+          assert max_abs_diff(embed.detach().cpu().numpy(), d[tag + "__embed"]) < 1e-14
+          assert np.abs(logits.detach().cpu().numpy() - d[tag + "__logits"]).max() < 1e-5
+          loss = (logits * t(d[tag + "__Wt"], dev)).sum() + (embed * t(d[tag + "__Ve"], dev)).sum()
+          loss.backward()
 
-        def rel(a, b):
-            return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-        assert z.grad.dtype == torch.float32 and mlr.P_MLR.grad.dtype == torch.float64
-        assert rel(embed.grad.cpu().numpy(), d[tag + "__g_embed"]) < 1e-10, tag
-        assert rel(mlr.P_MLR.grad.cpu().numpy(), d[tag + "__g_P"]) < 1e-10, tag
-        assert rel(mlr.A_MLR.grad.cpu().numpy(), d[tag + "__g_A"]) < 1e-10, tag
-        assert rel(z.grad.cpu().numpy(), d[tag + "__g_z"]) < 2e-6, tag                     # float32 gradient
-        # per-pixel check incl. the clamped / projected / origin pixels
-        gz, want = z.grad.cpu().numpy(), d[tag + "__g_z"]
-        assert np.abs(gz - want).max() <= 2e-6 * np.abs(want).max() + 1e-7
+          def rel(a, b):
+              return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+          assert z.grad.dtype == torch.float32 and mlr.P_MLR.grad.dtype == torch.float64
+          assert rel(embed.grad.cpu().numpy(), d[tag + "__g_embed"]) < 1e-10, tag
+          assert rel(mlr.P_MLR.grad.cpu().numpy(), d[tag + "__g_P"]) < 1e-10, tag
+          assert rel(mlr.A_MLR.grad.cpu().numpy(), d[tag + "__g_A"]) < 1e-10, tag
+          assert rel(z.grad.cpu().numpy(), d[tag + "__g_z"]) < 2e-6, tag                     # float32 gradient
+          # per-pixel check incl. the clamped / projected / origin pixels
+          gz, want = z.grad.cpu().numpy(), d[tag + "__g_z"]
+          assert np.abs(gz - want).max() <= 2e-6 * np.abs(want).max() + 1e-7
+
+
+def test_hypermlr_fused_backward_matches_term_path(dev):
+    """halo_hypermlr_backward (three kernels: reverse sweep + d x, d W partials, parameter algebra) against the term-map path
+    (reverse-sweep kernel + library GEMMs, HALO_MLR_BWD_TERMS=1) it replaces at the heads' shapes: the same per-element sweep,
+    sums in another order.  Shapes: ragged pixel counts (a partial last workgroup, an odd chunk), 1-4 channel blocks, 1-20
+    classes, pixels beyond the projection limit, an exact-origin pixel; and twice the same call -> the same bits."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper, _HyperMLRFn
+    rng = np.random.default_rng(91)
+    for (B, C, O, h, w, c) in ((2, 64, 19, 24, 40, 1.0), (1, 128, 19, 9, 7, 1.0), (1, 256, 5, 5, 13, 0.7), (2, 192, 20, 8, 8, 1.0),
+                               (3, 64, 1, 1, 3, 1.0), (1, 64, 19, 33, 129, 1.3)):
+        z = (rng.standard_normal((B, C, h, w)) * 0.15).astype(np.float32)
+        z[0, :, 0, 0] *= 40.0
+        z[0, :, 0, 1] = 0.0
+        x0 = HyperMapper(c).expmap(t(z, dev), dim=1).double()
+        bound = 1.0 / np.sqrt(C)
+        P0, A0 = t(rng.uniform(-bound, bound, (O, C)), dev), t(rng.uniform(-bound, bound, (O, C)), dev)
+        Wt = t(rng.standard_normal((B, O, h, w)), dev)
+        res = []
+        for env in ({}, {}, {"HALO_MLR_BWD_TERMS": "1"}):
+            with _env_set(env):
+                x, P, A = x0.clone().requires_grad_(True), P0.clone().requires_grad_(True), A0.clone().requires_grad_(True)
+                (_HyperMLRFn.apply(x, P, A, c) * Wt).sum().backward()
+                res.append([g.grad.cpu().numpy() for g in (x, P, A)])
+        for a_, b_ in zip(res[0], res[1]):
+            assert np.array_equal(a_, b_), "the fused backward is not deterministic"
+        for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[2]):
+            assert np.isfinite(a_).all(), (name, B, C, O)
+            assert np.abs(a_ - b_).max() <= 1e-11 * np.abs(b_).max() + 1e-300, (name, B, C, O, h, w, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
+    assert _lib_ws_zero_for_unserved_shapes()
+
+
+def _lib_ws_zero_for_unserved_shapes():
+    from halo_amd import _lib
+    L = _lib.lib()
+    return (L.halo_hypermlr_backward_workspace_bytes(1, 8, 19, 100) == 0 and L.halo_hypermlr_backward_workspace_bytes(1, 64, 21, 100) == 0
+            and L.halo_hypermlr_backward_workspace_bytes(1, 320, 19, 100) == 0 and L.halo_hypermlr_backward_workspace_bytes(2, 64, 19, 100) > 0)
 
 
 def test_empty_and_degenerate_inputs(dev):

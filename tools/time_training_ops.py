@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 
 
 def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
+    fn(); fn(); fn(); torch.cuda.synchronize()          # three warm-up calls: the caching allocator settles (a hipMalloc inside the timed loop costs milliseconds)
     t0 = time.perf_counter()
     for _ in range(n):
         fn()
