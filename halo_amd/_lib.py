@@ -63,8 +63,8 @@ SIGNATURES = {
     "halo_loss_workspace_bytes": (_sz, [_i64]),
     "halo_negative_learning_fwd": (_int, [_vp, _i64, _dbl, _vp, _vp, _sz, _vp]),
     "halo_negative_learning_bwd": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp]),
-    "halo_local_consistent_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "halo_local_consistent_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "halo_local_consistent_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "halo_local_consistent_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "halo_event_create": (_vp, []),
     "halo_event_record": (_int, [_vp, _vp]),
     "halo_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),

@@ -24,24 +24,25 @@ class _LocalConsistentFn(torch.autograd.Function):
         sums = torch.empty(2, dtype=torch.float64, device=dev)
         ca = torch.empty_like(xc) if need_grad else None
         cb = torch.empty_like(xc) if need_grad else None
+        mask = torch.empty((B, h, w), dtype=torch.uint8, device=dev) if need_grad else None      # ca / cb hold values where mask = 1 only
         L = _lib.lib()
         nws = L.halo_loss_workspace_bytes(B * h * w)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         _lib.check(L.halo_local_consistent_fwd(_lib.ptr(xc), _lib.ptr(lab), B, O, h, w, 1 if kl else 0, _lib.ptr(p), _lib.ptr(sums),
-                                               _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(ws), nws, _lib.stream_ptr(dev)),
+                                               _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(mask), _lib.ptr(ws), nws, _lib.stream_ptr(dev)),
                    "halo_local_consistent_fwd")
         if need_grad:
-            ctx.save_for_backward(p, ca, cb, sums)
+            ctx.save_for_backward(p, ca, cb, mask, sums)
         ctx.in_dtype = x.dtype
         return (sums[0] / sums[1]).to(torch.float32)          # 0/0 = nan for an empty selection, like tensor[mask].mean()
 
     @staticmethod
     def backward(ctx, g):
-        p, ca, cb, sums = ctx.saved_tensors
+        p, ca, cb, mask, sums = ctx.saved_tensors
         B, O, h, w = p.shape
         gx = torch.empty_like(p)
         g32 = g.detach().float().reshape(1).contiguous()
-        _lib.check(_lib.lib().halo_local_consistent_bwd(_lib.ptr(p), _lib.ptr(ca), _lib.ptr(cb), B, O, h, w, _lib.ptr(sums),
+        _lib.check(_lib.lib().halo_local_consistent_bwd(_lib.ptr(p), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(mask), B, O, h, w, _lib.ptr(sums),
                                                         _lib.ptr(g32), _lib.ptr(gx), _lib.stream_ptr(p.device)),
                    "halo_local_consistent_bwd")
         return gx.to(ctx.in_dtype), None, None

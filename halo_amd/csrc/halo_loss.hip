@@ -38,24 +38,43 @@ __global__ void __launch_bounds__(LTPB) k_sum2_finalize(const double *__restrict
 
 // ---------------------------------------------------------------- NegativeLearningLoss
 // forward: sums = { sum -mask*log(1 - p + 1e-6), sum mask },  mask = p < threshold
-__global__ void __launch_bounds__(LTPB) k_negative_fwd(const float *__restrict__ p, long long n, float thr, double *__restrict__ partials)
+// (n4 = n / 4 sixteen-byte groups when the tensor allows it -- round 5: the scalar grid-stride loop ran one dependent 4-byte load
+//  per trip; the element order inside a thread's double sums is unchanged in the scalar tail, regrouped in the vector body)
+typedef float f4_l __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(LTPB) k_negative_fwd(const float *__restrict__ p, long long n, long long n4, float thr, double *__restrict__ partials)
 {
     double s = 0.0, c = 0.0;
-    for (long long i = (long long)blockIdx.x * LTPB + threadIdx.x; i < n; i += (long long)gridDim.x * LTPB) {
+    const f4_l *p4 = reinterpret_cast<const f4_l *>(p);
+    for (long long i = (long long)blockIdx.x * LTPB + threadIdx.x; i < n4; i += (long long)gridDim.x * LTPB) {
+        const f4_l v = __builtin_nontemporal_load(p4 + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] < thr) { s += (double)(-det_logf((1.0f - v[e]) + 1e-6f)); c += 1.0; }
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * LTPB + threadIdx.x; i < n; i += (long long)gridDim.x * LTPB) {
         const float v = p[i];
         if (v < thr) { s += (double)(-det_logf((1.0f - v) + 1e-6f)); c += 1.0; }
     }
     block_sum2(s, c, partials + 2 * blockIdx.x);
 }
 // backward: gp = g * mask / ((1 - p + 1e-6) * count)
-__global__ void __launch_bounds__(LTPB) k_negative_bwd(const float *__restrict__ p, long long n, float thr, const double *__restrict__ sums,
+__global__ void __launch_bounds__(LTPB) k_negative_bwd(const float *__restrict__ p, long long n, long long n4, float thr, const double *__restrict__ sums,
                                                        const float *__restrict__ gloss, float *__restrict__ gp)
 {
     const long long i = (long long)blockIdx.x * LTPB + threadIdx.x;
-    if (i >= n) return;
-    const float v = p[i];
     const float scale = (float)((double)gloss[0] / sums[1]);
-    gp[i] = v < thr ? scale / ((1.0f - v) + 1e-6f) : 0.0f;
+    if (i < n4) {
+        const f4_l v = __builtin_nontemporal_load(reinterpret_cast<const f4_l *>(p) + i);
+        f4_l o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] < thr ? scale / ((1.0f - v[e]) + 1e-6f) : 0.0f;
+        __builtin_nontemporal_store(o, reinterpret_cast<f4_l *>(gp) + i);
+    }
+    const long long q = 4 * n4 + i;                                       // scalar remainder: n % 4 elements, or all n when n4 = 0 (unaligned)
+    if (q < n) {
+        const float v = p[q];
+        gp[q] = v < thr ? scale / ((1.0f - v) + 1e-6f) : 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------- softmax over the class planes (B,O,hw)
@@ -71,6 +90,42 @@ __global__ void __launch_bounds__(LTPB) k_softmax_nchw(const float *__restrict__
     for (int c = 0; c < O; ++c) s = s + det_expf(xb[(size_t)c * hw] - m);
     float *pb = p + (size_t)b * O * hw + i;
     for (int c = 0; c < O; ++c) pb[(size_t)c * hw] = det_expf(xb[(size_t)c * hw] - m) / s;
+}
+
+// The same values with every class of FOUR consecutive pixels in registers (O <= OMAX, hw % 4 == 0, 16-byte aligned planes): the
+// planes are read once with O sixteen-byte loads in flight instead of three dependent 4-byte walks (round 5: 124 MB in ~0.2 ms).
+template <int OMAX>
+__global__ void __launch_bounds__(LTPB) k_softmax_nchw_v4(const float *__restrict__ x, int O, long long hw, float *__restrict__ p)
+{
+    const int b = blockIdx.y;
+    const long long i4 = (long long)blockIdx.x * LTPB + threadIdx.x, hw4 = hw >> 2;
+    if (i4 >= hw4) return;
+    const f4_l *xb = reinterpret_cast<const f4_l *>(x + (size_t)b * O * hw) + i4;
+    f4_l v[OMAX];
+#pragma unroll
+    for (int c = 0; c < OMAX; ++c)
+        if (c < O) v[c] = __builtin_nontemporal_load(xb + (size_t)c * hw4);
+    f4_l m = v[0];
+#pragma unroll
+    for (int c = 1; c < OMAX; ++c)
+        if (c < O)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = v[c][e] > m[e] ? v[c][e] : m[e];
+    f4_l sden = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < OMAX; ++c)
+        if (c < O)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[c][e] = det_expf(v[c][e] - m[e]); sden[e] = sden[e] + v[c][e]; }
+    f4_l *pb = reinterpret_cast<f4_l *>(p + (size_t)b * O * hw) + i4;
+#pragma unroll
+    for (int c = 0; c < OMAX; ++c)
+        if (c < O) {
+            f4_l o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[c][e] / sden[e];
+            pb[(size_t)c * hw4] = o;
+        }
 }
 
 // semantic boundary & valid label (boundary.py:48-61 with zero padding, local_consistent_loss.py:14-15)
@@ -90,10 +145,12 @@ __device__ __forceinline__ bool lcl_mask(const long long *__restrict__ lab, int 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Per masked pixel: l = sum_c |p - mean| (l1) or sum_c p*log(p/(mean+1e-6)+1e-6) (kl), mean = 3x3 replicate-padded box
-// mean; block partial sums of (l, 1).  When coef != nullptr also writes, per (pixel, class), a = dl/dp (direct) and
-// b = dl/dmean for the backward pass (zeros outside the mask).
+// mean; block partial sums of (l, 1).  When ca != nullptr also writes the mask as one byte per pixel and, AT MASKED PIXELS ONLY,
+// per class a = dl/dp (direct) and b = dl/dmean for the backward pass: the boundary is a few per cent of the pixels, and round 4's
+// dense coefficient maps were 2 x 124 MB of zeros written here and read nine times over in the backward.
 __global__ void __launch_bounds__(LTPB) k_lcl_fwd(const float *__restrict__ p, const long long *__restrict__ label, int O, int h, int w,
-                                                  int kl, double *__restrict__ partials, float *__restrict__ ca, float *__restrict__ cb)
+                                                  int kl, double *__restrict__ partials, float *__restrict__ ca, float *__restrict__ cb,
+                                                  unsigned char *__restrict__ mask)
 {
     const int b = blockIdx.y;
     const long long hw = (long long)h * w;
@@ -102,17 +159,23 @@ __global__ void __launch_bounds__(LTPB) k_lcl_fwd(const float *__restrict__ p, c
     if (i < hw) {
         const int y = (int)(i / w), x = (int)(i % w);
         const bool m = lcl_mask(label + (size_t)b * hw, h, w, y, x);
-        const float *pb = p + (size_t)b * O * hw;
-        float l = 0.0f;
-        for (int c = 0; c < O; ++c) {
-            float a = 0.0f, bb = 0.0f;
-            if (m) {
+        if (mask) mask[(size_t)b * hw + i] = m ? 1 : 0;
+        if (m) {
+            const float *pb = p + (size_t)b * O * hw;
+            const int ym = clampi(y - 1, 0, h - 1), yp = clampi(y + 1, 0, h - 1), xm = clampi(x - 1, 0, w - 1), xp = clampi(x + 1, 0, w - 1);
+            float l = 0.0f;
+#pragma unroll 4
+            for (int c = 0; c < O; ++c) {
                 const float *pc = pb + (size_t)c * hw;
+                const float *r0 = pc + (size_t)ym * w, *r1 = pc + (size_t)y * w, *r2 = pc + (size_t)yp * w;
+                // the nine taps in the order dy = -1..1, dx = -1..1 of the replicate-padded window
+                const float t0 = r0[xm], t1 = r0[x], t2 = r0[xp], t3 = r1[xm], t4 = r1[x], t5 = r1[xp], t6 = r2[xm], t7 = r2[x], t8 = r2[xp];
                 float mean = 0.0f;
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx)
-                        mean = __builtin_fmaf(pc[(size_t)clampi(y + dy, 0, h - 1) * w + clampi(x + dx, 0, w - 1)], 1.0f / 9.0f, mean);
-                const float pv = pc[i];
+                mean = __builtin_fmaf(t0, 1.0f / 9.0f, mean); mean = __builtin_fmaf(t1, 1.0f / 9.0f, mean); mean = __builtin_fmaf(t2, 1.0f / 9.0f, mean);
+                mean = __builtin_fmaf(t3, 1.0f / 9.0f, mean); mean = __builtin_fmaf(t4, 1.0f / 9.0f, mean); mean = __builtin_fmaf(t5, 1.0f / 9.0f, mean);
+                mean = __builtin_fmaf(t6, 1.0f / 9.0f, mean); mean = __builtin_fmaf(t7, 1.0f / 9.0f, mean); mean = __builtin_fmaf(t8, 1.0f / 9.0f, mean);
+                const float pv = t4;
+                float a, bb;
                 if (!kl) {
                     const float d = pv - mean;
                     l = l + (d < 0.0f ? -d : d);
@@ -124,45 +187,118 @@ __global__ void __launch_bounds__(LTPB) k_lcl_fwd(const float *__restrict__ p, c
                     a = lg + (pv / me) / re;                 // d/dp [p log(p/me + eps)]
                     bb = -(pv * pv) / (me * me * re);        // d/dmean
                 }
+                if (ca) { ca[((size_t)b * O + c) * hw + i] = a; cb[((size_t)b * O + c) * hw + i] = bb; }
             }
-            if (ca) { ca[((size_t)b * O + c) * hw + i] = a; cb[((size_t)b * O + c) * hw + i] = bb; }
+            ls = (double)l; cnt = 1.0;
         }
-        if (m) { ls = (double)l; cnt = 1.0; }
     }
     block_sum2(ls, cnt, partials + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
 // gx = softmax-backward( gp ),  gp_c(j) = a_c(j) + sum_{i in 3x3(j)} mult(i -> j)/9 * b_c(i),  scaled by g / count.
-// mult(i -> j) = number of taps of i's replicate-padded window that land on j.
+// mult(i -> j) = number of taps of i's replicate-padded window that land on j.  a / b exist at masked pixels only (mask byte map):
+// a pixel with no masked pixel in its 3x3 neighbourhood has gp = 0 for every class, hence gx = 0 -- it writes its zeros and reads
+// nothing else (most pixels).  gp of the O classes stays in registers between the dot product and the write (O <= OMAX).
+template <int OMAX>
 __global__ void __launch_bounds__(LTPB) k_lcl_bwd(const float *__restrict__ p, const float *__restrict__ ca, const float *__restrict__ cb,
-                                                  int O, int h, int w, const double *__restrict__ sums, const float *__restrict__ gloss,
-                                                  float *__restrict__ gx)
+                                                  const unsigned char *__restrict__ mask, int O, int h, int w, const double *__restrict__ sums,
+                                                  const float *__restrict__ gloss, float *__restrict__ gx)
 {
     const int b = blockIdx.y;
     const long long hw = (long long)h * w;
     const long long j = (long long)blockIdx.x * LTPB + threadIdx.x;
     if (j >= hw) return;
     const int y = (int)(j / w), x = (int)(j % w);
+    const size_t base = (size_t)b * O * hw;
+    const unsigned char *mb = mask + (size_t)b * hw;
+    // neighbour (y + ny, x + nx): its weight is multiplicity / 9 where it exists AND is masked, else 0; the multiplicity is a
+    // product of a row and a column count (how many of the neighbour's three clamped taps along that axis land on this pixel:
+    // 1 in the interior, 2 for an edge pixel seen from itself).  Offsets are clamped into the image so that every load below is
+    // unconditional (no branch per tap: round 5's first version spent its time in 171 of them per pixel); a zero weight SELECTS
+    // zero, because b holds no value at unmasked pixels.
+    int cy[3], cx[3];
+#pragma unroll
+    for (int n = -1; n <= 1; ++n) {
+        const int iy = y + n, ix = x + n;
+        int ky = 0, kx = 0;
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) { ky += clampi(iy + d, 0, h - 1) == y ? 1 : 0; kx += clampi(ix + d, 0, w - 1) == x ? 1 : 0; }
+        cy[n + 1] = (iy >= 0 && iy < h) ? ky : 0;
+        cx[n + 1] = (ix >= 0 && ix < w) ? kx : 0;
+    }
+    float wgt[9];
+    int off[9];
+    bool any = false;
+#pragma unroll
+    for (int ny = -1; ny <= 1; ++ny)
+#pragma unroll
+        for (int nx = -1; nx <= 1; ++nx) {
+            const int o_ = clampi(y + ny, 0, h - 1) * w + clampi(x + nx, 0, w - 1);
+            const int mult = mb[o_] ? cy[ny + 1] * cx[nx + 1] : 0;      // (a clamped duplicate of an existing pixel has count 0)
+            off[(ny + 1) * 3 + nx + 1] = o_;
+            wgt[(ny + 1) * 3 + nx + 1] = (float)mult * (1.0f / 9.0f);
+            any = any || mult != 0;
+        }
+    if (!any) {
+#pragma unroll 4
+        for (int c = 0; c < O; ++c) gx[base + (size_t)c * hw + j] = 0.0f;
+        return;
+    }
     const double cnt = sums[1];
     const float scale = cnt > 0.0 ? (float)((double)gloss[0] / cnt) : 0.0f;       // mean over an empty selection: zero gradient
-    // multiplicities of the <= 9 neighbours
+    const bool mj = mb[j] != 0;
+    float gpv[OMAX], pvv[OMAX], dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < OMAX; ++c) {
+        if (c < O) {
+            const float *bc = cb + base + (size_t)c * hw;
+            const float av = ca[base + (size_t)c * hw + j];
+            float t[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) t[q] = bc[off[q]];
+            float gp = mj ? av : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) gp = __builtin_fmaf(wgt[q], wgt[q] != 0.0f ? t[q] : 0.0f, gp);
+            gpv[c] = gp;
+            pvv[c] = p[base + (size_t)c * hw + j];
+            dot = __builtin_fmaf(pvv[c], gp, dot);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < OMAX; ++c)
+        if (c < O) gx[base + (size_t)c * hw + j] = scale * (pvv[c] * (gpv[c] - dot));
+}
+// any number of classes: the same statements with gp recomputed in the second pass
+__global__ void __launch_bounds__(LTPB) k_lcl_bwd_any(const float *__restrict__ p, const float *__restrict__ ca, const float *__restrict__ cb,
+                                                      const unsigned char *__restrict__ mask, int O, int h, int w, const double *__restrict__ sums,
+                                                      const float *__restrict__ gloss, float *__restrict__ gx)
+{
+    const int b = blockIdx.y;
+    const long long hw = (long long)h * w;
+    const long long j = (long long)blockIdx.x * LTPB + threadIdx.x;
+    if (j >= hw) return;
+    const int y = (int)(j / w), x = (int)(j % w);
+    const size_t base = (size_t)b * O * hw;
+    const unsigned char *mb = mask + (size_t)b * hw;
     float wgt[3][3];
     for (int ny = -1; ny <= 1; ++ny)
         for (int nx = -1; nx <= 1; ++nx) {
             const int iy = y + ny, ix = x + nx;
             int mult = 0;
-            if (iy >= 0 && iy < h && ix >= 0 && ix < w)
+            if (iy >= 0 && iy < h && ix >= 0 && ix < w && mb[(size_t)iy * w + ix])
                 for (int dy = -1; dy <= 1; ++dy)
                     for (int dx = -1; dx <= 1; ++dx)
                         mult += (clampi(iy + dy, 0, h - 1) == y && clampi(ix + dx, 0, w - 1) == x) ? 1 : 0;
             wgt[ny + 1][nx + 1] = (float)mult * (1.0f / 9.0f);
         }
-    const size_t base = (size_t)b * O * hw;
+    const double cnt = sums[1];
+    const float scale = cnt > 0.0 ? (float)((double)gloss[0] / cnt) : 0.0f;
+    const bool mj = mb[j] != 0;
     float dot = 0.0f;
     for (int pass = 0; pass < 2; ++pass)
         for (int c = 0; c < O; ++c) {
             const float *bc = cb + base + (size_t)c * hw;
-            float gp = ca[base + (size_t)c * hw + j];
+            float gp = mj ? ca[base + (size_t)c * hw + j] : 0.0f;
             for (int ny = -1; ny <= 1; ++ny)
                 for (int nx = -1; nx <= 1; ++nx) {
                     const float wv = wgt[ny + 1][nx + 1];
@@ -193,7 +329,8 @@ extern "C" int halo_negative_learning_fwd(const float *p, int64_t n, double thre
     if (!workspace || workspace_bytes < (size_t)nblk * 16 + 256) return fail(HALO_E_WORKSPACE, "halo_negative_learning_fwd: workspace too small");
     double *part = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_negative_fwd, dim3(nblk), dim3(LTPB), 0, st, p, (long long)n, (float)threshold, part);
+    const long long n4 = ((uintptr_t)p % 16) == 0 ? n / 4 : 0;
+    hipLaunchKernelGGL(k_negative_fwd, dim3(nblk), dim3(LTPB), 0, st, p, (long long)n, n4, (float)threshold, part);
     hipLaunchKernelGGL(k_sum2_finalize, dim3(1), dim3(LTPB), 0, st, (const double *)part, nblk, sums);
     return check_launch("halo_negative_learning_fwd");
 }
@@ -202,36 +339,46 @@ extern "C" int halo_negative_learning_bwd(const float *p, int64_t n, double thre
                                           float *gp, void *stream)
 {
     if (!p || !sums || !gloss || !gp || n <= 0) return fail(HALO_E_ARG, "halo_negative_learning_bwd: null/empty argument");
-    hipLaunchKernelGGL(k_negative_bwd, dim3((unsigned)cdiv(n, LTPB)), dim3(LTPB), 0, (hipStream_t)stream, p, (long long)n, (float)threshold, sums, gloss, gp);
+    const long long n4 = (((uintptr_t)p | (uintptr_t)gp) % 16) == 0 ? n / 4 : 0;
+    const long long nthreads = n4 > 0 ? (n4 > n - 4 * n4 ? n4 : n - 4 * n4) : n;
+    hipLaunchKernelGGL(k_negative_bwd, dim3((unsigned)cdiv(nthreads, LTPB)), dim3(LTPB), 0, (hipStream_t)stream, p, (long long)n, n4, (float)threshold, sums, gloss, gp);
     return check_launch("halo_negative_learning_bwd");
 }
 
 // LocalConsistentLoss.forward: x (B,O,h,w) logits, label (B,h,w) i64 -> p (softmax, kept for backward), sums = {sum l, count};
 // coef_a / coef_b (B,O,h,w) receive dl/dp and dl/dmean when not NULL.  kl: 0 = 'l1', 1 = 'kl'.
 extern "C" int halo_local_consistent_fwd(const float *x, const int64_t *label, int64_t B, int64_t O, int64_t h, int64_t w, int kl,
-                                         float *p, double *sums, float *coef_a, float *coef_b, void *workspace,
+                                         float *p, double *sums, float *coef_a, float *coef_b, uint8_t *mask, void *workspace,
                                          size_t workspace_bytes, void *stream)
 {
     if (!x || !label || !p || !sums || B <= 0 || O <= 0 || h <= 0 || w <= 0) return fail(HALO_E_ARG, "halo_local_consistent_fwd: null/empty argument");
-    if ((coef_a == nullptr) != (coef_b == nullptr)) return fail(HALO_E_ARG, "halo_local_consistent_fwd: coef_a and coef_b go together");
+    if ((coef_a == nullptr) != (coef_b == nullptr) || (coef_a == nullptr) != (mask == nullptr))
+        return fail(HALO_E_ARG, "halo_local_consistent_fwd: coef_a, coef_b and mask go together");
     const long long hw = (long long)h * w;
     const int nb = (int)cdiv(hw, LTPB), nblk = nb * (int)B;
     if (!workspace || workspace_bytes < (size_t)nblk * 16 + 256) return fail(HALO_E_WORKSPACE, "halo_local_consistent_fwd: workspace too small");
     double *part = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nb, (unsigned)B);
-    hipLaunchKernelGGL(k_softmax_nchw, grid, dim3(LTPB), 0, st, x, (int)O, hw, p);
-    hipLaunchKernelGGL(k_lcl_fwd, grid, dim3(LTPB), 0, st, (const float *)p, (const long long *)label, (int)O, (int)h, (int)w, kl, part, coef_a, coef_b);
+    if (O <= 20 && hw % 4 == 0 && (((uintptr_t)x | (uintptr_t)p) % 16) == 0)
+        hipLaunchKernelGGL((k_softmax_nchw_v4<20>), dim3((unsigned)cdiv(hw / 4, LTPB), (unsigned)B), dim3(LTPB), 0, st, x, (int)O, hw, p);
+    else
+        hipLaunchKernelGGL(k_softmax_nchw, grid, dim3(LTPB), 0, st, x, (int)O, hw, p);
+    hipLaunchKernelGGL(k_lcl_fwd, grid, dim3(LTPB), 0, st, (const float *)p, (const long long *)label, (int)O, (int)h, (int)w, kl, part, coef_a, coef_b,
+                       (unsigned char *)mask);
     hipLaunchKernelGGL(k_sum2_finalize, dim3(1), dim3(LTPB), 0, st, (const double *)part, nblk, sums);
     return check_launch("halo_local_consistent_fwd");
 }
 
-extern "C" int halo_local_consistent_bwd(const float *p, const float *coef_a, const float *coef_b, int64_t B, int64_t O, int64_t h,
-                                         int64_t w, const double *sums, const float *gloss, float *gx, void *stream)
+extern "C" int halo_local_consistent_bwd(const float *p, const float *coef_a, const float *coef_b, const uint8_t *mask, int64_t B, int64_t O,
+                                         int64_t h, int64_t w, const double *sums, const float *gloss, float *gx, void *stream)
 {
-    if (!p || !coef_a || !coef_b || !sums || !gloss || !gx || B <= 0 || O <= 0 || h <= 0 || w <= 0)
+    if (!p || !coef_a || !coef_b || !mask || !sums || !gloss || !gx || B <= 0 || O <= 0 || h <= 0 || w <= 0)
         return fail(HALO_E_ARG, "halo_local_consistent_bwd: null/empty argument");
     dim3 grid((unsigned)cdiv(h * w, LTPB), (unsigned)B);
-    hipLaunchKernelGGL(k_lcl_bwd, grid, dim3(LTPB), 0, (hipStream_t)stream, p, coef_a, coef_b, (int)O, (int)h, (int)w, sums, gloss, gx);
+    if (O <= 20)
+        hipLaunchKernelGGL((k_lcl_bwd<20>), grid, dim3(LTPB), 0, (hipStream_t)stream, p, coef_a, coef_b, (const unsigned char *)mask, (int)O, (int)h, (int)w, sums, gloss, gx);
+    else
+        hipLaunchKernelGGL(k_lcl_bwd_any, grid, dim3(LTPB), 0, (hipStream_t)stream, p, coef_a, coef_b, (const unsigned char *)mask, (int)O, (int)h, (int)w, sums, gloss, gx);
     return check_launch("halo_local_consistent_bwd");
 }

@@ -1731,6 +1731,54 @@ def test_training_losses_match_reference_values_and_gradients(golden, dev):
         LocalConsistentLoss(19, "l2")
 
 
+def _torch_local_consistent(x, label, kl):
+    """plain torch statement of LocalConsistentLoss (core/loss/local_consistent_loss.py:12-17, boundary.py:48-61, 94-103) on x's device"""
+    import torch.nn.functional as F
+    O = x.shape[1]
+    p = torch.softmax(x, dim=1)
+    mean = F.conv2d(F.pad(p, (1, 1, 1, 1), mode="replicate"), torch.full((O, 1, 3, 3), 1.0 / 9.0, device=x.device), groups=O)
+    l = (p * torch.log(p / (mean + 1e-6) + 1e-6)).sum(dim=1) if kl else (p - mean).abs().sum(dim=1)
+    k = torch.tensor([[[[-1., -1., -1.], [-1., 8., -1.], [-1., -1., -1.]]]], device=x.device)
+    mask = (F.conv2d(label.float().unsqueeze(1), k, padding=1).long().squeeze(1) != 0) & (label != 255)
+    return l[mask].mean()
+
+
+def test_training_losses_ragged_shapes_and_many_classes(dev):
+    """The loss kernels' other arms against a plain torch statement of the same modules under autograd: pixel counts that are not a
+    multiple of four (scalar softmax), more than 20 classes (two-pass backward), one class, a single row / column, a label map
+    with no boundary at all in one image, ignore labels; NegativeLearningLoss on unaligned views and lengths n % 4 != 0."""
+    from halo_amd.core.loss import LocalConsistentLoss, NegativeLearningLoss
+    g = torch.Generator(device="cpu").manual_seed(31)
+    for (B, O, h, w) in ((2, 19, 24, 40), (1, 19, 7, 9), (2, 21, 6, 10), (1, 3, 1, 17), (1, 5, 13, 1), (2, 1, 5, 6), (1, 20, 16, 12)):
+        x0 = (torch.randn((B, O, h, w), generator=g) * 2.0).to(dev)
+        label = torch.randint(0, max(2, O), (B, (h + 3) // 4, (w + 3) // 4), generator=g).repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :h, :w].contiguous()
+        label[torch.rand((B, h, w), generator=g) < 0.1] = 255
+        if B > 1:
+            label[1] = 3                                              # no boundary in the second image
+        label = label.to(dev)
+        for lt in ("l1", "kl"):
+            xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+            la = LocalConsistentLoss(O, lt)(xa, label)
+            lb = _torch_local_consistent(xb, label, lt == "kl")
+            if bool(torch.isnan(lb)):
+                assert bool(torch.isnan(la))
+                continue
+            assert abs(la.item() - lb.item()) < 3e-6 * max(1.0, abs(lb.item())), (B, O, h, w, lt, la.item(), lb.item())
+            (ga,), (gb,) = torch.autograd.grad(la, xa), torch.autograd.grad(lb, xb)
+            assert float((ga - gb).abs().max()) < 3e-5 * float(gb.abs().max()) + 1e-9, (B, O, h, w, lt)
+    for n, off in ((1000, 0), (1003, 0), (1001, 1), (5, 3), (4096, 2)):
+        buf = torch.rand(n + off + 8, generator=g).to(dev) * 0.2
+        pa, pb = buf[off:off + n].clone().requires_grad_(True), buf[off:off + n].clone().requires_grad_(True)
+        view = buf[off:off + n].detach().requires_grad_(True)       # an unaligned view of the buffer
+        la = NegativeLearningLoss(0.05)(view if off else pa)
+        mk = (pb < 0.05).detach()
+        lb = (-(mk * torch.log(1 - pb + 1e-6))).sum() / mk.sum()
+        assert abs(la.item() - lb.item()) < 3e-6, (n, off)
+        (ga,) = torch.autograd.grad(la, view if off else pa)
+        (gb,) = torch.autograd.grad(lb, pb)
+        assert float((ga - gb).abs().max()) < 3e-5 * float(gb.abs().max()), (n, off)
+
+
 @pytest.mark.parametrize("c", [0.5, 2.0])
 def test_score_with_other_curvatures(dev, c):
     """cfg.MODEL.CURVATURE != 1 reaches the scorer through HyperMapper(c) (floating_region.py:68)."""
