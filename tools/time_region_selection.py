@@ -77,7 +77,7 @@ def batched(items, nb):
 
 STAGING = os.environ.get("HALO_RS_STAGING", "table")
 REPEATS = int(os.environ.get("HALO_RS_REPEATS", "5"))
-for MODE, busy in (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0)):
+for MODE, busy in (() if os.environ.get("HALO_RS_FLOOR_ONLY") else (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0))):
     CONFIGS = ((0, 1, 1, "serial (in_flight=0, 1 writer)"), (8, 8, 1, "pipelined (in_flight=8, 4 streams, 8 writers)"), (8, 16, 1, "pipelined (in_flight=8, 4 streams, 16 writers)"),
                (8, 12, 1, "pipelined (in_flight=8, 4 streams, 12 writers)"), (None, None, 1, "pipelined (defaults)"),
                (None, None, 2, "pipelined (defaults), loader batch 2"), (None, None, 4, "pipelined (defaults), loader batch 4"))
@@ -116,7 +116,7 @@ def writers_alone(n_threads):
     import numpy as np
     from halo_amd import _hostlib
     from halo_amd.core.active.build import _IndicatorTemplate
-    tmp = tempfile.mkdtemp(prefix="halo_rs_w_")
+    tmp = tempfile.mkdtemp(prefix="halo_rs_w_", dir=os.environ.get("HALO_RS_TMP"))            # HALO_RS_TMP=/dev/shm: the same work without the disk-backed file system
     rng = np.random.default_rng(0)
     om = np.full((H, W), 255, np.int64); gt = rng.integers(0, O, (H, W)).astype(np.int64)
     act = np.zeros((H, W), np.bool_); sel = np.zeros((H, W), np.bool_)
@@ -132,7 +132,8 @@ def writers_alone(n_threads):
                 i = nxt[0]; nxt[0] += 1
             if i >= N:
                 return
-            _hostlib.retire_image(os.path.join(tmp, f"m{i}.png"), os.path.join(tmp, f"i{i}.pth"), om, gt, picks, k, 1, act, sel, tpl, compose_mask_radius=5)
+            _hostlib.retire_image(os.path.join(tmp, f"m{i}.png"), os.path.join(tmp, f"i{i}.pth"), om, gt, picks, k, 1, act, sel,
+                                  None if os.environ.get("HALO_RS_NO_INDICATOR") else tpl, compose_mask_radius=5)
     runs = []
     for _ in range(REPEATS + 1):
         nxt[0] = 0
