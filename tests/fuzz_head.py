@@ -34,6 +34,7 @@ def rel(a, b):
 
 
 worst = {}
+worst_mlr_case = None
 t0 = time.time()
 for i in range(N):
     c = float(rng.choice([1.0, 1.0, 0.5, 2.0, 0.1]))
@@ -85,6 +86,8 @@ for i in range(N):
         got64 = mlr._hyper_logits(t(e_or)).cpu().numpy()
         got32 = mlr._hyper_logits(t(e_or), out_dtype=torch.float32).cpu().numpy()
     r = float(np.max(np.abs(got64 - want) / np.maximum(1.0, np.abs(want))))
+    if r > worst.get("hypermlr f64", 0.0):
+        worst_mlr_case = dict(desc, O=O, r=r)
     worst["hypermlr f64"] = max(worst.get("hypermlr f64", 0.0), r)
     if not np.array_equal(np.isnan(got64), np.isnan(want)) or r > 1e-9:
         print("MISMATCH hypermlr", r, dict(desc, O=O)); sys.exit(1)
@@ -98,5 +101,35 @@ for i in range(N):
             print("MISMATCH bilinear", arr.dtype, dict(desc, H2=H2, W2=W2)); sys.exit(1)
     if i % 25 == 0:
         print("case %d ok %s" % (i, dict(desc, O=O, H2=H2, W2=W2)), flush=True)
+# the fused native HyperMLR backward (halo_hypermlr_backward: <= 20 classes, 64 | C <= 256) against the term-map path it replaces
+from halo_amd.core.utils.hyperbolic import _HyperMLRFn
+for i in range(max(1, N // 10)):
+    c = float(rng.choice([1.0, 1.0, 0.5, 2.0, 0.1]))
+    B, C, O = int(rng.integers(1, 4)), int(rng.choice([64, 64, 128, 192, 256])), int(rng.integers(1, 21))
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+    scale = float(rng.choice([1e-3, 0.05, 0.2, 1.0, 30.0]))
+    z = (rng.standard_normal((B, C, h, w)) * scale).astype(np.float32)
+    if rng.random() < 0.3:
+        z[0, :, 0, 0] = 0.0
+    desc = dict(i=i, c=c, B=B, C=C, O=O, h=h, w=w, scale=scale)
+    x0 = HyperMapper(c).expmap(t(z), dim=1).double()
+    bound = 1.0 / np.sqrt(C)
+    P0, A0, Wt = t(rng.uniform(-bound, bound, (O, C))), t(rng.uniform(-bound, bound, (O, C))), t(rng.standard_normal((B, O, h, w)))
+    res = []
+    for env in (None, "1"):
+        if env:
+            os.environ["HALO_MLR_BWD_TERMS"] = env
+        else:
+            os.environ.pop("HALO_MLR_BWD_TERMS", None)
+        xg, Pg, Ag = x0.clone().requires_grad_(True), P0.clone().requires_grad_(True), A0.clone().requires_grad_(True)
+        (_HyperMLRFn.apply(xg, Pg, Ag, c) * Wt).sum().backward()
+        res.append([g.grad.cpu().numpy() for g in (xg, Pg, Ag)])
+    os.environ.pop("HALO_MLR_BWD_TERMS", None)
+    for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[1]):
+        r = float(np.abs(a_ - b_).max() / (np.abs(b_).max() + 1e-300))
+        worst["mlr backward " + name] = max(worst.get("mlr backward " + name, 0.0), r)
+        if not np.isfinite(a_).all() or r > 1e-10:
+            print("MISMATCH fused backward", name, r, desc); sys.exit(1)
+print("worst hypermlr case:", worst_mlr_case)
 print("fuzz_head: %d cases, seed %d, %.0f s: dist0 / bilinear bit for bit; worst relative differences %s" %
       (N, SEED, time.time() - t0, {k: float("%.2g" % v) for k, v in worst.items()}))
