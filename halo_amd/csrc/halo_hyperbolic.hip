@@ -1300,13 +1300,13 @@ __global__ void __launch_bounds__(256) k_mlr_bwd_dx(const double *__restrict__ x
 // wave's steps; the workgroup's four waves are added through LDS as (0 + 1) + (2 + 3) and leave ONE partial per workgroup and
 // column block.  (First version, VALU over LDS-staged chunks: 205 us at the training shape, latency-bound in its staging loop.)
 __global__ void __launch_bounds__(256) k_mlr_bwd_weights(const double *__restrict__ x, const double *__restrict__ Dws, int O, int C,
-                                                         long long hw, int Bn, double *__restrict__ w_part)
+                                                         long long hw, int Bn, int vec_ok, double *__restrict__ w_part)
 {
     constexpr int NCT = 2;                                               // 16-column tiles per workgroup (blockIdx.y = 32-column block): 24 accumulators,
     __shared__ double s_acc[2][48 * 16 * NCT];                           // several waves per SIMD to cover the operand loads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, k = lane >> 4, cb = blockIdx.y;
     const long long spi = (hw + 15) / 16, nsteps = spi * Bn;             // steps per image
-    const bool vec = (hw & 3) == 0;                                      // 32-byte aligned pixel quads
+    const bool vec = vec_ok != 0;                                        // host: hw % 4 == 0 and 16-byte aligned bases -> aligned pixel quads
     v4d_t acc[3][NCT];
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt)
@@ -1941,8 +1941,9 @@ extern "C" int halo_hypermlr_backward(const double *x, const double *P, const do
     {
         const long long nsteps = cdiv(hw, 16) * B;
         const unsigned g = (unsigned)(cdiv(nsteps, 4) < MLRB_NWG ? cdiv(nsteps, 4) : MLRB_NWG);
+        const int vec_ok = hw % 4 == 0 && (((uintptr_t)x | (uintptr_t)Dws) % 16) == 0;
         hipLaunchKernelGGL(k_mlr_bwd_weights, dim3(g, (unsigned)(C / 32)), dim3(256), 0, st, x, (const double *)Dws, (int)O, (int)C, (long long)hw,
-                           (int)B, w_part);
+                           (int)B, vec_ok, w_part);
         hipLaunchKernelGGL(k_mlr_bwd_final, dim3((unsigned)O), dim3(MLRF_TPB), 0, st, A, (const double *)consts, (const double *)w_part, (int)g,
                            (const double *)cls_part, (int)npb, (int)O, (int)C, gP, gA);
     }

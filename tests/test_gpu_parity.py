@@ -1431,6 +1431,16 @@ def test_hypermlr_fused_backward_matches_term_path(dev):
         for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[2]):
             assert np.isfinite(a_).all(), (name, B, C, O)
             assert np.abs(a_ - b_).max() <= 1e-11 * np.abs(b_).max() + 1e-300, (name, B, C, O, h, w, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
+        # the same input at an address that is 8 but not 16 bytes aligned (a contiguous view one element into a buffer): the
+        # 16-byte operand loads of the weight-gradient kernel and of the forward give way to their scalar arms
+        buf = torch.empty(x0.numel() + 1, dtype=torch.float64, device=dev)
+        buf[1:].copy_(x0.reshape(-1))
+        xu = buf[1:].view_as(x0).detach().requires_grad_(True)
+        assert xu.data_ptr() % 16 == 8
+        Pu, Au = P0.clone().requires_grad_(True), A0.clone().requires_grad_(True)
+        (_HyperMLRFn.apply(xu, Pu, Au, c) * Wt).sum().backward()
+        for name, a_, b_ in zip(("gx", "gP", "gA"), (xu.grad, Pu.grad, Au.grad), res[0]):
+            assert np.abs(a_.cpu().numpy() - b_).max() <= 1e-11 * np.abs(b_).max() + 1e-300, ("unaligned", name, B, C, O, h, w)
     assert _lib_ws_zero_for_unserved_shapes()
 
 
