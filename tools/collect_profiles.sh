@@ -59,6 +59,7 @@ done
 run ab_feat_map.txt python3 $R/tools/ab_feat_map.py
 run ab_lowres_dma.txt python3 $R/tools/ab_lowres_dma.py
 run gram_ab.txt python3 $R/tools/ab_gram.py
+run ab_mlr_epilogue.txt python3 $R/tools/ab_mlr_epilogue.py
 # ---- selection, the RegionSelection driver, the head tail, training ops
 METHODS=auto,serial run select_timing.txt python3 $R/tools/time_select.py
 METHODS=auto RANGED=1 run select_timing_ranged.txt python3 $R/tools/time_select.py
@@ -70,6 +71,11 @@ run branches.txt python3 $R/tools/time_branches.py
 run feat_alone.txt python3 $R/tools/time_feat.py
 run lowres_timing.txt python3 $R/tools/time_lowres.py
 run training_ops.txt python3 $R/tools/time_training_ops.py
+run mlr_backward.txt python3 $R/tools/time_mlr_bwd.py
+HALO_RS_FLOOR_ONLY=1 HALO_RS_TMP=/dev/shm run region_selection_host_floor_tmpfs.txt python3 $R/tools/time_region_selection.py
+HALO_RS_FLOOR_ONLY=1 HALO_RS_NO_INDICATOR=1 run region_selection_host_floor_mask_only.txt python3 $R/tools/time_region_selection.py
+run fuzz_head.txt python3 $R/tests/fuzz_head.py 1500 11
+prof trace_head_bwd --kernel-trace --stats --output-format csv -d $OUT/trace_head_bwd -- python3 $R/tools/prof_head_bwd.py
 prof trace_feat_alone --kernel-trace --stats --output-format csv -d $OUT/trace_feat_alone -- python3 $R/tools/time_feat.py
 prof trace_head --kernel-trace --stats --output-format csv -d $OUT/trace_head -- python3 $R/tools/time_head.py
 prof trace_select --kernel-trace --stats --output-format csv -d $OUT/trace_select -- python3 $R/tools/time_select.py

@@ -78,6 +78,7 @@ def main():
     stats_csv("trace_f32/*/*_kernel_stats.csv", RND + "_kernel_stats_f32.csv", 25)
     stats_csv("trace_lowres_gram/*/*_kernel_stats.csv", RND + "_kernel_stats_lowres_gram.csv", 25)
     stats_csv("trace_head/*/*_kernel_stats.csv", RND + "_kernel_stats_head.csv", 25)
+    stats_csv("trace_head_bwd/*/*_kernel_stats.csv", RND + "_kernel_stats_head_bwd.csv", 25)
     lr = counters("pmc_lowres/*/*counter_collection.csv")
     if lr:
         clk = counters("pmc_lowres_clk/*/*counter_collection.csv")
@@ -108,10 +109,13 @@ def main():
     for t in ("select_timing.txt", "select_timing_mrad3.txt", "region_selection_timing.txt", "secondary_kernels.txt", "branches.txt", "training_ops.txt", "feat_alone.txt", "lowres_timing.txt", "tail_timeline.txt", "ab_lowres_dma.txt", "two_ranks_one_gpu.txt", "select_timing_ranged.txt",
               "select16_breakdown.txt", "bench_repeats.txt", "ab_feat_map.txt", "region_selection_timing_device_staging.txt",
               "region_selection_timing_python_writer.txt", "host_pieces.txt", "hw_queues.txt", "gram_ab.txt", "op_rate.txt",
-              "lowres_overlap_probe.txt", "head_timing.txt", "region_selection_timing_eager_launches.txt", "FAILED"):
+              "lowres_overlap_probe.txt", "head_timing.txt", "region_selection_timing_eager_launches.txt", "ab_mlr_epilogue.txt", "mlr_backward.txt",
+              "region_selection_host_floor_tmpfs.txt", "region_selection_host_floor_mask_only.txt", "fuzz_head.txt", "FAILED"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]
+            if t == "fuzz_head.txt":
+                keep = keep[-2:]
             open(os.path.join(DST, RND + "_" + t), "w").writelines(keep)
     # ---- HBM traffic of the roofline kernel (two separate --pmc passes; gfx950: FETCH_SIZE doubled)
     fetch, write = counters("pmc_fetch/*/*counter_collection.csv"), counters("pmc_write/*/*counter_collection.csv")
