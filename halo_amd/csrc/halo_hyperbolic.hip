@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(HTPB) k_pdist(const double *__restrict__ x, co
 // are staged in LDS with coalesced loads, lane 0 runs the three fma chains IN CHANNEL ORDER from there (the same sums as before,
 // bit for bit), the element-wise parts (A / ||A||, -P) are spread over the lanes.
 __global__ void __launch_bounds__(64) k_mlr_prep(const double *__restrict__ P, const double *__restrict__ A, int O, int C,
-                                                 double *__restrict__ consts)
+                                                 double *__restrict__ consts, double *__restrict__ Wt = nullptr, int wt_half = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
     double *sP = reinterpret_cast<double *>(smem_p), *sA = sP + C;     // P row | A row, then A^ row in place of A
@@ -347,6 +347,12 @@ __global__ void __launch_bounds__(64) k_mlr_prep(const double *__restrict__ P, c
         sA[j] = v;
         An[(size_t)o * C + j] = v;
         nP[(size_t)o * C + j] = -sP[j];
+        if (Wt) {                                                        // channel-major image for the fused backward: row j = [-P of classes 0..half-1 | A^ ...]
+            Wt[(size_t)j * 2 * wt_half + o] = -sP[j];
+            Wt[(size_t)j * 2 * wt_half + wt_half + o] = v;
+            if (o == 0)
+                for (int q = O; q < wt_half; ++q) { Wt[(size_t)j * 2 * wt_half + q] = 0.0; Wt[(size_t)j * 2 * wt_half + wt_half + q] = 0.0; }
+        }
     }
     __syncthreads();
     if (lane == 0) {
@@ -1001,10 +1007,8 @@ __global__ void __launch_bounds__(HTPB) k_expmap0_project_bwd(const TIN *__restr
 // recomputed from px = <x,-P>, xa = <x,A^>, xx = ||x||^2 and the class constants, then differentiated statement by statement
 // (clamps and the projection's where() pass no gradient on their inactive side, as autograd has it).
 struct MlrGrad { double d_px, d_xa, d_pp, d_pa, d_an, d_xx; };
-// FAST (the fused backward): the two reciprocals the sweep needs (1/D, 1/(1 - K mob)) and 1/sqrt(1 + s^2) through the corrected
-// hardware estimates (rcp_q / rsqrt_q, <= 1 ulp), every other quotient as a product with them, asinh as log(|s| + sqrt(1 + s^2));
-// the projection arm (pixels beyond the ball: rare) keeps its IEEE quotients.  !FAST: IEEE division / sqrt / asinh throughout.
-template <bool FAST>
+// IEEE division / sqrt / asinh throughout, every clamp and both sides of the projection's where(): the term-map kernel's statement and
+// the fused backward's rare arm.
 __device__ __forceinline__ MlrGrad mlr_reverse(double px, double xa, double gF, double ppo, double pao, double ano, double xx, double K,
                                                double sqK, double maxnorm)
 {
@@ -1014,10 +1018,9 @@ __device__ __forceinline__ MlrGrad mlr_reverse(double px, double xa, double gF, 
     const double D0 = t + ((K * xx) * K) * ppo;
     const bool Dlive = D0 >= 1e-12;
     const double D = Dlive ? D0 : 1e-12;
-    const double rD = FAST ? rcp_q(D) : 1.0 / D;
-    const double al = FAST ? Aa * rD : Aa / D, be = FAST ? Bb * rD : Bb / D;
+    const double al = Aa / D, be = Bb / D;
     const double mob = ((al * al) * ppo + (be * be) * xx) + ((2.0 * al) * be) * px;
-    const double sq = (FAST && mob > 1e-300 && mob < 1e300) ? sqrt_q(mob) : __builtin_sqrt(mob);
+    const double sq = __builtin_sqrt(mob);
     const bool over = sq > maxnorm, under = sq < maxnorm;
     const double pn = over ? maxnorm / (sq < 1e-12 ? 1e-12 : sq) : 1.0;
     const double mp = under ? mob : maxnorm * maxnorm;
@@ -1026,39 +1029,26 @@ __device__ __forceinline__ MlrGrad mlr_reverse(double px, double xa, double gF, 
     const double den = 1.0 - K * mp;
     const bool denlive = den >= 1e-12;
     const double denc = denlive ? den : 1e-12;
-    const double rden = FAST ? rcp_q(denc) : 1.0 / denc;
-    const double lam = FAST ? 2.0 * rden : 2.0 / denc;
+    const double lam = 2.0 / denc;
     const double s = (sqK * md) * lam;
     // ---- reverse
     const double two_sqK = 2.0 / sqK;
-    double asinh_s, rsq1;                                                // asinh(s), 1 / sqrt(1 + s^2)
-    const double a_ = __builtin_fabs(s);
-    if (FAST && a_ < 1e150) {
-        const double u = __builtin_fma(a_, a_, 1.0);
-        rsq1 = rsqrt_q(u);
-        asinh_s = __builtin_copysign(log_ge1_q(__builtin_fma(u, rsq1, a_)), s);
-    } else {
-        asinh_s = asinh(s);
-        rsq1 = 1.0 / __builtin_sqrt(1.0 + s * s);
-    }
-    const double d_an = gF * two_sqK * asinh_s;
-    const double d_s = FAST ? gF * two_sqK * ano * rsq1 : gF * two_sqK * ano / __builtin_sqrt(1.0 + s * s);
+    const double d_an = gF * two_sqK * asinh(s);
+    const double d_s = gF * two_sqK * ano / __builtin_sqrt(1.0 + s * s);
     const double d_md = d_s * sqK * lam;
     const double d_lam = d_s * sqK * md;
-    const double d_den = denlive ? (FAST ? -d_lam * 2.0 * (rden * rden) : -d_lam * 2.0 / (denc * denc)) : 0.0;
+    const double d_den = denlive ? -d_lam * 2.0 / (denc * denc) : 0.0;
     double d_mob = under ? -K * d_den : 0.0;
     const double d_inner = d_md * pn, d_pn = d_md * inner;
     double d_be = d_inner * xa, d_al = d_inner * pao;
     const double d_xa = d_inner * be, d_pa = d_inner * al;
-    if (over) {                                                          // d pn / d sq (zero on the other side of the where())
-        const double d_sq = -d_pn * maxnorm / (sq * sq);
-        if (sq > 0.0) d_mob += d_sq / (2.0 * sq);
-    }
+    const double d_sq = over ? -d_pn * maxnorm / (sq * sq) : 0.0;
+    if (sq > 0.0) d_mob += d_sq / (2.0 * sq);
     d_al += d_mob * (2.0 * al * ppo + 2.0 * be * px);
     d_be += d_mob * (2.0 * be * xx + 2.0 * al * px);
     double d_pp = d_mob * al * al, d_xx = d_mob * be * be, d_px = d_mob * 2.0 * al * be;
-    const double d_Aa = FAST ? d_al * rD : d_al / D, d_Bb = FAST ? d_be * rD : d_be / D;
-    const double d_D0 = Dlive ? (FAST ? -(d_al * Aa + d_be * Bb) * (rD * rD) : -(d_al * Aa + d_be * Bb) / (D * D)) : 0.0;
+    const double d_Aa = d_al / D, d_Bb = d_be / D;
+    const double d_D0 = Dlive ? -(d_al * Aa + d_be * Bb) / (D * D) : 0.0;
     double d_t = d_D0;
     d_xx += d_D0 * K * K * ppo;
     d_pp += d_D0 * K * K * xx;
@@ -1067,6 +1057,51 @@ __device__ __forceinline__ MlrGrad mlr_reverse(double px, double xa, double gF, 
     d_xx += K * d_Aa;
     d_px += 2.0 * K * d_t;
     return MlrGrad{d_px, d_xa, d_pp, d_pa, d_an, d_xx};
+}
+// The same sweep for a pixel INSIDE the ball with no clamp active -- D >= 1e-12, 0 < ||mobadd|| < maxnorm (hence 1 - K mob > 2e-3),
+// |sineterm| < 1e150: every trained head, every pixel -- as ONE straight line: two corrected reciprocals (1/D, 1/(1 - K mob)) and one
+// reciprocal root (1/sqrt(1 + s^2)) through rcp_q / rsqrt_q (<= 1 ulp), every other quotient a product with them, asinh as
+// log(|s| + sqrt(1 + s^2)).  `ok` says whether the conditions held (NaN operands fail them); the caller recomputes the others with
+// mlr_reverse.  No branch inside: two classes' chains written back to back interleave in one basic block.
+struct MlrFast { MlrGrad g; bool ok; };
+__device__ __forceinline__ MlrFast mlr_reverse_inside(double px, double xa, double gF, double ppo, double pao, double ano, double xx, double K,
+                                                      double sqK, double maxnorm)
+{
+    const double t = __builtin_fma(2.0 * K, px, 1.0);
+    const double Kxx = K * xx;
+    const double Aa = t + Kxx, Bb = __builtin_fma(-K, ppo, 1.0);
+    const double D = __builtin_fma(Kxx * K, ppo, t);
+    bool ok = D >= 1e-12;
+    const double rD = rcp_q(D);
+    const double al = Aa * rD, be = Bb * rD;
+    const double mob = __builtin_fma(al * al, ppo, __builtin_fma(be * be, xx, ((2.0 * al) * be) * px));
+    ok = ok && mob > 1e-300 && mob < 1e300;
+    ok = ok && sqrt_q(mob) < maxnorm;
+    const double inner = __builtin_fma(be, xa, al * pao);
+    const double rden = rcp_q(__builtin_fma(-K, mob, 1.0));
+    const double lam = 2.0 * rden;
+    const double s = (sqK * inner) * lam;
+    const double a_ = __builtin_fabs(s);
+    ok = ok && a_ < 1e150;
+    const double u = __builtin_fma(a_, a_, 1.0), rsq1 = rsqrt_q(u);
+    const double asinh_s = __builtin_copysign(log_ge1_q(__builtin_fma(u, rsq1, a_)), s);
+    // ---- reverse
+    const double gs = gF * (2.0 / sqK);
+    const double d_an = gs * asinh_s;
+    const double d_s = (gs * ano) * rsq1;
+    const double d_md = (d_s * sqK) * lam;                               // pn = 1: d inner = d md, no gradient through pn
+    const double d_lam = (d_s * sqK) * inner;
+    const double d_mob = (K * 2.0) * (d_lam * (rden * rden));            // -K * d_den, d_den = -d_lam 2 / den^2
+    const double d_xa = d_md * be, d_pa = d_md * al;
+    const double d_al = __builtin_fma(d_mob, 2.0 * __builtin_fma(al, ppo, be * px), d_md * pao);
+    const double d_be = __builtin_fma(d_mob, 2.0 * __builtin_fma(be, xx, al * px), d_md * xa);
+    const double d_Aa = d_al * rD, d_Bb = d_be * rD;
+    const double d_D0 = -__builtin_fma(d_al, Aa, d_be * Bb) * (rD * rD);
+    const double KK = K * K;
+    const double d_xx = __builtin_fma(K, d_Aa, __builtin_fma(d_D0 * KK, ppo, (d_mob * be) * be));
+    const double d_pp = __builtin_fma(-K, d_Bb, __builtin_fma(d_D0 * KK, xx, (d_mob * al) * al));
+    const double d_px = __builtin_fma(2.0 * K, d_D0 + d_Aa, ((d_mob * 2.0) * al) * be);
+    return MlrFast{MlrGrad{d_px, d_xa, d_pp, d_pa, d_an, d_xx}, ok};
 }
 
 // Reverse sweep through _hyper_logits' scalar algebra (hyperbolic.py:146-183) for every (pixel, class):
@@ -1107,7 +1142,7 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr_bwd_terms(const double *__res
             const int o = o0 + q;
             if (o < O) {
             const size_t oi = ((size_t)b * O + o) * hw + i;
-            const MlrGrad g_ = mlr_reverse<false>(px[q], xa[q], gout[oi], pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
+            const MlrGrad g_ = mlr_reverse(px[q], xa[q], gout[oi], pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
             dpx[oi] = g_.d_px; dxa[oi] = g_.d_xa; dpp[oi] = g_.d_pp; dpa[oi] = g_.d_pa; dan[oi] = g_.d_an;
             dxx_acc += g_.d_xx;
             }
@@ -1140,30 +1175,32 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-__global__ void __launch_bounds__(MLRB_TPB) k_mlr_bwd_pixels(const double *__restrict__ x, const double *__restrict__ consts,
-                                                             const double *__restrict__ gout, int O, int C, long long hw, double K,
-                                                             double *__restrict__ Dws, double *__restrict__ dxx_out,
-                                                             double *__restrict__ cls_part)
+template <bool SCALAR_W>
+__global__ void __launch_bounds__(MLRB_TPB, SCALAR_W ? 3 : 2) k_mlr_bwd_pixels(const double *__restrict__ x, const double *__restrict__ consts,
+                                                             const double *__restrict__ Wg, const double *__restrict__ gout, int O, int C,
+                                                             long long hw, double K, double *__restrict__ Dws,
+                                                             double *__restrict__ dxx_out, double *__restrict__ cls_part)
 {
+    // Wg [C][MLRB_WS]: -P of classes 0..OP-1 | A^ of classes 0..OP-1 (zero beyond O), written by k_mlr_prep.  Every lane of a wave
+    // wants the SAME weight at the same time, and there are two ways to hand it over:
+    //   SCALAR_W   the addresses are wave-uniform: the 40 doubles of a channel arrive through the scalar cache into SGPRs and feed
+    //              v_fma_f64 as scalar operands (s_load_dwordx16 x 5 per channel in the emitted code);
+    //   otherwise  broadcast from an LDS copy: 20 ds_read_b128 per channel and wave, 8 cycles each on the CU's ONE LDS pipe against
+    //              41 x 4.5 cycles of fma on each of its four SIMDs -- LDS-bound by a factor of 3.5 once the chip is full.
+    // Measured (pixels kernel alone): 819 200 pixels (the v2 head) 366 us from LDS, 296 us scalar; 102 400 pixels (the training shape:
+    // 1.5 waves per SIMD, nothing to hide an s_load's latency behind) 57 us from LDS, 64 us scalar -- the host picks by pixel count.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    double *Wt = reinterpret_cast<double *>(smem_b);                      // [C][MLRB_WS]: -P of classes 0..OP-1 | A^ of classes 0..OP-1 (zero beyond O)
     __shared__ double s_red[MLRB_TPB / 64][3 * MLRB_OP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
-    const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O, *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
-    for (int e0 = 0; e0 < C * MLRB_WS; e0 += 5 * MLRB_TPB) {              // rows of [-P | A^] read along the channels, five independent loads per
-        double v[5];                                                     // thread in flight (C * WS is a multiple of 5 * 256: 64 | C, WS = 40)
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int e = e0 + u * MLRB_TPB + tid, r = e / C, j = e - r * C, o = r % MLRB_OP;
-            v[u] = o < O ? (r < MLRB_OP ? nP : An)[(size_t)o * C + j] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int e = e0 + u * MLRB_TPB + tid, r = e / C, j = e - r * C;
-            Wt[j * MLRB_WS + r] = v[u];
-        }
+    const double *pp = consts, *anorm = consts + O, *pa = consts + 2 * O;
+    const double *Wt = Wg;
+    if constexpr (!SCALAR_W) {
+        double *Wl = reinterpret_cast<double *>(smem_b);
+        const d2_h *src = reinterpret_cast<const d2_h *>(Wg);
+        for (int e = tid; e < C * MLRB_WS / 2; e += MLRB_TPB) reinterpret_cast<d2_h *>(Wl)[e] = src[e];
+        __syncthreads();
+        Wt = Wl;
     }
-    __syncthreads();
     const long long i_raw = (long long)blockIdx.x * MLRB_TPB + tid;
     const bool live = i_raw < hw;
     const long long i = live ? i_raw : hw - 1;                           // idle lanes repeat the last pixel (loads stay valid, nothing stored, zero summed)
@@ -1186,7 +1223,7 @@ __global__ void __launch_bounds__(MLRB_TPB) k_mlr_bwd_pixels(const double *__res
             if (j0 + UN < C) load8(nxt, j0 + UN);
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const double *wr = Wt + (j0 + u) * MLRB_WS;
+                const double *wr = Wt + (size_t)(j0 + u) * MLRB_WS;            // wave-uniform address
                 ssq = __builtin_fma(cur[u], cur[u], ssq);
 #pragma unroll
                 for (int q = 0; q < MLRB_OP; ++q) {
@@ -1202,15 +1239,32 @@ __global__ void __launch_bounds__(MLRB_TPB) k_mlr_bwd_pixels(const double *__res
     const double sqK = __builtin_sqrt(K), maxnorm = (1.0 - 1e-3) / sqK;
     double dxx_acc = 0.0;
     double *d0 = Dws + (size_t)b * 2 * O * hw + i;
+    // Two classes per trip, both straight-line sweeps written back to back (one basic block: their dependent chains interleave),
+    // then ONE wave-uniform test for the rare arm.  Class O of an odd O is padding (zero weights, constants read in bounds, nothing
+    // stored or summed).
+    const double *gb = gout + (size_t)b * O * hw + i;
 #pragma unroll
-    for (int o = 0; o < MLRB_OP; ++o) {
+    for (int o = 0; o < MLRB_OP; o += 2) {
         if (o < O) {                                                     // wave-uniform
-            const MlrGrad g_ = mlr_reverse<true>(px[o], xa[o], gout[((size_t)b * O + o) * hw + i], pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
-            if (live) { d0[(size_t)o * hw] = g_.d_px; d0[(size_t)(O + o) * hw] = g_.d_xa; }
-            dxx_acc += g_.d_xx;
-            // the three per-class sums: fixed shuffle trees (their ds_bpermute latency hides behind the other waves of the SIMD now)
-            const double s0 = wave_sum(live ? g_.d_pp : 0.0), s1 = wave_sum(live ? g_.d_pa : 0.0), s2 = wave_sum(live ? g_.d_an : 0.0);
+            const bool has1 = o + 1 < O;                                 // wave-uniform
+            const double gF0 = gb[(size_t)o * hw], gF1 = has1 ? gb[(size_t)(o + 1) * hw] : 0.0;
+            MlrFast f0 = mlr_reverse_inside(px[o], xa[o], gF0, pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
+            MlrFast f1 = mlr_reverse_inside(px[o + 1], xa[o + 1], gF1, pp[o + 1], pa[o + 1], anorm[o + 1], xx, K, sqK, maxnorm);
+            if (__any(!f0.ok || (has1 && !f1.ok))) {                     // clamped D, on / beyond the ball, NaN / inf: never in a trained head
+                if (!f0.ok) f0.g = mlr_reverse(px[o], xa[o], gF0, pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
+                if (has1 && !f1.ok) f1.g = mlr_reverse(px[o + 1], xa[o + 1], gF1, pp[o + 1], pa[o + 1], anorm[o + 1], xx, K, sqK, maxnorm);
+            }
+            if (live) { d0[(size_t)o * hw] = f0.g.d_px; d0[(size_t)(O + o) * hw] = f0.g.d_xa; }
+            dxx_acc += f0.g.d_xx;
+            // the three per-class sums: fixed shuffle trees (their ds_bpermute latency hides behind the other chains and waves)
+            const double s0 = wave_sum(live ? f0.g.d_pp : 0.0), s1 = wave_sum(live ? f0.g.d_pa : 0.0), s2 = wave_sum(live ? f0.g.d_an : 0.0);
             if (lane == 0) { s_red[wave][o] = s0; s_red[wave][MLRB_OP + o] = s1; s_red[wave][2 * MLRB_OP + o] = s2; }
+            if (has1) {
+                if (live) { d0[(size_t)(o + 1) * hw] = f1.g.d_px; d0[(size_t)(O + o + 1) * hw] = f1.g.d_xa; }
+                dxx_acc += f1.g.d_xx;
+                const double t0 = wave_sum(live ? f1.g.d_pp : 0.0), t1 = wave_sum(live ? f1.g.d_pa : 0.0), t2 = wave_sum(live ? f1.g.d_an : 0.0);
+                if (lane == 0) { s_red[wave][o + 1] = t0; s_red[wave][MLRB_OP + o + 1] = t1; s_red[wave][2 * MLRB_OP + o + 1] = t2; }
+            }
         }
     }
     if (live) dxx_out[(size_t)b * hw + i] = dxx_acc;
@@ -1894,14 +1948,14 @@ extern "C" int halo_expmap0_project_bwd(const void *x, int x_dtype, const double
     return check_launch("halo_expmap0_project_bwd");
 }
 
-// ---- fused HyperMLR backward (k_mlr_bwd_pixels / _dx / _weights / _final).  Workspace: consts | D (B,2O,hw) | dxx (B,hw) | class partials | weight partials.
+// ---- fused HyperMLR backward (k_mlr_bwd_pixels / _dx / _weights / _final).  Workspace: consts | D (B,2O,hw) | dxx (B,hw) | Wt (C,40) | class partials | weight partials.
 static inline bool mlr_bwd_fused_ok(int64_t C, int64_t O) { return O >= 1 && O <= MLRB_OP && C % 64 == 0 && C >= 64 && C <= 256; }
 static inline int64_t mlr_bwd_pix_blocks(int64_t B, int64_t hw) { return cdiv(hw, MLRB_TPB) * B; }
 extern "C" size_t halo_hypermlr_backward_workspace_bytes(int64_t B, int64_t C, int64_t O, int64_t hw)
 {
     if (B <= 0 || C <= 0 || O <= 0 || hw <= 0 || !mlr_bwd_fused_ok(C, O)) return 0;       // 0: shape not served (use halo_hypermlr_bwd_terms)
-    return halo_hypermlr_workspace_bytes(O, C) + 256 + ((size_t)B * (2 * O + 1) * hw + (size_t)mlr_bwd_pix_blocks(B, hw) * 3 * O +
-                                                       (size_t)MLRB_NWG * 2 * O * C) * sizeof(double) + 4 * 256;
+    return halo_hypermlr_workspace_bytes(O, C) + 256 + ((size_t)B * (2 * O + 1) * hw + (size_t)C * MLRB_WS + (size_t)mlr_bwd_pix_blocks(B, hw) * 3 * O +
+                                                       (size_t)MLRB_NWG * 2 * O * C) * sizeof(double) + 5 * 256;
 }
 
 extern "C" int halo_hypermlr_backward(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
@@ -1921,18 +1975,28 @@ extern "C" int halo_hypermlr_backward(const double *x, const double *P, const do
     double *consts = ar.take<double>((size_t)(3 * O + 2 * O * C));
     double *Dws = ar.take<double>((size_t)B * 2 * O * hw);
     double *dxx = ar.take<double>((size_t)B * hw);
+    double *Wt = ar.take<double>((size_t)C * MLRB_WS);
     const int64_t npb = mlr_bwd_pix_blocks(B, hw);
     double *cls_part = ar.take<double>((size_t)npb * 3 * O);
     double *w_part = ar.take<double>((size_t)MLRB_NWG * 2 * O * C);
-    if (!ar.ok() || !consts || !Dws || !dxx || !cls_part || !w_part) return fail(HALO_E_WORKSPACE, "halo_hypermlr_backward: workspace too small");
-    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)O), dim3(64), (size_t)2 * C * sizeof(double), st, P, A, (int)O, (int)C, consts);
+    if (!ar.ok() || !consts || !Dws || !dxx || !Wt || !cls_part || !w_part) return fail(HALO_E_WORKSPACE, "halo_hypermlr_backward: workspace too small");
+    hipLaunchKernelGGL(k_mlr_prep, dim3((unsigned)O), dim3(64), (size_t)2 * C * sizeof(double), st, P, A, (int)O, (int)C, consts, Wt, MLRB_OP);
     {
-        const size_t lds = (size_t)C * MLRB_WS * sizeof(double);         // 80 KiB at C = 256
-        static LdsLimitSeen seen;
-        if (lds > 64 * 1024 && !raise_lds_limit(seen, (const void *)k_mlr_bwd_pixels, 96 * 1024))
-            return fail(HALO_E_LAUNCH, "halo_hypermlr_backward: cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL(k_mlr_bwd_pixels, dim3((unsigned)cdiv(hw, MLRB_TPB), (unsigned)B), dim3(MLRB_TPB), lds, st, x, (const double *)consts, gout,
-                           (int)O, (int)C, (long long)hw, c, Dws, dxx, cls_part);
+        const dim3 gp((unsigned)cdiv(hw, MLRB_TPB), (unsigned)B);
+        // >= 2 resident waves on every SIMD: weights through the scalar cache (HALO_MLR_BWD_W=lds|scalar forces an arm: tests, A/B)
+        const char *wenv = getenv("HALO_MLR_BWD_W");
+        const bool scalar_w = wenv ? wenv[0] == 's' : (long long)B * hw >= 400000;
+        if (scalar_w) {
+            hipLaunchKernelGGL((k_mlr_bwd_pixels<true>), gp, dim3(MLRB_TPB), 0, st, x, (const double *)consts, (const double *)Wt, gout, (int)O, (int)C,
+                               (long long)hw, c, Dws, dxx, cls_part);
+        } else {
+            const size_t lds = (size_t)C * MLRB_WS * sizeof(double);     // 80 KiB at C = 256
+            static LdsLimitSeen seen;
+            if (lds > 48 * 1024 && !raise_lds_limit(seen, (const void *)k_mlr_bwd_pixels<false>, 96 * 1024))
+                return fail(HALO_E_LAUNCH, "halo_hypermlr_backward: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL((k_mlr_bwd_pixels<false>), gp, dim3(MLRB_TPB), lds, st, x, (const double *)consts, (const double *)Wt, gout, (int)O, (int)C,
+                               (long long)hw, c, Dws, dxx, cls_part);
+        }
         const long long ntiles = cdiv(hw, 16) * B;
         const unsigned gdx = (unsigned)(cdiv(ntiles, 4) < 512 ? cdiv(ntiles, 4) : 512);
         hipLaunchKernelGGL(k_mlr_bwd_dx, dim3(gdx, (unsigned)(C / 64)), dim3(256), 0, st, x, (const double *)consts, (const double *)Dws, (const double *)dxx,

@@ -1421,14 +1421,17 @@ def test_hypermlr_fused_backward_matches_term_path(dev):
         P0, A0 = t(rng.uniform(-bound, bound, (O, C)), dev), t(rng.uniform(-bound, bound, (O, C)), dev)
         Wt = t(rng.standard_normal((B, O, h, w)), dev)
         res = []
-        for env in ({}, {}, {"HALO_MLR_BWD_TERMS": "1"}):
+        # twice the default arm (small pixel counts: weights broadcast from LDS), then the scalar-cache arm, then the term-map path
+        for env in ({}, {}, {"HALO_MLR_BWD_W": "scalar"}, {"HALO_MLR_BWD_TERMS": "1"}):
             with _env_set(env):
                 x, P, A = x0.clone().requires_grad_(True), P0.clone().requires_grad_(True), A0.clone().requires_grad_(True)
                 (_HyperMLRFn.apply(x, P, A, c) * Wt).sum().backward()
                 res.append([g.grad.cpu().numpy() for g in (x, P, A)])
         for a_, b_ in zip(res[0], res[1]):
             assert np.array_equal(a_, b_), "the fused backward is not deterministic"
-        for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[2]):
+        for a_, b_ in zip(res[0], res[2]):
+            assert np.array_equal(a_, b_), "the two weight paths of the pixel kernel run the same fma chains: same bits"
+        for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[3]):
             assert np.isfinite(a_).all(), (name, B, C, O)
             assert np.abs(a_ - b_).max() <= 1e-11 * np.abs(b_).max() + 1e-300, (name, B, C, O, h, w, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
         # the same input at an address that is 8 but not 16 bytes aligned (a contiguous view one element into a buffer): the
