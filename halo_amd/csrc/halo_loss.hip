@@ -147,7 +147,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x mod 8), and a 3x3 window kernel re-reads the rows above and below its
 // own: with the plain blockIdx -> pixel-chunk map vertically adjacent chunks sit on different XCDs and each XCD's L2 fetches the same
 // rows again.  Here XCD k walks one contiguous eighth of the chunks (whole groups of 8 only; the remainder keeps the plain map):
-// k_lcl_bwd 178 -> 158 us at 2 x 19 x 640 x 1280.
+// k_lcl_bwd 178 -> 158 us at 2 x 19 x 640 x 1280.  (A strip-walking backward like k_lcl_fwd_strip -- separable weights, one
+// carried sum per class and row -- measured 340 us: 202 registers, two waves per SIMD, eight rows in series per thread; not kept.)
 __device__ __forceinline__ long long xcd_contiguous_chunk(unsigned bid, unsigned nblk)
 {
     const unsigned per = nblk >> 3;
@@ -203,6 +204,82 @@ __global__ void __launch_bounds__(LTPB) k_lcl_fwd(const float *__restrict__ p, c
         }
     }
     block_sum2(ls, cnt, partials + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+}
+
+// The same forward with a workgroup walking LCL_ROWS rows of a 256-column strip, classes in groups of CG: a thread keeps the taps of
+// the two rows above its next one in registers (6 per class), so every row of p is loaded ONCE per strip (+ 2 halo rows per
+// LCL_ROWS) instead of by the three workgroups that own it and its neighbours -- which the plain pixel-chunk map puts on three
+// different XCDs, i.e. three L2 misses per element.  Same statements per (pixel, class) as k_lcl_fwd; the per-pixel float32 sum over
+// the classes is formed per group and the groups are added in float64 (bits differ from k_lcl_fwd's in the last place of a sum).
+constexpr int LCL_ROWS = 8, LCL_CG = 10;
+__global__ void __launch_bounds__(LTPB) k_lcl_fwd_strip(const float *__restrict__ p, const long long *__restrict__ label, int O, int h, int w,
+                                                        int kl, double *__restrict__ partials, float *__restrict__ ca, float *__restrict__ cb,
+                                                        unsigned char *__restrict__ mask)
+{
+    const int b = blockIdx.z, x = blockIdx.x * LTPB + threadIdx.x, y0 = blockIdx.y * LCL_ROWS;
+    const int y1 = y0 + LCL_ROWS < h ? y0 + LCL_ROWS : h;
+    const long long hw = (long long)h * w;
+    const bool col = x < w;
+    const int xc = col ? x : w - 1, xm = clampi(xc - 1, 0, w - 1), xp = clampi(xc + 1, 0, w - 1);
+    const long long *lab = label + (size_t)b * hw;
+    unsigned mbits = 0;                                                  // the strip's mask bits of this column, row y0 + k in bit k
+    for (int y = y0; y < y1; ++y) {
+        const bool m = col && lcl_mask(lab, h, w, y, xc);
+        mbits |= (m ? 1u : 0u) << (y - y0);
+        if (mask && col) mask[(size_t)b * hw + (size_t)y * w + x] = m ? 1 : 0;
+    }
+    double ls = 0.0, cnt = (double)__builtin_popcount(mbits);
+    for (int c0 = 0; c0 < O; c0 += LCL_CG) {
+        float r0[LCL_CG][3], r1[LCL_CG][3], r2[LCL_CG][3];
+        const float *pb = p + ((size_t)b * O + c0) * hw;
+        auto load_row = [&](float (&r)[LCL_CG][3], int yy) {
+            const size_t ro = (size_t)clampi(yy, 0, h - 1) * w;
+#pragma unroll
+            for (int q = 0; q < LCL_CG; ++q)
+                if (c0 + q < O) { const float *pc = pb + (size_t)q * hw + ro; r[q][0] = pc[xm]; r[q][1] = pc[xc]; r[q][2] = pc[xp]; }
+        };
+        load_row(r0, y0 - 1);
+        load_row(r1, y0);
+        for (int y = y0; y < y1; ++y) {
+            load_row(r2, y + 1);
+            if ((mbits >> (y - y0)) & 1u) {
+                const size_t i = (size_t)y * w + x;
+                float l = 0.0f;
+#pragma unroll
+                for (int q = 0; q < LCL_CG; ++q) {
+                    if (c0 + q < O) {
+                        float mean = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) mean = __builtin_fmaf(r0[q][k], 1.0f / 9.0f, mean);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) mean = __builtin_fmaf(r1[q][k], 1.0f / 9.0f, mean);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) mean = __builtin_fmaf(r2[q][k], 1.0f / 9.0f, mean);
+                        const float pv = r1[q][1];
+                        float a, bb;
+                        if (!kl) {
+                            const float d = pv - mean;
+                            l = l + (d < 0.0f ? -d : d);
+                            a = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+                            bb = -a;
+                        } else {
+                            const float me = mean + 1e-6f, r = pv / me, re = r + 1e-6f, lg = det_logf(re);
+                            l = l + pv * lg;
+                            a = lg + (pv / me) / re;                     // d/dp [p log(p/me + eps)]
+                            bb = -(pv * pv) / (me * me * re);            // d/dmean
+                        }
+                        if (ca) { ca[((size_t)b * O + c0 + q) * hw + i] = a; cb[((size_t)b * O + c0 + q) * hw + i] = bb; }
+                    }
+                }
+                ls += (double)l;
+            }
+#pragma unroll
+            for (int q = 0; q < LCL_CG; ++q)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { r0[q][k] = r1[q][k]; r1[q][k] = r2[q][k]; }
+        }
+    }
+    block_sum2(ls, cnt, partials + 2 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x));
 }
 
 // gx = softmax-backward( gp ),  gp_c(j) = a_c(j) + sum_{i in 3x3(j)} mult(i -> j)/9 * b_c(i),  scaled by g / count.
@@ -327,7 +404,7 @@ using namespace halo;
 extern "C" size_t halo_loss_workspace_bytes(int64_t n_pixels)
 {
     if (n_pixels <= 0) return 0;
-    return (size_t)(cdiv(n_pixels, LTPB) + 1) * 2 * sizeof(double) + 512;
+    return (size_t)(cdiv(n_pixels, 8) + 8) * 2 * sizeof(double) + 512;       // covers the strip kernel's workgroups (256 columns x 8 rows, ragged edges)
 }
 
 // NegativeLearningLoss.forward: sums[0] = sum of loss items, sums[1] = number of selected entries (float64, device)
@@ -365,7 +442,10 @@ extern "C" int halo_local_consistent_fwd(const float *x, const int64_t *label, i
     if ((coef_a == nullptr) != (coef_b == nullptr) || (coef_a == nullptr) != (mask == nullptr))
         return fail(HALO_E_ARG, "halo_local_consistent_fwd: coef_a, coef_b and mask go together");
     const long long hw = (long long)h * w;
-    const int nb = (int)cdiv(hw, LTPB), nblk = nb * (int)B;
+    const int nb = (int)cdiv(hw, LTPB);
+    const bool strip = getenv("HALO_LCL_PLAIN") == nullptr && B <= 65535 && cdiv(h, LCL_ROWS) <= 65535;      // A/B switch: the one-pixel-per-thread forward
+    const dim3 gs((unsigned)cdiv(w, LTPB), (unsigned)cdiv(h, LCL_ROWS), (unsigned)B);
+    const int nblk = strip ? (int)(gs.x * gs.y * gs.z) : nb * (int)B;
     if (!workspace || workspace_bytes < (size_t)nblk * 16 + 256) return fail(HALO_E_WORKSPACE, "halo_local_consistent_fwd: workspace too small");
     double *part = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipStream_t st = (hipStream_t)stream;
@@ -374,8 +454,12 @@ extern "C" int halo_local_consistent_fwd(const float *x, const int64_t *label, i
         hipLaunchKernelGGL((k_softmax_nchw_v4<20>), dim3((unsigned)cdiv(hw / 4, LTPB), (unsigned)B), dim3(LTPB), 0, st, x, (int)O, hw, p);
     else
         hipLaunchKernelGGL(k_softmax_nchw, grid, dim3(LTPB), 0, st, x, (int)O, hw, p);
-    hipLaunchKernelGGL(k_lcl_fwd, grid, dim3(LTPB), 0, st, (const float *)p, (const long long *)label, (int)O, (int)h, (int)w, kl, part, coef_a, coef_b,
-                       (unsigned char *)mask);
+    if (strip)
+        hipLaunchKernelGGL(k_lcl_fwd_strip, gs, dim3(LTPB), 0, st, (const float *)p, (const long long *)label, (int)O, (int)h, (int)w, kl, part, coef_a, coef_b,
+                           (unsigned char *)mask);
+    else
+        hipLaunchKernelGGL(k_lcl_fwd, grid, dim3(LTPB), 0, st, (const float *)p, (const long long *)label, (int)O, (int)h, (int)w, kl, part, coef_a, coef_b,
+                           (unsigned char *)mask);
     hipLaunchKernelGGL(k_sum2_finalize, dim3(1), dim3(LTPB), 0, st, (const double *)part, nblk, sums);
     return check_launch("halo_local_consistent_fwd");
 }
