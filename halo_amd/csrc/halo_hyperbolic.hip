@@ -767,7 +767,10 @@ __global__ void __launch_bounds__(MLRP_TPB) k_hypermlr_mfma_res(const double *__
                     const int k = st * (4 * MLRP_SK) + kk * 4 + lk;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const double bf = wok[n] ? wts[wrow[n] + k] : 0.0;
+                        // unconditional read (wrow points at a valid row for padding columns too), then a select: a read under a lane
+                        // condition is a branch region with its own lgkmcnt(0) in front of the MFMA that uses it -- and cost 37 registers
+                        const double bfv = wts[wrow[n] + k];
+                        const double bf = wok[n] ? bfv : 0.0;
 #pragma unroll
                         for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][kk][m], bf, acc[m][n], 0, 0, 0);
                     }
