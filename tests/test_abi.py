@@ -60,6 +60,12 @@ def test_workspace_queries_are_pure_host_functions():
     assert L.halo_score_workspace_bytes(1, 1024, 2048) >= 1024 * 2048 * 18
     assert L.halo_score_workspace_bytes(0, 4, 4) == 0
     assert L.halo_hypermlr_workspace_bytes(19, 256) >= (3 * 19 + 2 * 19 * 256) * 8
+    # the fused HyperMLR backward: a size for the shapes it serves (<= 20 classes, 64 | C <= 256), 0 = "use halo_hypermlr_bwd_terms" otherwise
+    n = L.halo_hypermlr_backward_workspace_bytes(2, 64, 19, 160 * 320)
+    assert n >= (2 * (2 * 19 + 1) * 160 * 320 + 64 * 40 + 256 * 2 * 19 * 64) * 8
+    for bad in ((2, 8, 19, 100), (2, 96, 19, 100), (2, 320, 19, 100), (2, 64, 21, 100), (0, 64, 19, 100), (2, 64, 19, 0)):
+        assert L.halo_hypermlr_backward_workspace_bytes(*bad) == 0, bad
+    assert L.halo_loss_workspace_bytes(129) >= (3 + 1) * 16            # a 1 x 129 image: three strips of the row-walking forward
     # the binned selector stages up to 2 x 121 x n candidates per image (28 bytes each); the serial kernel needs none
     assert L.halo_select_workspace_bytes(4, 1024, 2048, 2331, 5) > 4 * 2 * 121 * 2331 * 28
     assert L.halo_select_workspace_bytes(4, 1024, 2048, 2331, 40) == 256          # mask radius above 14: serial kernel only
