@@ -1481,7 +1481,7 @@ __global__ void __launch_bounds__(MLRF_TPB) k_mlr_bwd_final(const double *__rest
         const int c = c0 + lane;
         double gp = 0.0, ga = 0.0;
         if (c < C)
-#pragma unroll 4
+#pragma unroll 16                                                            // 256 partials / 16 waves: every load of the wave in flight at once
             for (int g = wave; g < n_wpart; g += MLRF_NW) {
                 gp += w_part[((size_t)g * 2 * O + o) * C + c];
                 ga += w_part[((size_t)g * 2 * O + O + o) * C + c];
