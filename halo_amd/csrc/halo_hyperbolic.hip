@@ -1314,7 +1314,10 @@ __global__ void __launch_bounds__(256) k_mlr_bwd_dx(const double *__restrict__ x
 #pragma unroll
         for (int ks = 0; ks < MLRX_KS; ++ks) {
             const int kk = 4 * ks + k;
-            d[ks] = kk < 2 * O ? Dws[((size_t)b * 2 * O + kk) * hw + pc] : 0.0;
+            // unconditional (the two padding rows of the last step read row 0) + select: under a lane condition this load is a
+            // branch region whose merge waits for EVERY load in flight -- the prefetch it belongs to included
+            const double v = Dws[((size_t)b * 2 * O + (kk < 2 * O ? kk : 0)) * hw + pc];
+            d[ks] = kk < 2 * O ? v : 0.0;
         }
     };
     double bd[MLRX_KS], bn[MLRX_KS];
@@ -1377,11 +1380,10 @@ __global__ void __launch_bounds__(256) k_mlr_bwd_weights(const double *__restric
         for (int rt = 0; rt < 3; ++rt) {
             const int j = rt * 16 + r;
             const double *src = Dws + ((size_t)b * 2 * O + (j < 2 * O ? j : 0)) * hw + p;
-            if (vec && p < hw && j < 2 * O) {
-                const d2_h v0 = *reinterpret_cast<const d2_h *>(src), v1 = *reinterpret_cast<const d2_h *>(src + 2);
+            if (vec && p < hw && j < 2 * O) {                            // (here the lane condition pays: unconditional loads of the 10 padding
+                const d2_h v0 = *reinterpret_cast<const d2_h *>(src), v1 = *reinterpret_cast<const d2_h *>(src + 2);      // rows + select measured 233 us against 185)
                 av[rt][0] = v0.x; av[rt][1] = v0.y; av[rt][2] = v1.x; av[rt][3] = v1.y;
-            } else {
-#pragma unroll
+            } else {#pragma unroll
                 for (int e = 0; e < 4; ++e) av[rt][e] = (j < 2 * O && p + e < hw) ? src[e] : 0.0;
             }
         }
