@@ -1383,7 +1383,8 @@ __global__ void __launch_bounds__(256) k_mlr_bwd_weights(const double *__restric
             if (vec && p < hw && j < 2 * O) {                            // (here the lane condition pays: unconditional loads of the 10 padding
                 const d2_h v0 = *reinterpret_cast<const d2_h *>(src), v1 = *reinterpret_cast<const d2_h *>(src + 2);      // rows + select measured 233 us against 185)
                 av[rt][0] = v0.x; av[rt][1] = v0.y; av[rt][2] = v1.x; av[rt][3] = v1.y;
-            } else {#pragma unroll
+            } else {
+#pragma unroll
                 for (int e = 0; e < 4; ++e) av[rt][e] = (j < 2 * O && p + e < hw) ? src[e] : 0.0;
             }
         }
