@@ -1164,8 +1164,9 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr_bwd_terms(const double *__res
 //                      from an LDS image of [-P | A^] laid out channel-major), the reverse sweep for every class; dpx / dxa (the
 //                      matrix D, 2O x pixels) and dxx go to the workspace, the three per-class sums (dpp, dpa, d||A||) leave as one
 //                      partial per workgroup (fixed shuffle tree, fixed order afterwards: deterministic);
-//   k_mlr_bwd_dx       gx = W^T D + 2 x dxx on the f64 matrix cores;
-//   k_mlr_bwd_weights  d W = D x^T on the f64 matrix cores, one (2O x C) partial per persistent workgroup;
+//   k_mlr_bwd_dxw      gx = W^T D + 2 x dxx  and  d W = D x^T  in ONE pass over D and x on the f64 matrix cores, the tile transposed
+//                      through LDS between the two products; one (2O x C) partial of d W per persistent workgroup
+//                      (k_mlr_bwd_dx + k_mlr_bwd_weights: the same as two kernels, kept as the cross-check, HALO_MLR_BWD_DXW=0);
 //   k_mlr_bwd_final    sums the partials in a fixed order and applies the (O,C)-sized algebra (||P||^2, <-P,A^>, F.normalize).
 // Serves O <= MLRB_OP classes and C a multiple of 64 up to 256 (the heads: 19 classes, 64 channels); anything else keeps the
 // term-map path above.
@@ -1453,6 +1454,143 @@ __global__ void __launch_bounds__(256) k_mlr_bwd_weights(const double *__restric
                 for (int q = 0; q < 4; ++q) {
                     const int j = rt * 16 + k + 4 * q;
                     if (j < 2 * O) w_part[((size_t)blockIdx.x * 2 * O + j) * C + cb * (16 * NCT) + ct * 16 + r] = acc[rt][ct][q];
+                }
+    }
+}
+
+// d x AND d W in one pass over D and x (the two kernels above read x twice and D three times between them, and are HBM-bound at large
+// pixel counts).  A wave takes a 16-pixel tile in the d x kernel's layout -- lane (pixel = lane & 15, k = lane >> 4) holds D[4 ks + k][pixel]
+// and x[16 ct + k + 4 q][pixel] -- runs the d x MFMAs (weights from an LDS image), then parks D and x of the tile in its own LDS
+// slab and reads them back TRANSPOSED for the d W MFMAs, whose k slot is the pixel: lane (row = lane & 15, slot = lane >> 4) takes
+// D[16 rt + row][4 e + slot] and x[16 ct + row][4 e + slot].  48 x 64 d W accumulators stay in registers over the wave's tiles.
+constexpr int MLRZ_RS = 17, MLRZ_WS = 66;                                // row strides (doubles) of the per-wave slabs / of the weight image
+__global__ void __launch_bounds__(256, 2) k_mlr_bwd_dxw(const double *__restrict__ x, const double *__restrict__ consts, const double *__restrict__ Dws,
+                                                        const double *__restrict__ dxx, int O, int C, long long hw, int Bn, double *__restrict__ gx,
+                                                        double *__restrict__ w_part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_z[];
+    double *Wl = reinterpret_cast<double *>(smem_z);                      // [40][MLRZ_WS]: row kk = -P of class kk (< O) | A^ of class kk - O | zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, k = lane >> 4, cb = blockIdx.y;
+    double *Dt = Wl + 4 * MLRX_KS * MLRZ_WS + (size_t)wave * (4 * MLRX_KS + 64) * MLRZ_RS, *Xt = Dt + 4 * MLRX_KS * MLRZ_RS;
+    const double *An = consts + 3 * O, *nP = consts + 3 * O + (size_t)O * C;
+    for (int e = tid; e < 4 * MLRX_KS * 64; e += 256) {
+        const int kk = e >> 6, c = e & 63;
+        Wl[kk * MLRZ_WS + c] = kk < O ? nP[(size_t)kk * C + cb * 64 + c] : (kk < 2 * O ? An[(size_t)(kk - O) * C + cb * 64 + c] : 0.0);
+    }
+    __syncthreads();
+    const long long tpi = (hw + 15) / 16, ntiles = tpi * Bn, tstride = (long long)gridDim.x * 4;
+    auto load_d = [&](long long t_, double (&d)[MLRX_KS]) {
+        const long long tl = t_ < ntiles ? t_ : ntiles - 1;
+        const int b = (int)(tl / tpi);
+        const long long p = (tl % tpi) * 16 + col, pc = p < hw ? p : hw - 1;
+#pragma unroll
+        for (int ks = 0; ks < MLRX_KS; ++ks) {
+            const int kk = 4 * ks + k;
+            const double v = Dws[((size_t)b * 2 * O + (kk < 2 * O ? kk : 0)) * hw + pc];     // unconditional + select (see k_mlr_bwd_dx)
+            d[ks] = kk < 2 * O ? v : 0.0;
+        }
+    };
+    v4d_t accw[3][4];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) accw[rt][ct] = (v4d_t){0, 0, 0, 0};
+    double bd[MLRX_KS], bn[MLRX_KS];
+    long long t_ = (long long)blockIdx.x * 4 + wave;
+    load_d(t_, bd);
+    for (; t_ < ntiles; t_ += tstride) {
+        const int b = (int)(t_ / tpi);
+        const long long p = (t_ % tpi) * 16 + col;
+        const bool in = p < hw;
+        const long long pc = in ? p : hw - 1;
+        load_d(t_ + tstride, bn);
+        const double two_dxx = 2.0 * dxx[(size_t)b * hw + pc];
+        double xv[4][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[ct][q] = x[((size_t)b * C + cb * 64 + ct * 16 + k + 4 * q) * hw + pc];
+        // ---- d x = W^T D (+ 2 x dxx)
+        v4d_t acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (v4d_t){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < MLRX_KS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wl[(4 * ks + k) * MLRZ_WS + ct * 16 + col], bd[ks], acc[ct], 0, 0, 0);
+        // ---- the tile's D and x to the slab (pixels beyond the image contribute nothing to d W)
+#pragma unroll
+        for (int ks = 0; ks < MLRX_KS; ++ks) Dt[(4 * ks + k) * MLRZ_RS + col] = in ? bd[ks] : 0.0;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xt[(ct * 16 + k + 4 * q) * MLRZ_RS + col] = xv[ct][q];
+        if (in)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    gx[((size_t)b * C + cb * 64 + ct * 16 + k + 4 * q) * hw + p] = __builtin_fma(two_dxx, xv[ct][q], acc[ct][q]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's slab writes before its own transposed reads
+        __builtin_amdgcn_wave_barrier();
+        // ---- d W += D x^T over the tile's 16 pixels: slot = lane >> 4 is pixel 4 e + slot
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double aw_[3], bw_[4];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                const int j = rt * 16 + col;                             // row of D (col doubles as the row index here)
+                const double v = Dt[(j < 4 * MLRX_KS ? j : 0) * MLRZ_RS + 4 * e + k];
+                aw_[rt] = j < 4 * MLRX_KS ? v : 0.0;                     // rows 40..47 do not exist (rows 2O..39 hold zeros)
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) bw_[ct] = Xt[(ct * 16 + col) * MLRZ_RS + 4 * e + k];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) accw[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw_[rt], bw_[ct], accw[rt][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // the transposed reads before the next tile's writes
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < MLRX_KS; ++ks) bd[ks] = bn[ks];
+    }
+    // ---- the workgroup's partial of d W: waves combined as (0 + 1) + (2 + 3) through the (now free) slabs
+    __syncthreads();
+    double *s_acc = Wl + 4 * MLRX_KS * MLRZ_WS;                           // two areas of 48 x 64 doubles inside the four slabs' space
+    auto publish = [&](double *dst) {
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[(rt * 16 + k + 4 * q) * 64 + ct * 16 + col] = accw[rt][ct][q];
+    };
+    auto absorb = [&](const double *src) {
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accw[rt][ct][q] += src[(rt * 16 + k + 4 * q) * 64 + ct * 16 + col];
+    };
+    if (wave & 1) publish(s_acc + (wave >> 1) * 48 * 64);
+    __syncthreads();
+    if (!(wave & 1)) absorb(s_acc + (wave >> 1) * 48 * 64);
+    __syncthreads();
+    if (wave == 2) publish(s_acc);
+    __syncthreads();
+    if (wave == 0) {
+        absorb(s_acc);
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = rt * 16 + k + 4 * q;
+                    if (j < 2 * O) w_part[((size_t)blockIdx.x * 2 * O + j) * C + cb * 64 + ct * 16 + col] = accw[rt][ct][q];
                 }
     }
 }
@@ -2004,16 +2142,29 @@ extern "C" int halo_hypermlr_backward(const double *x, const double *P, const do
                                (long long)hw, c, Dws, dxx, cls_part);
         }
         const long long ntiles = cdiv(hw, 16) * B;
+        // one pass for d x and d W (k_mlr_bwd_dxw): 2 x 64 x 160 x 320 123 us against 138 for the whole backward, 1 x 64 x 640 x 1280 607 against
+        // 736.  HALO_MLR_BWD_DXW=0: the two separate kernels (the test's cross-check: identical d x, d W within 1e-12)
+        const char *fenv = getenv("HALO_MLR_BWD_DXW");
+        const bool one_pass = !(fenv && fenv[0] == '0');
+        unsigned g = 0;
+        if (one_pass) {
+            g = (unsigned)(cdiv(ntiles, 4) < MLRB_NWG ? cdiv(ntiles, 4) : MLRB_NWG);
+            const size_t lds = ((size_t)4 * MLRX_KS * MLRZ_WS + (size_t)4 * (4 * MLRX_KS + 64) * MLRZ_RS) * sizeof(double);
+            static LdsLimitSeen seen;
+            if (!raise_lds_limit(seen, (const void *)k_mlr_bwd_dxw, 96 * 1024))
+                return fail(HALO_E_LAUNCH, "halo_hypermlr_backward: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL(k_mlr_bwd_dxw, dim3(g, (unsigned)(C / 64)), dim3(256), lds, st, x, (const double *)consts, (const double *)Dws, (const double *)dxx,
+                               (int)O, (int)C, (long long)hw, (int)B, gx, w_part);
+        } else {
         const unsigned gdx = (unsigned)(cdiv(ntiles, 4) < 512 ? cdiv(ntiles, 4) : 512);
         hipLaunchKernelGGL(k_mlr_bwd_dx, dim3(gdx, (unsigned)(C / 64)), dim3(256), 0, st, x, (const double *)consts, (const double *)Dws, (const double *)dxx,
                            (int)O, (int)C, (long long)hw, (int)B, gx);
-    }
-    {
         const long long nsteps = cdiv(hw, 16) * B;
-        const unsigned g = (unsigned)(cdiv(nsteps, 4) < MLRB_NWG ? cdiv(nsteps, 4) : MLRB_NWG);
+        g = (unsigned)(cdiv(nsteps, 4) < MLRB_NWG ? cdiv(nsteps, 4) : MLRB_NWG);
         const int vec_ok = hw % 4 == 0 && (((uintptr_t)x | (uintptr_t)Dws) % 16) == 0;
         hipLaunchKernelGGL(k_mlr_bwd_weights, dim3(g, (unsigned)(C / 32)), dim3(256), 0, st, x, (const double *)Dws, (int)O, (int)C, (long long)hw,
                            (int)B, vec_ok, w_part);
+        }
         hipLaunchKernelGGL(k_mlr_bwd_final, dim3((unsigned)O), dim3(MLRF_TPB), 0, st, A, (const double *)consts, (const double *)w_part, (int)g,
                            (const double *)cls_part, (int)npb, (int)O, (int)C, gP, gA);
     }
