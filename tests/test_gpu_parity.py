@@ -1421,24 +1421,25 @@ def test_hypermlr_fused_backward_matches_term_path(dev):
         P0, A0 = t(rng.uniform(-bound, bound, (O, C)), dev), t(rng.uniform(-bound, bound, (O, C)), dev)
         Wt = t(rng.standard_normal((B, O, h, w)), dev)
         res = []
-        # twice the default arm (small pixel counts: weights broadcast from LDS), then the scalar-cache arm, then the term-map path
-        for env in ({}, {}, {"HALO_MLR_BWD_W": "scalar"}, {"HALO_MLR_BWD_TERMS": "1"}, {"HALO_MLR_BWD_DXW": "0"}):
+        # 0, 1: the default twice   2: the pixel kernel's weights from LDS   3: its weights through the scalar cache   4: the term-map path
+        # 5: the two separate d x / d W kernels instead of the one-pass kernel
+        for env in ({}, {}, {"HALO_MLR_BWD_W": "lds"}, {"HALO_MLR_BWD_W": "scalar"}, {"HALO_MLR_BWD_TERMS": "1"}, {"HALO_MLR_BWD_DXW": "0"}):
             with _env_set(env):
                 x, P, A = x0.clone().requires_grad_(True), P0.clone().requires_grad_(True), A0.clone().requires_grad_(True)
                 (_HyperMLRFn.apply(x, P, A, c) * Wt).sum().backward()
                 res.append([g.grad.cpu().numpy() for g in (x, P, A)])
         for a_, b_ in zip(res[0], res[1]):
             assert np.array_equal(a_, b_), "the fused backward is not deterministic"
-        for a_, b_ in zip(res[0], res[2]):
+        for a_, b_ in zip(res[2], res[3]):
             assert np.array_equal(a_, b_), "the two weight paths of the pixel kernel run the same fma chains: same bits"
-        # the two separate d x / d W kernels (HALO_MLR_BWD_DXW=0) against the one-pass kernel: the same MFMA chains for d x (same bits),
-        # other partial sums for d W
-        assert np.array_equal(res[4][0], res[0][0]), "d x of the one-pass kernel differs from the d x kernel's"
-        for name, a_, b_ in zip(("gP", "gA"), res[4][1:], res[0][1:]):
+        # the two separate d x / d W kernels against the one-pass kernel: the same MFMA chains for d x (same bits), other partial sums for d W
+        assert np.array_equal(res[5][0], res[2][0]), "d x of the one-pass kernel differs from the d x kernel's"
+        for name, a_, b_ in zip(("gP", "gA"), res[5][1:], res[2][1:]):
             assert np.abs(a_ - b_).max() <= 1e-12 * np.abs(b_).max() + 1e-300, ("two kernels", name, B, C, O, h, w)
-        for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[3]):
-            assert np.isfinite(a_).all(), (name, B, C, O)
-            assert np.abs(a_ - b_).max() <= 1e-11 * np.abs(b_).max() + 1e-300, (name, B, C, O, h, w, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
+        for other, tag in ((2, "weights from LDS"), (4, "term maps")):
+            for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[other]):
+                assert np.isfinite(a_).all(), (name, B, C, O)
+                assert np.abs(a_ - b_).max() <= 1e-11 * np.abs(b_).max() + 1e-300, (tag, name, B, C, O, h, w, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
         # the same input at an address that is 8 but not 16 bytes aligned (a contiguous view one element into a buffer): the
         # 16-byte operand loads of the weight-gradient kernel and of the forward give way to their scalar arms
         buf = torch.empty(x0.numel() + 1, dtype=torch.float64, device=dev)
