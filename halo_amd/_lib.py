@@ -40,7 +40,7 @@ SIGNATURES = {
     "halo_hypermlr_bwd_terms": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _sz, _vp]),
     "halo_hypermlr_backward_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "halo_hypermlr_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "halo_hypermlr_backward": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "halo_bilinear_upsample": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp]),
     "halo_score_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "halo_score_maps": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int,

@@ -36,7 +36,7 @@ def hyper_head_tail(feat, mapper: HyperMapper, conv_seg: HyperMLR, size=None, re
         # expmap and HyperMLR carry HIP backward kernels; the resize stays on F.interpolate, which autograd
         # already differentiates (it is outside the kernels' scope under training)
         embed = mapper.expmap(feat, dim=1)
-        out = conv_seg(embed).float()
+        out = conv_seg._hyper_logits(embed, out_dtype=torch.float32)      # = conv_seg(embed).float(), the cast fused into the kernel's store
         if size is not None:
             out = F.interpolate(out, size=size, mode="bilinear", align_corners=True)
             if resize_embed:

@@ -189,12 +189,14 @@ class _HyperMLRFn(torch.autograd.Function):
         W = [-P ; A/||A||],  D = [dpx ; dxa]."""
 
     @staticmethod
-    def forward(ctx, x, P, A, c):
+    def forward(ctx, x, P, A, c, out_dtype=torch.float64):
+        # out_dtype=float32: the head's `.float()` (classifier.py:554) fused into the forward kernel's store; the backward then
+        # receives a float32 gradient and the native call reads it as it is (no cast kernels either way)
         xd = x.detach().double().contiguous()
         Pd, Ad = P.detach().contiguous(), A.detach().contiguous()
         ctx.save_for_backward(xd, Pd, Ad)
         ctx.c = c
-        return _mlr_forward(xd, Pd, Ad, c, torch.float64)
+        return _mlr_forward(xd, Pd, Ad, c, out_dtype)
 
     @staticmethod
     def backward(ctx, gout):
@@ -202,18 +204,18 @@ class _HyperMLRFn(torch.autograd.Function):
         dev = x.device
         B, Cc, H, W = x.shape
         O, hw = P.shape[0], H * W
-        gout = gout.double().contiguous()
         L = _lib.lib()
         nfused = 0 if os.environ.get("HALO_MLR_BWD_TERMS") else L.halo_hypermlr_backward_workspace_bytes(B, Cc, O, hw)
+        gout = (gout if (nfused and gout.dtype == torch.float32) else gout.double()).contiguous()
         if nfused:
             # the heads' shapes (<= 20 classes, 64 | C <= 256): the whole backward on the device in one call (three kernels)
             gx = torch.empty((B, Cc, H, W), dtype=torch.float64, device=dev)
             gP, gA = torch.empty_like(P), torch.empty_like(A)
             ws = torch.empty(nfused, dtype=torch.uint8, device=dev)
-            _lib.check(L.halo_hypermlr_backward(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(gout), B, Cc, O, hw, float(ctx.c),
+            _lib.check(L.halo_hypermlr_backward(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(gout), _lib.dtype_code(gout), B, Cc, O, hw, float(ctx.c),
                                                 _lib.ptr(gx), _lib.ptr(gP), _lib.ptr(gA), _lib.ptr(ws), nfused, _lib.stream_ptr(dev)),
                        "halo_hypermlr_backward")
-            return gx, gP, gA, None
+            return gx, gP, gA, None, None
         terms = torch.empty((5, B, O, hw), dtype=torch.float64, device=dev)       # dpx, dxa, dpp, dpa, dan
         dxx = torch.empty((B, hw), dtype=torch.float64, device=dev)
         nws = L.halo_hypermlr_workspace_bytes(O, Cc)
@@ -234,7 +236,7 @@ class _HyperMLRFn(torch.autograd.Function):
         g_An = gW[O:] + dpa[:, None] * (-P)                                       # through xa and pa = <-P, An>
         gP = -g_negP + dpp[:, None] * (2.0 * P) - dpa[:, None] * An               # pp = ||P||^2
         gA = (g_An - (g_An * An).sum(dim=1, keepdim=True) * An) / dn[:, None] + dan[:, None] * A / a_norm[:, None]
-        return gx.reshape(B, Cc, H, W), gP, gA, None
+        return gx.reshape(B, Cc, H, W), gP, gA, None, None
 
 
 class HyperMapper(object):
@@ -335,9 +337,10 @@ class HyperMLR(nn.Module):
         """inputs (B,C,H,W) float64 -> (B,O,H,W).  out_dtype=float32 fuses the head's `.float()`
         (core/models/classifier.py:373,554)."""
         _lib.require_device(inputs, self.P_MLR, self.A_MLR)
-        if _needs_grad(inputs, self.P_MLR, self.A_MLR):          # training: float64 logits with a HIP backward
-            out = _HyperMLRFn.apply(inputs, self.P_MLR, self.A_MLR, float(self.c))
-            return out if out_dtype == torch.float64 else out.to(out_dtype)
+        if _needs_grad(inputs, self.P_MLR, self.A_MLR):          # training: HIP backward; float32 logits straight from the kernel
+            if out_dtype in (torch.float64, torch.float32):
+                return _HyperMLRFn.apply(inputs, self.P_MLR, self.A_MLR, float(self.c), out_dtype)
+            return _HyperMLRFn.apply(inputs, self.P_MLR, self.A_MLR, float(self.c)).to(out_dtype)
         return _mlr_forward(inputs.double().contiguous(), self.P_MLR.detach().contiguous(),
                             self.A_MLR.detach().contiguous(), self.c, out_dtype)
 

@@ -1179,9 +1179,9 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-template <bool SCALAR_W>
+template <bool SCALAR_W, typename TG>      // TG: dtype of gout (float32: the head's .float() under autograd hands a float32 gradient back)
 __global__ void __launch_bounds__(MLRB_TPB, SCALAR_W ? 3 : 2) k_mlr_bwd_pixels(const double *__restrict__ x, const double *__restrict__ consts,
-                                                             const double *__restrict__ Wg, const double *__restrict__ gout, int O, int C,
+                                                             const double *__restrict__ Wg, const TG *__restrict__ gout, int O, int C,
                                                              long long hw, double K, double *__restrict__ Dws,
                                                              double *__restrict__ dxx_out, double *__restrict__ cls_part)
 {
@@ -1246,12 +1246,12 @@ __global__ void __launch_bounds__(MLRB_TPB, SCALAR_W ? 3 : 2) k_mlr_bwd_pixels(c
     // Two classes per trip, both straight-line sweeps written back to back (one basic block: their dependent chains interleave),
     // then ONE wave-uniform test for the rare arm.  Class O of an odd O is padding (zero weights, constants read in bounds, nothing
     // stored or summed).
-    const double *gb = gout + (size_t)b * O * hw + i;
+    const TG *gb = gout + (size_t)b * O * hw + i;
 #pragma unroll
     for (int o = 0; o < MLRB_OP; o += 2) {
         if (o < O) {                                                     // wave-uniform
             const bool has1 = o + 1 < O;                                 // wave-uniform
-            const double gF0 = gb[(size_t)o * hw], gF1 = has1 ? gb[(size_t)(o + 1) * hw] : 0.0;
+            const double gF0 = (double)gb[(size_t)o * hw], gF1 = has1 ? (double)gb[(size_t)(o + 1) * hw] : 0.0;
             MlrFast f0 = mlr_reverse_inside(px[o], xa[o], gF0, pp[o], pa[o], anorm[o], xx, K, sqK, maxnorm);
             MlrFast f1 = mlr_reverse_inside(px[o + 1], xa[o + 1], gF1, pp[o + 1], pa[o + 1], anorm[o + 1], xx, K, sqK, maxnorm);
             if (__any(!f0.ok || (has1 && !f1.ok))) {                     // clamped D, on / beyond the ball, NaN / inf: never in a trained head
@@ -2102,13 +2102,14 @@ extern "C" size_t halo_hypermlr_backward_workspace_bytes(int64_t B, int64_t C, i
                                                        (size_t)MLRB_NWG * 2 * O * C) * sizeof(double) + 5 * 256;
 }
 
-extern "C" int halo_hypermlr_backward(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
-                                      int64_t O, int64_t hw, double c, double *gx, double *gP, double *gA, void *workspace,
+extern "C" int halo_hypermlr_backward(const double *x, const double *P, const double *A, const void *gout, int gout_dtype, int64_t B,
+                                      int64_t C, int64_t O, int64_t hw, double c, double *gx, double *gP, double *gA, void *workspace,
                                       size_t workspace_bytes, void *stream)
 {
     if (!x || !P || !A || !gout || !gx || !gP || !gA || B <= 0 || C <= 0 || O <= 0 || hw <= 0)
         return fail(HALO_E_ARG, "halo_hypermlr_backward: null/empty argument");
     if (c <= 0) return fail(HALO_E_UNSUPPORTED, "halo_hypermlr_backward: curvature must be > 0");
+    if (gout_dtype != HALO_F32 && gout_dtype != HALO_F64) return fail(HALO_E_ARG, "halo_hypermlr_backward: bad gout dtype");
     if (!mlr_bwd_fused_ok(C, O))
         return fail(HALO_E_UNSUPPORTED, "halo_hypermlr_backward: serves at most %d classes and 64 | C <= 256 (got O = %lld, C = %lld): use halo_hypermlr_bwd_terms",
                     MLRB_OP, (long long)O, (long long)C);
@@ -2130,17 +2131,20 @@ extern "C" int halo_hypermlr_backward(const double *x, const double *P, const do
         // >= 2 resident waves on every SIMD: weights through the scalar cache (HALO_MLR_BWD_W=lds|scalar forces an arm: tests, A/B)
         const char *wenv = getenv("HALO_MLR_BWD_W");
         const bool scalar_w = wenv ? wenv[0] == 's' : (long long)B * hw >= 400000;
+#define HALO_MLRB_PIX(SW_, TG_, LDS_)                                                                                              \
+    hipLaunchKernelGGL((k_mlr_bwd_pixels<SW_, TG_>), gp, dim3(MLRB_TPB), LDS_, st, x, (const double *)consts, (const double *)Wt, (const TG_ *)gout, \
+                       (int)O, (int)C, (long long)hw, c, Dws, dxx, cls_part)
         if (scalar_w) {
-            hipLaunchKernelGGL((k_mlr_bwd_pixels<true>), gp, dim3(MLRB_TPB), 0, st, x, (const double *)consts, (const double *)Wt, gout, (int)O, (int)C,
-                               (long long)hw, c, Dws, dxx, cls_part);
+            if (gout_dtype == HALO_F32) HALO_MLRB_PIX(true, float, 0); else HALO_MLRB_PIX(true, double, 0);
         } else {
             const size_t lds = (size_t)C * MLRB_WS * sizeof(double);     // 80 KiB at C = 256
-            static LdsLimitSeen seen;
-            if (lds > 48 * 1024 && !raise_lds_limit(seen, (const void *)k_mlr_bwd_pixels<false>, 96 * 1024))
+            static LdsLimitSeen seen_f, seen_d;
+            if (lds > 48 * 1024 && !(gout_dtype == HALO_F32 ? raise_lds_limit(seen_f, (const void *)k_mlr_bwd_pixels<false, float>, 96 * 1024)
+                                                            : raise_lds_limit(seen_d, (const void *)k_mlr_bwd_pixels<false, double>, 96 * 1024)))
                 return fail(HALO_E_LAUNCH, "halo_hypermlr_backward: cannot raise the dynamic LDS limit");
-            hipLaunchKernelGGL((k_mlr_bwd_pixels<false>), gp, dim3(MLRB_TPB), lds, st, x, (const double *)consts, (const double *)Wt, gout, (int)O, (int)C,
-                               (long long)hw, c, Dws, dxx, cls_part);
+            if (gout_dtype == HALO_F32) HALO_MLRB_PIX(false, float, lds); else HALO_MLRB_PIX(false, double, lds);
         }
+#undef HALO_MLRB_PIX
         const long long ntiles = cdiv(hw, 16) * B;
         // one pass for d x and d W (k_mlr_bwd_dxw): 2 x 64 x 160 x 320 123 us against 138 for the whole backward, 1 x 64 x 640 x 1280 607 against
         // 736.  HALO_MLR_BWD_DXW=0: the two separate kernels (the test's cross-check: identical d x, d W within 1e-12)

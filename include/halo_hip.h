@@ -95,14 +95,15 @@ int halo_hypermlr_bwd_terms(const double *x, const double *P, const double *A, c
                             int64_t O, int64_t hw, double c, double *dpx, double *dxa, double *dxx, double *dpp,
                             double *dpa, double *dan, void *workspace, size_t workspace_bytes, void *stream);
 
-/* The whole backward of HyperMLR._hyper_logits in one call (ABI 7): from gout = dL/dlogit (B,O,hw) f64 it writes
+/* The whole backward of HyperMLR._hyper_logits in one call (ABI 7): from gout = dL/dlogit (B,O,hw), HALO_F64 or HALO_F32 (the head's
+ * `.float()` under autograd hands a float32 gradient back: classifier.py:554), it writes
  * gx = dL/dx (B,C,hw), gP = dL/dP_MLR and gA = dL/dA_MLR (O,C), all f64 -- the reverse sweep above, d x = W^T D + 2 x dxx,
  * d W = D x^T and the parameter algebra (||P||^2, <-P,A^>, F.normalize, ||A||; hyperbolic.py:137-174) on the device, every sum
  * in a fixed order (run-to-run identical).  Serves O <= 20 classes and C a multiple of 64 up to 256 (the heads' 19 x 64):
  * halo_hypermlr_backward_workspace_bytes returns 0 for any other shape, and the caller then composes the backward from
  * halo_hypermlr_bwd_terms and its own GEMMs (halo_amd/core/utils/hyperbolic.py does). */
 size_t halo_hypermlr_backward_workspace_bytes(int64_t B, int64_t C, int64_t O, int64_t hw);
-int halo_hypermlr_backward(const double *x, const double *P, const double *A, const double *gout, int64_t B, int64_t C,
+int halo_hypermlr_backward(const double *x, const double *P, const double *A, const void *gout, int gout_dtype, int64_t B, int64_t C,
                            int64_t O, int64_t hw, double c, double *gx, double *gP, double *gA, void *workspace,
                            size_t workspace_bytes, void *stream);
 

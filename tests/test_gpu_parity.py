@@ -1440,6 +1440,19 @@ def test_hypermlr_fused_backward_matches_term_path(dev):
             for name, a_, b_ in zip(("gx", "gP", "gA"), res[0], res[other]):
                 assert np.isfinite(a_).all(), (name, B, C, O)
                 assert np.abs(a_ - b_).max() <= 1e-11 * np.abs(b_).max() + 1e-300, (tag, name, B, C, O, h, w, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
+        # float32 logits straight from the forward kernel and a float32 gradient straight into the backward (the head's `.float()`
+        # fused at both ends): the bits of the float64 route with the cast outside
+        W32 = Wt.float()
+        xa_, Pa_, Aa_ = x0.clone().requires_grad_(True), P0.clone().requires_grad_(True), A0.clone().requires_grad_(True)
+        o32 = _HyperMLRFn.apply(xa_, Pa_, Aa_, c, torch.float32)
+        assert o32.dtype == torch.float32
+        (o32 * W32).sum().backward()
+        xb_, Pb_, Ab_ = x0.clone().requires_grad_(True), P0.clone().requires_grad_(True), A0.clone().requires_grad_(True)
+        o64 = _HyperMLRFn.apply(xb_, Pb_, Ab_, c)
+        assert torch.equal(o32, o64.float())
+        (o64.float() * W32).sum().backward()
+        for ga_, gb_ in ((xa_.grad, xb_.grad), (Pa_.grad, Pb_.grad), (Aa_.grad, Ab_.grad)):
+            assert torch.equal(ga_, gb_), "float32 gradient route differs from the float64 route"
         # the same input at an address that is 8 but not 16 bytes aligned (a contiguous view one element into a buffer): the
         # 16-byte operand loads of the weight-gradient kernel and of the forward give way to their scalar arms
         buf = torch.empty(x0.numel() + 1, dtype=torch.float64, device=dev)

@@ -19,7 +19,7 @@ for (B, C, O, h, w) in ((2, 64, 19, 160, 320), (1, 64, 19, 640, 1280)):
     ws = torch.empty(n, dtype=torch.uint8, device=dev)
 
     def call():
-        _lib.check(L.halo_hypermlr_backward(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(gout), B, C, O, h * w, 1.0, _lib.ptr(gx), _lib.ptr(gP),
+        _lib.check(L.halo_hypermlr_backward(_lib.ptr(x), _lib.ptr(P), _lib.ptr(A), _lib.ptr(gout), _lib.dtype_code(gout), B, C, O, h * w, 1.0, _lib.ptr(gx), _lib.ptr(gP),
                                             _lib.ptr(gA), _lib.ptr(ws), n, _lib.stream_ptr(dev)), "halo_hypermlr_backward")
     for _ in range(3):
         call()

@@ -32,7 +32,7 @@ mapper, mlr = HyperMapper(1.0), HyperMLR(64, 19).to(dev)
 
 def head():
     emb = mapper.expmap(feat, dim=1)
-    out = mlr(emb).float()
+    out = mlr._hyper_logits(emb, out_dtype=torch.float32)      # = mlr(emb).float() as halo_amd/core/models/classifier.py's training tail calls it
     out.sum().backward()
 
 
