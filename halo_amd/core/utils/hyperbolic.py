@@ -184,7 +184,7 @@ class _HyperMLRFn(torch.autograd.Function):
 
     backward, at the heads' shapes (<= 20 classes, 64 | C <= 256): ONE native call (halo_hypermlr_backward: the reverse sweep
     through the Moebius / projection / asinh algebra per pixel and class, d x = W^T D + 2 x dxx, d W = D x^T and the
-    parameter algebra, three kernels, fixed summation order).  Any other shape (and HALO_MLR_BWD_TERMS=1, the cross-check):
+    parameter algebra: prep + three kernels, fixed summation order).  Any other shape (and HALO_MLR_BWD_TERMS=1, the cross-check):
     one HIP kernel for the reverse sweep + the two dense contractions as library GEMMs (torch.einsum -> rocBLAS),
         W = [-P ; A/||A||],  D = [dpx ; dxa]."""
 
@@ -208,7 +208,7 @@ class _HyperMLRFn(torch.autograd.Function):
         nfused = 0 if os.environ.get("HALO_MLR_BWD_TERMS") else L.halo_hypermlr_backward_workspace_bytes(B, Cc, O, hw)
         gout = (gout if (nfused and gout.dtype == torch.float32) else gout.double()).contiguous()
         if nfused:
-            # the heads' shapes (<= 20 classes, 64 | C <= 256): the whole backward on the device in one call (three kernels)
+            # the heads' shapes (<= 20 classes, 64 | C <= 256): the whole backward on the device in one call
             gx = torch.empty((B, Cc, H, W), dtype=torch.float64, device=dev)
             gP, gA = torch.empty_like(P), torch.empty_like(A)
             ws = torch.empty(nfused, dtype=torch.uint8, device=dev)

@@ -1159,7 +1159,7 @@ __global__ void __launch_bounds__(HTPB) k_hypermlr_bwd_terms(const double *__res
 // Until round 5 the backward was k_hypermlr_bwd_terms (five (B,O,hw) term maps written to HBM) followed by ~45 library launches
 // in halo_amd/core/utils/hyperbolic.py: three full-map sums, two einsums with their permuted copies, a padded / permuted batched
 // GEMM for d W, and a dozen (O,C)-sized element-wise kernels -- 0.56 ms of the 0.81 ms the head tail's forward + backward took at
-// the training shape (2 x 64 x 160 x 320; profiles/r05_head_bwd_kernels.txt), against 0.03 ms for the forward.  Four kernels now:
+// the training shape (2 x 64 x 160 x 320; profiles/r05_head_bwd_kernels.txt), against 0.03 ms for the forward.  Now, behind k_mlr_prep:
 //   k_mlr_bwd_pixels   one lane per pixel: ||x||^2 and the two contractions px / xa in ONE walk over the channels (weights broadcast
 //                      from an LDS image of [-P | A^] laid out channel-major), the reverse sweep for every class; dpx / dxa (the
 //                      matrix D, 2O x pixels) and dxx go to the workspace, the three per-class sums (dpp, dpa, d||A||) leave as one
