@@ -1789,15 +1789,19 @@ def test_training_losses_ragged_shapes_and_many_classes(dev):
             label[1] = 3                                              # no boundary in the second image
         label = label.to(dev)
         for lt in ("l1", "kl"):
-            xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
-            la = LocalConsistentLoss(O, lt)(xa, label)
+            xb = x0.clone().requires_grad_(True)
             lb = _torch_local_consistent(xb, label, lt == "kl")
-            if bool(torch.isnan(lb)):
-                assert bool(torch.isnan(la))
-                continue
-            assert abs(la.item() - lb.item()) < 3e-6 * max(1.0, abs(lb.item())), (B, O, h, w, lt, la.item(), lb.item())
-            (ga,), (gb,) = torch.autograd.grad(la, xa), torch.autograd.grad(lb, xb)
-            assert float((ga - gb).abs().max()) < 3e-5 * float(gb.abs().max()) + 1e-9, (B, O, h, w, lt)
+            gb = None if bool(torch.isnan(lb)) else torch.autograd.grad(lb, xb)[0]
+            for env in ({}, {"HALO_LCL_PLAIN": "1"}):          # the strip-walking forward (default) and the one-pixel-per-thread forward
+                with _env_set(env):
+                    xa = x0.clone().requires_grad_(True)
+                    la = LocalConsistentLoss(O, lt)(xa, label)
+                    if gb is None:
+                        assert bool(torch.isnan(la))
+                        continue
+                    assert abs(la.item() - lb.item()) < 3e-6 * max(1.0, abs(lb.item())), (B, O, h, w, lt, env, la.item(), lb.item())
+                    (ga,) = torch.autograd.grad(la, xa)
+                    assert float((ga - gb).abs().max()) < 3e-5 * float(gb.abs().max()) + 1e-9, (B, O, h, w, lt, env)
     for n, off in ((1000, 0), (1003, 0), (1001, 1), (5, 3), (4096, 2)):
         buf = torch.rand(n + off + 8, generator=g).to(dev) * 0.2
         pa, pb = buf[off:off + n].clone().requires_grad_(True), buf[off:off + n].clone().requires_grad_(True)
