@@ -1222,6 +1222,31 @@ def test_hypermlr_matrix_core_path_matches_valu_path(golden, dev):
     assert max_abs_diff(got, ho.hypermlr(x, mlr.P_MLR.detach().cpu().numpy(), mlr.A_MLR.detach().cpu().numpy(), 1.0)) < 1e-11
 
 
+def test_hypermlr_epilogue_forms_agree(dev):
+    """The matrix-core HyperMLR's one-quotient epilogue (default) against the reference-order statement it replaced
+    (HALO_MLR_EPI_REF=1: also its rare arm): ordinary embeddings, every x on the ball's boundary, curvatures != 1, an exact-origin
+    pixel; NaN / inf in x must come out as the reference-order form propagates them."""
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
+    rng = np.random.default_rng(5)
+    for (B, C, O, h, w, c, scale) in ((1, 64, 19, 20, 36, 1.0, 0.1), (2, 64, 19, 16, 24, 1.0, 0.7), (1, 128, 16, 9, 14, 0.5, 0.3),
+                                      (1, 256, 20, 8, 8, 2.0, 0.2), (1, 64, 32, 6, 10, 0.1, 1.0)):
+        z = (rng.standard_normal((B, C, h, w)) * scale).astype(np.float32)
+        z[0, :, 0, 0] = 0.0
+        x = HyperMapper(c).expmap(t(z, dev), dim=1).double()
+        mlr = HyperMLR(C, O, c=c).to(dev)
+        with torch.no_grad():
+            a = mlr(x)
+            r = _with_env({"HALO_MLR_EPI_REF": "1"}, lambda: mlr(x))
+            assert bool(torch.isfinite(a).all())
+            assert float((a - r).abs().max()) < 2e-12 * max(1.0, float(r.abs().max())), (B, C, O, c, scale, float((a - r).abs().max()))
+            xn = x.clone()
+            xn[0, 3, 1, 1] = float("nan"); xn[0, 5, 2, 3] = float("inf")
+            an, rn = mlr(xn), _with_env({"HALO_MLR_EPI_REF": "1"}, lambda: mlr(xn))
+            assert torch.equal(torch.isnan(an), torch.isnan(rn)) and bool(torch.isnan(an[0, :, 1, 1]).all())
+            ok = ~torch.isnan(rn)
+            assert float((an[ok] - rn[ok]).abs().max()) < 2e-12 * max(1.0, float(rn[ok].abs().max()))
+
+
 def test_selection_is_stable_beside_streaming_kernels(dev):
     """The selector's window stores are drained one step late and masked analytically meanwhile
     (halo_select.hip); its loads see HBM latencies several times longer when the feature stream
