@@ -103,6 +103,32 @@ __global__ void __launch_bounds__(FIN_TPB) k_minmax_finalize2(const double *__re
 // independent chains (that fills the two-cycle hazard slots between v_cmp / v_cndmask pairs).  Built without SLP
 // vectorisation (_build.py): packed v_pk_fma_f32 would save 10 % of the instructions and cost 40 VGPRs.
 
+// torch.sum over the class axis in ATen's order (SumKernel.cpp, multi_row_sum; floating_region.py:72,119): terms enter acc[0]
+// one by one; every 16 terms acc[0] is flushed into acc[1], every 256 acc[1] into acc[2], every 4096 acc[2] into acc[3]; the result
+// is ((acc[0] + acc[1]) + acc[2]) + acc[3].  For 19 classes: (t16 + t17 + t18) + (t0 + ... + t15).  Stated here on the class
+// index alone -- a flush happens when the NEXT term's index lies in another block, and the last block is never flushed: the
+// same value, because the flushes ATen does beyond that either add +0 or commute with the final additions -- so that the window
+// histograms below can skip their empty classes (an empty class contributes (-0) log(1e-6) = +0).  oracle/halo_oracle.c states
+// ATen's loop literally (cascade_sum_f32).
+struct ClassSum {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int prev = 0;
+    __device__ __forceinline__ void add(int c, float t)
+    {
+        const int x = c ^ prev;
+        if (x >> 4) {
+            a1 = a1 + a0; a0 = 0.0f;
+            if (x >> 8) {
+                a2 = a2 + a1; a1 = 0.0f;
+                if (x >> 12) { a3 = a3 + a2; a2 = 0.0f; }
+            }
+        }
+        a0 = a0 + t;
+        prev = c;
+    }
+    __device__ __forceinline__ float result() const { return ((a0 + a1) + a2) + a3; }
+};
+
 // General statement for one pixel whose class planes start at lp (stride hw).  is_prob: the planes already hold softmax
 // probabilities (helper-method API).
 __device__ __forceinline__ void px_general(const float *__restrict__ lp, int O, long long hw, int is_prob, int unc_type,
@@ -117,15 +143,17 @@ __device__ __forceinline__ void px_general(const float *__restrict__ lp, int O, 
 #pragma unroll 1
         for (int c = 0; c < O; ++c) s = s + det_expf(lp[(size_t)c * hw] - m);
     }
-    float a = 0.0f, best = 0.0f, pg = 0.0f;
+    float best = 0.0f, pg = 0.0f;
+    ClassSum acc;
     int am = 0;               // torch.argmax: first maximal class
 #pragma unroll 1
     for (int c = 0; c < O; ++c) {
         const float p = is_prob ? lp[(size_t)c * hw] : det_expf(lp[(size_t)c * hw] - m) / s;
         if (c == 0 || p > best) { best = p; am = c; }
         if (c == (int)g) pg = p;
-        a = a + (-p) * det_logf(p + 1e-6f);
+        acc.add(c, (-p) * det_logf(p + 1e-6f));
     }
+    const float a = acc.result();
     if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) ent = a / (float)2.9444389791664403;   // math.log(19): hard-coded in the reference (:74-76)
     else if (unc_type == HALO_UNC_ORACLE_ACC) ent = 1.0f - (g == 255 ? best : pg);
     else ent = 0.0f;
@@ -228,19 +256,25 @@ __device__ __forceinline__ void finish_px(float (&p)[NP][O_T], int unc_type, int
             for (int j = 0; j < NP; ++j) { const bool gtb = p[j][c] > best[j]; am[j] = gtb ? c : am[j]; best[j] = gtb ? p[j][c] : best[j]; }
     }
     if (unc_type == HALO_UNC_ENTROPY || unc_type == HALO_UNC_PIXEL_ENTROPY) {
-        float a[NP];
+        // torch.sum(dim=0) in ATen's order (ClassSum above, unrolled): full blocks of 16 classes each from +0 into a1, the rest into a0
+        static_assert(O_T <= 256, "class count of the unrolled statement");
+        float a0[NP], a1[NP];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) a[j] = 0.0f;
+        for (int j = 0; j < NP; ++j) a0[j] = a1[j] = 0.0f;
 #pragma unroll
         for (int c = 0; c < O_T; ++c) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const float q = p[j][c] + 1e-6f;
-                a[j] = a[j] + (-p[j][c]) * (LEAN ? det_logf_core(q) : det_logf(q));
+                a0[j] = a0[j] + (-p[j][c]) * (LEAN ? det_logf_core(q) : det_logf(q));
             }
-            }
+            if ((c & 15) == 15 && c + 1 < O_T) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) ent[j] = a[j] / (float)2.9444389791664403;   // math.log(19): hard-coded in the reference (:74-76)
+                for (int j = 0; j < NP; ++j) { a1[j] = a1[j] + a0[j]; a0[j] = 0.0f; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) ent[j] = (a0[j] + a1[j]) / (float)2.9444389791664403;   // math.log(19): hard-coded in the reference (:74-76)
     } else if (unc_type == HALO_UNC_ORACLE_ACC) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -518,8 +552,8 @@ __global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const
 }
 
 // ---------------------------------------------------------------- compute_region_impurity (floating_region.py:112-121)
-// Window class histogram -> sum_c -d*log(d+1e-6) / log(K), classes visited in ascending order
-// (= the reference's sum over the one-hot channel axis; empty classes contribute exactly 0).
+// Window class histogram -> sum_c -d*log(d+1e-6) / log(K), classes visited in ascending order and added in
+// torch.sum's order over the one-hot channel axis (ClassSum; empty classes contribute exactly +0).
 // No one-hot tensor: the <= k*k window labels are re-scanned once per distinct class.
 // nn.Conv2d(padding_mode=...) of the two box filters (floating_region.py:49,63): where a window tap falls outside the image.
 // 'zeros' contributes nothing (and does not count in the purity window); the other three modes read an image pixel
@@ -548,7 +582,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const TL *__restrict__ 
     const int x0 = pad ? x - r : (x - r < 0 ? 0 : x - r), x1 = pad ? x + r : (x + r >= W ? W - 1 : x + r);
     const TL *pp = pred + (size_t)b * hw;
     const float cnt = (float)((y1 - y0 + 1) * (x1 - x0 + 1));
-    float a = 0.0f;
+    ClassSum acc;
     int cur = -1;
     while (true) {
         int nxt = 0x7fffffff, n = 0;
@@ -562,10 +596,10 @@ __global__ void __launch_bounds__(TPB) k_region_impurity(const TL *__restrict__ 
             }
         if (n == 0) break;
         const float d = (float)n / cnt;
-        a = a + (-d) * det_logf(d + 1e-6f);
+        acc.add(nxt, (-d) * det_logf(d + 1e-6f));
         cur = nxt;
     }
-    imp[(size_t)b * hw + i] = a / logK;
+    imp[(size_t)b * hw + i] = acc.result() / logK;
     if (count) count[(size_t)b * hw + i] = cnt;
 }
 
@@ -619,7 +653,7 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
         const int cnti = ny * ((x > 0 ? 1 : 0) + 1 + (x < W - 1 ? 1 : 0));
         const float cnt = (float)cnti;
         const float *tc = term[cnti];
-        float a = 0.0f;
+        ClassSum acc;
         int cur = -1;
         while (true) {
             int nxt = 0x7fffffff;
@@ -633,10 +667,10 @@ __global__ void __launch_bounds__(TPB) k_region_impurity3(const TL *__restrict__
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) n += v[dy][j + dx] == nxt ? 1 : 0;
-            a = a + tc[n];
+            acc.add(nxt, tc[n]);
             cur = nxt;
         }
-        const float res = a / logK;
+        const float res = acc.result() / logK;
         imp[(size_t)b * hw + (size_t)y * W + x] = res;
         if (count) count[(size_t)b * hw + (size_t)y * W + x] = cnt;
         if (j == 0) mn = mx = (double)res;

@@ -35,6 +35,17 @@ float halo_o_expf(float x) { return ho_expf(x); }
 float halo_o_logf(float x) { return ho_logf(x); }
 double halo_o_log(double x) { return ho_log(x); }
 
+void halo_o_expf_v(const float *x, float *y, i64 n)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) y[i] = ho_expf(x[i]);
+}
+void halo_o_logf_v(const float *x, float *y, i64 n)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) y[i] = ho_logf(x[i]);
+}
+
 /* sabs(k)**0.5 with k = -c  (geoopt sabs: |x| + 1e-15) */
 static double k_sqrt(double c) { return sqrt(fabs(-c) + 1e-15); }
 
@@ -404,11 +415,55 @@ static i64 argmax_px(const float *p, i64 O)
     for (i64 c = 1; c < O; ++c) if (p[c] > p[b]) b = c;
     return b;
 }
+/* torch.sum over a strided dimension of float32 terms, in ATen's order (aten/src/ATen/native/cpu/SumKernel.cpp,
+ * multi_row_sum; floating_region.py:72,119 reduce dim 0 / dim 1 of a tensor that is contiguous over H x W): a cascade
+ * of four accumulators -- rows are added one by one into acc[0]; after every 2^lp rows acc[0] is flushed into acc[1],
+ * after every 2^(2 lp) rows acc[1] into acc[2], and so on; lp = max(4, ceil(log2 n) / 4); at the end the remainder in
+ * acc[0] takes acc[1], acc[2], acc[3] in turn.  For the 19 classes: (t16 + t17 + t18) + (t0 + ... + t15), each
+ * bracket from +0 left to right.  Bit for bit torch's CPU result, for the vectorised columns and the scalar tail
+ * alike (tests/test_aten_exact.py). */
+static float cascade_sum_f32(const float *t, i64 n)
+{
+    i64 cl = 0;
+    while (((i64)1 << cl) < n) ++cl;                               /* utils::CeilLog2 */
+    const i64 lp = cl / 4 > 4 ? cl / 4 : 4, step = (i64)1 << lp, mask = step - 1;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    i64 i = 0;
+    while (i + step <= n) {
+        for (i64 j = 0; j < step; ++j, ++i) acc[0] = acc[0] + t[i];
+        for (int j = 1; j < 4; ++j) {
+            acc[j] = acc[j] + acc[j - 1];
+            acc[j - 1] = 0.0f;
+            if ((i & (mask << (j * lp))) != 0) break;
+        }
+    }
+    for (; i < n; ++i) acc[0] = acc[0] + t[i];
+    for (int j = 1; j < 4; ++j) acc[0] = acc[0] + acc[j];
+    return acc[0];
+}
+
+/* torch.sum(t, dim=0) of a dense (n, hw) float32 array (test probe of the order above) */
+void halo_o_sum_dim0(const float *t, i64 n, i64 hw, float *out)
+{
+#pragma omp parallel
+    {
+        float *col = (float *)malloc(sizeof(float) * (size_t)n);
+#pragma omp for schedule(static)
+        for (i64 i = 0; i < hw; ++i) {
+            for (i64 c = 0; c < n; ++c) col[c] = t[c * hw + i];
+            out[i] = cascade_sum_f32(col, n);
+        }
+        free(col);
+    }
+}
+
 /* sum_c -p*log(p+1e-6) / log(19)   (floating_region.py:72-76,123-127: the 19 is hard-coded) */
 static float entropy_px(const float *p, i64 O)
 {
-    float a = 0.0f;
-    for (i64 c = 0; c < O; ++c) a = a + (-p[c]) * ho_logf(p[c] + 1e-6f);
+    float tbuf[64], *t = O <= 64 ? tbuf : (float *)malloc(sizeof(float) * (size_t)O);
+    for (i64 c = 0; c < O; ++c) t[c] = (-p[c]) * ho_logf(p[c] + 1e-6f);
+    const float a = cascade_sum_f32(t, O);
+    if (t != tbuf) free(t);
     return a / (float)log(19.0);
 }
 
@@ -424,7 +479,11 @@ static i64 pad_index(i64 t, i64 n, int mode)
     return t < 0 ? t + n : t - n;
 }
 
-/* k x k all-ones conv, padding k/2 (floating_region.py:42-51,90): row-major tap order */
+/* k x k all-ones conv, padding k/2 (floating_region.py:42-51,90): taps added in row-major order from +0.  That is bit for bit
+ * what F.conv2d returns on the CPU whenever ATen hands the convolution to oneDNN -- for this 1 -> 1 channel 3 x 3 filter: every
+ * image of more than 20480 pixels (aten/src/ATen/native/Convolution.cpp, use_mkldnn), i.e. every size the reference's pipeline
+ * runs (tests/test_aten_exact.py: 101 x 203 up to 1024 x 2048).  At or below 20480 pixels ATen unfolds the image and calls
+ * MKL's sgemm, whose summation order is MKL's own: the small fixtures agree with this order to an ulp or two, not bitwise. */
 static void box_sum_f32(const float *in, float *out, i64 H, i64 W, int k, int pad)
 {
     const int r = k / 2;
@@ -442,6 +501,8 @@ static void box_sum_f32(const float *in, float *out, i64 H, i64 W, int k, int pa
         }
 }
 
+void halo_o_box_sum(const float *in, float *out, i64 H, i64 W, int k, int pad) { box_sum_f32(in, out, H, W, k, pad); }
+
 /* compute_region_impurity (floating_region.py:112-121): window class histogram -> entropy/log(K) */
 static void region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *imp, float *count, int pad)
 {
@@ -449,7 +510,7 @@ static void region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *
     const float logK = (float)log((double)K);
 #pragma omp parallel
     {
-        float *hist = (float *)malloc(sizeof(float) * (size_t)K);
+        float *hist = (float *)malloc(sizeof(float) * (size_t)K * 2), *term = hist + K;
 #pragma omp for schedule(static)
         for (i64 y = 0; y < H; ++y)
             for (i64 x = 0; x < W; ++x) {
@@ -460,10 +521,11 @@ static void region_impurity(const i64 *pred, i64 K, int k, i64 H, i64 W, float *
                         const i64 yy = pad_index(y + dy, H, pad), xx = pad_index(x + dx, W, pad);
                         if (yy >= 0 && xx >= 0) { hist[pred[yy * W + xx]] += 1.0f; cnt += 1.0f; }
                     }
-                float a = 0.0f;
-                for (i64 c = 0; c < K; ++c)
-                    if (hist[c] > 0.0f) { float d = hist[c] / cnt; a = a + (-d) * ho_logf(d + 1e-6f); }
-                imp[y * W + x] = a / logK;
+                for (i64 c = 0; c < K; ++c) {                          /* an empty bin contributes (-0) * log(1e-6) = +0 */
+                    const float d = hist[c] / cnt;
+                    term[c] = hist[c] > 0.0f ? (-d) * ho_logf(d + 1e-6f) : 0.0f;
+                }
+                imp[y * W + x] = cascade_sum_f32(term, K) / logK;  /* torch.sum(dim=1), :119 */
                 count[y * W + x] = cnt;
             }
         free(hist);

@@ -211,6 +211,39 @@ def floating_region_score(logit, decoder_out=None, unc_type=None, pur_type=None,
     return score, imp, unc
 
 
+def _map_f32(fn, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    fn(_p(x), _p(y), _i64(x.size))
+    return y
+
+
+def expf(x):
+    """The contract's float32 exp (Sleef expf_u10 = ATen's Vectorized<float>::exp) elementwise."""
+    return _map_f32(lib().halo_o_expf_v, x)
+
+
+def logf(x):
+    """The contract's float32 log (correctly rounded) elementwise."""
+    return _map_f32(lib().halo_o_logf_v, x)
+
+
+def sum_dim0(t):
+    """torch.sum(t, dim=0) of a float32 (n, ...) array in ATen's cascade order."""
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    out = np.empty(t.shape[1:], np.float32)
+    lib().halo_o_sum_dim0(_p(t), _i64(t.shape[0]), _i64(out.size), _p(out))
+    return out
+
+
+def box_sum(x, size=3, padding_mode="zeros"):
+    """entropy_conv (floating_region.py:42-51): k x k all-ones box sum of an (H,W) float32 map."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().halo_o_box_sum(_p(x), _p(out), _i64(x.shape[0]), _i64(x.shape[1]), _int(size), _int(PAD[padding_mode]))
+    return out
+
+
 def softmax(logit):
     logit = np.ascontiguousarray(logit, dtype=np.float32)
     O, H, W = logit.shape

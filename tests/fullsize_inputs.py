@@ -1,0 +1,63 @@
+"""Deterministic full-size inputs for the reference-held checks.
+
+Everything here is numpy's PCG64 stream plus the oracle's C (expmap, HyperMLR, bilinear), so the build container
+-- where the reference's own FloatingRegionScore / select_pixels_to_label can be imported and run on the result
+(tests/golden/make_fixtures.py, tests/test_reference_fullsize.py, tools/flip_rate.py) -- and the GPU box -- where
+only the committed pick tables travel (tests/golden/fullsize_picks.npz) -- build the same arrays bit for bit;
+`digest` says so in the fixture.  Shapes and distributions follow SURVEY 8(d): low-res latent z ~ N(0, 0.1^2) at
+(C, H/4, W/4), embed = expmap0 + project, logit = HyperMLR(embed) with P, A ~ U(-1/sqrt C, 1/sqrt C) (kaiming
+uniform, a = sqrt 5), both upsampled x4 with align_corners=True (core/active/build.py:122-135).
+Modifiers (bench.py --data): saturated, peaked, late_round.
+"""
+import hashlib
+import math
+
+import numpy as np
+
+BRANCHES = {   # name -> (unc_type, pur_type, normalize, mask radius, K): bench.py BRANCHES / make_fixtures.COMBOS
+    "halo": ("entropy", "radius", True, 5, 100),      # configs/gtav/source_target.yaml:20-27
+    "ripu": ("entropy", "ripu", False, 3, 100),       # configs/gtav/ripu.yaml:23-29
+    "hyper": ("entropy", "hyper", True, 5, 100),      # core/configs/defaults.py:66-79
+}
+
+
+def n_regions(H, W, budget=0.05, rounds=5, radius_k=1):
+    """core/active/build.py:148-150"""
+    return math.ceil(H * W * (budget / rounds) / (2 * radius_k + 1) ** 2)
+
+
+def build(seed, C=64, O=19, H=1024, W=2048, mods=(), f32_embed=False, lowres_only=False):
+    import oracle.halo_oracle as ho
+    rng = np.random.default_rng(seed)
+    h, w = H // 4, W // 4
+    z = rng.standard_normal((1, C, h, w), dtype=np.float32) * np.float32(0.1)
+    if "saturated" in mods:
+        z[..., w // 2:] *= np.float32(40.0)
+    prng = np.random.default_rng(7)
+    b = 1.0 / math.sqrt(C)
+    P = prng.uniform(-b, b, (O, C))
+    A = prng.uniform(-b, b, (O, C))
+    embed_lr = ho.expmap(z, dim=1)
+    logit_lr = ho.hypermlr(embed_lr, P, A).astype(np.float32)
+    if "peaked" in mods:
+        logit_lr *= np.float32(30.0)
+    gt = rng.integers(0, O, (H, W), dtype=np.int64)
+    gt[rng.random((H, W)) < 0.05] = 255
+    prior = np.zeros((H, W), bool)
+    if "late_round" in mods:
+        blocks = np.random.default_rng(99991 + seed).random(((H + 10) // 11, (W + 10) // 11)) < 0.5
+        prior = np.repeat(np.repeat(blocks, 11, 0), 11, 1)[:H, :W].copy()
+    out = dict(embed_lr=embed_lr, logit_lr=logit_lr, gt=gt, prior=prior, P=P, A=A)
+    if not lowres_only:
+        out["logit"] = ho.bilinear(logit_lr, (H, W))
+        emb = ho.bilinear(embed_lr, (H, W))
+        out["embed"] = emb.astype(np.float32) if f32_embed else emb
+    return out
+
+
+def digest(inp):
+    """sha256 over the bits of the arrays the scorer reads (first 16 hex digits)."""
+    hsh = hashlib.sha256()
+    for k in ("logit_lr", "embed_lr", "gt", "prior"):
+        hsh.update(np.ascontiguousarray(inp[k]).tobytes())
+    return hsh.hexdigest()[:16]

@@ -479,6 +479,106 @@ def gen_padding(cfg, hyp, fr, ab):
     np.savez_compressed(os.path.join(OUT_DIR, "padding.npz"), **out)
 
 
+# ---- reference-held vectors at sizes where ATen's CPU kernels take their production paths ----
+sys.path.insert(0, os.path.dirname(HERE))          # tests/fullsize_inputs.py: numpy + oracle C only, travels to the GPU box
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))      # the repository root: oracle/
+SAMPLE_STRIDE = 1031                                # the maps are sampled at every 1031st pixel (prime): 2035 values per map
+
+# tag -> (seed, C, branch, modifiers, float32 embedding); 1024 x 2048, 19 classes, 2331 regions (core/active/build.py:148-150)
+FULLSIZE = {
+    "halo_c256_s1234": (1234, 256, "halo", (), False),                               # the bench's image 0 shape (BASELINE configs[1])
+    "halo_c64_late_sat_peak_s3": (3, 64, "halo", ("late_round", "saturated", "peaked"), False),
+    "ripu_s2": (2, 64, "ripu", (), False),
+    "hyper_s1": (1, 64, "hyper", (), False),                                       # the reference's DEFAULT purity (defaults.py:69)
+    "hyper_late_s6": (6, 64, "hyper", ("late_round",), False),
+}
+
+
+def run_reference_fullsize(fr, ab, inp, branch, O=19, n=None):
+    """The reference's FloatingRegionScore.forward + select_pixels_to_label on numpy inputs (tests/fullsize_inputs.build).
+    The pick table is read off the reference's own score map by the oracle's selector (the reference keeps no table,
+    build.py:37-62) and CHECKED against the masks the reference's select_pixels_to_label left behind."""
+    import fullsize_inputs as fi
+    import oracle.halo_oracle as ho
+    unc, pur, norm, mrad, K = fi.BRANCHES[branch]
+    logit, embed, gt = torch.from_numpy(inp["logit"]), torch.from_numpy(inp["embed"]), torch.from_numpy(inp["gt"])
+    H, W = gt.shape
+    n = fi.n_regions(H, W) if n is None else n
+    frs = fr.FloatingRegionScore(in_channels=O, size=3, purity_type=pur, K=K)
+    with torch.no_grad():
+        score, imp, uncm = frs(logit.clone(), decoder_out=embed, unc_type=unc, pur_type=pur, normalize=norm, ground_truth=gt.clone())
+    active = torch.from_numpy(inp["prior"].copy())
+    selected = torch.zeros(H, W, dtype=torch.bool)
+    amask = torch.full((H, W), 255, dtype=torch.int64)
+    score = score.clone()
+    score[active] = -float("inf")                                                   # build.py:146
+    s0 = score.numpy().copy()
+    ab.select_pixels_to_label(score, n, 1, mrad, active, selected, amask, gt)        # build.py:151-160
+    a2, s2, m2 = inp["prior"].copy(), np.zeros((H, W), bool), np.full((H, W), 255, np.int64)
+    _, _, _, _, picks = ho.select_pixels_to_label(s0.copy(), n, 1, mrad, a2, s2, m2, inp["gt"], return_picks=True)
+    assert np.array_equal(a2, active.numpy()) and np.array_equal(s2, selected.numpy()) and np.array_equal(m2, amask.numpy()), \
+        "the replayed table does not reproduce the reference's masks"
+    return dict(score=s0, impurity=imp.numpy(), uncertainty=uncm.numpy(), active=a2, selected=s2, active_mask=m2, picks=picks)
+
+
+def mask_digest(res):
+    import hashlib
+    hsh = hashlib.sha256()
+    for k in ("active", "selected", "active_mask"):
+        hsh.update(np.ascontiguousarray(res[k]).tobytes())
+    return np.frombuffer(hsh.digest(), dtype=np.uint8).copy()
+
+
+def gen_fullsize(cfg, fr, ab):
+    """Pick tables + sampled maps of the reference at 1024 x 2048 (what VERDICT r5 calls reference-held golden at BASELINE size)."""
+    import fullsize_inputs as fi
+    cfg.MODEL.NUM_CLASSES = 19
+    out = {}
+    for tag, (seed, C, branch, mods, f32) in FULLSIZE.items():
+        inp = fi.build(seed, C=C, mods=mods, f32_embed=f32)
+        res = run_reference_fullsize(fr, ab, inp, branch)
+        out[f"{tag}__digest"] = np.frombuffer(fi.digest(inp).encode(), dtype=np.uint8).copy()
+        out[f"{tag}__picks"] = res["picks"]
+        out[f"{tag}__mask_digest"] = mask_digest(res)
+        out[f"{tag}__n_selected"] = np.array([int(res["selected"].sum()), int(res["active"].sum())], dtype=np.int64)
+        for k in ("score", "impurity", "uncertainty"):
+            out[f"{tag}__{k}_sample"] = res[k].ravel()[::SAMPLE_STRIDE].copy()
+        print(f"  fullsize/{tag}: picks {len(res['picks'])}, selected px {int(res['selected'].sum())}, score {res['score'].dtype}")
+    np.savez_compressed(os.path.join(OUT_DIR, "fullsize_picks.npz"), **out)
+
+
+def gen_mid(cfg, hyp, fr, ab):
+    """A case ABOVE 20480 pixels (112 x 192), where the reference's 3 x 3 box convolution runs in oneDNN like at every production
+    size (aten/src/ATen/native/Convolution.cpp:use_mkldnn; the cases A-D take the im2col + MKL sgemm path, whose summation order is
+    MKL's): low-res inputs (the x4 resize is regenerated by the consumer and checked through `logit_digest`) and the three maps."""
+    import hashlib
+    H, W, C, O = 112, 192, 8, 19
+    cfg.MODEL.NUM_CLASSES = O
+    inp = make_inputs(hyp, H, W, C, O, 55)
+    out = {k: inp[k].numpy() for k in ("logit_lr", "embed_lr", "gt", "prior_active")}
+    out["meta_HWCO"] = np.array([H, W, C, O], dtype=np.int64)
+    hsh = hashlib.sha256()
+    hsh.update(inp["logit"].numpy().tobytes())
+    hsh.update(inp["embed"].numpy().tobytes())
+    out["resized_digest"] = np.frombuffer(hsh.digest(), dtype=np.uint8).copy()
+    for tag, unc, pur, norm, mrad, K in [c for c in COMBOS if c[0] in ("halo", "ripu", "hyper")]:
+        frs = fr.FloatingRegionScore(in_channels=O, size=3, purity_type=pur, K=K)
+        with torch.no_grad():
+            score, imp, uncm = frs(inp["logit"].clone(), decoder_out=inp["embed"].clone(), unc_type=unc, pur_type=pur, normalize=norm,
+                                   ground_truth=inp["gt"].clone())
+        out[f"{tag}__score"], out[f"{tag}__impurity"], out[f"{tag}__uncertainty"] = score.numpy().copy(), imp.numpy().copy(), uncm.numpy().copy()
+        active = inp["prior_active"].clone()
+        selected = torch.zeros(H, W, dtype=torch.bool)
+        active_mask = torch.full((H, W), 255, dtype=torch.int64)
+        s = score.clone()
+        s[active] = -float("inf")
+        picks, gap = run_selection(ab, s, 40, 1, mrad, active, selected, active_mask, inp["gt"])
+        out[f"{tag}__picks"] = picks
+        out[f"{tag}__params"] = np.array([mrad, K, int(norm)], dtype=np.int64)
+        print(f"  mid/{tag}: picks {len(picks)} min_rel_gap {gap:.3e}")
+    np.savez_compressed(os.path.join(OUT_DIR, "mid_112x192_c8_o19.npz"), **out)
+
+
 def main():
     torch.set_num_threads(4)
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -496,6 +596,12 @@ def main():
         return
     if only == "padding":
         gen_padding(cfg, hyp, fr, ab)
+        return
+    if only == "fullsize":
+        gen_fullsize(cfg, fr, ab)
+        return
+    if only == "mid":
+        gen_mid(cfg, hyp, fr, ab)
         return
     print("case A 32x64 C8 O19 (selection runs to exhaustion)")
     gen_case(cfg, hyp, fr, ab, "case_a_32x64_c8_o19", 32, 64, 8, 19, 11, 200, COMBOS)
@@ -519,6 +625,10 @@ def main():
     gen_region_selection(cfg, hyp, fr, ab)
     print("padding modes of the two box windows")
     gen_padding(cfg, hyp, fr, ab)
+    print("mid 112x192 C8 O19 (above ATen's 20480-pixel switch to oneDNN)")
+    gen_mid(cfg, hyp, fr, ab)
+    print("reference pick tables at 1024 x 2048")
+    gen_fullsize(cfg, fr, ab)
 
 
 if __name__ == "__main__":
