@@ -4,7 +4,7 @@ import threading
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lock = threading.Lock()
 _handle = None
 

@@ -171,7 +171,8 @@ class AcquisitionParams:
 class _InFlight:
     """One loader batch (b images of one label size, b = 1 in the reference) whose staging, scoring, selection and device->host
     copies have been enqueued on a side stream."""
-    __slots__ = ("done", "keep", "picks", "npk", "slot", "buf", "b", "left", "lock", "table", "radius", "compose", "mask_radius", "write")
+    __slots__ = ("done", "keep", "picks", "npk", "slot", "buf", "b", "left", "lock", "table", "radius", "compose", "mask_radius", "write",
+                 "out_picks")
 
 
 class _SlotBuffers:
@@ -191,16 +192,16 @@ class _SlotBuffers:
         self.out_active = torch.empty(shp, dtype=torch.bool, pin_memory=True)
         self.out_selected = torch.empty(shp, dtype=torch.bool, pin_memory=True)
         self.out_npk = torch.empty((b,), dtype=torch.int32, pin_memory=True)
-        self.out_picks = None
         self.out_picks_by_n = {}
 
     def picks_out(self, n):
         """pinned (b, n, 3) float64 for the round's pick tables (one buffer per table width, never re-allocated: a recorded launch
-        group copies into it)"""
+        group copies into it).  The batch in flight remembers WHICH one it wrote (`rec.out_picks`): one slot shape can serve
+        several table widths (another ACTIVE.BUDGET or RADIUS_K in the same process), and a replayed recording fills the buffer
+        of the width it was recorded with."""
         got = self.out_picks_by_n.get(int(n))
         if got is None:
             got = self.out_picks_by_n[int(n)] = torch.empty((self.shape[0], int(n), 3), dtype=torch.float64, pin_memory=True)
-        self.out_picks = got
         return got
 
 
@@ -230,7 +231,7 @@ class _SlotGraph:
     `score[active] = -inf` -> selection -> device-to-host copies of the pick table, reading STATIC device copies of the head's
     outputs and writing the slot's pinned buffers.  A batch then costs the launching thread three copies into the static inputs, one
     replay and one event record instead of ~25 launches through Python and ctypes (0.24-0.35 ms per image, VERDICT r4 #9)."""
-    __slots__ = ("graph", "logits", "embed", "picks", "npk", "scratch")
+    __slots__ = ("graph", "logits", "embed", "picks", "npk", "scratch", "out_picks")
 
 
 _SIDE = {}
@@ -282,6 +283,7 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
     Same files either way (tests/test_gpu_parity.py runs both against the reference's PNGs)."""
     import time
     rec = _InFlight()
+    rec.out_picks = None
     rec.slot, rec.b = slot, int(origin_mask.shape[0])
     H, W = int(origin_mask.shape[-2]), int(origin_mask.shape[-1])
     buf = rec.buf = slot.buffers(rec.b, H, W, dev)
@@ -310,7 +312,8 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
                              mask_radius=prm.mask_radius, ksize=prm.scorer.size, purity_size=prm.scorer.purity_size,
                              K=prm.K, c=prm.scorer.mapper.c, lowres_mode=lowres_mode)
         if rec.table:
-            buf.picks_out(picks.shape[1]).copy_(picks, non_blocking=True)
+            rec.out_picks = buf.picks_out(picks.shape[1])
+            rec.out_picks.copy_(picks, non_blocking=True)
         else:
             # uint8 on the device first: 2 MB instead of 16 MB over PCIe per 1024x2048 mask (same values as the
             # reference's cast-after-copy, build.py:67-68,162)
@@ -336,7 +339,7 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
             sg.embed.copy_(embed_lr, non_blocking=True)
             buf.d_active.copy_(active_in, non_blocking=True)
             sg.graph.replay()
-            rec.picks, rec.npk = sg.picks, sg.npk
+            rec.picks, rec.npk, rec.out_picks = sg.picks, sg.npk, sg.out_picks
         else:
             if not rec.table:
                 buf.d_amask.copy_(origin_mask, non_blocking=True)
@@ -362,6 +365,7 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
                         from .floating_region import private_workspaces
                         with private_workspaces() as pw, torch.cuda.graph(g_.graph, stream=stream, capture_error_mode="thread_local"):
                             g_.picks, g_.npk = body(g_.logits, g_.embed)
+                        g_.out_picks = rec.out_picks              # the pinned table the recording copies into
                         g_.scratch = pw.held                      # the recording owns the scratch buffers it points to
                         slot.graphs[gkey] = g_
                     except Exception as exc:                      # capture refused (driver / torch build): stay eager, say so once
@@ -627,12 +631,12 @@ def _finish_image(rec, i, paths, slots, stats=None):
         buf = rec.buf
         k = int(buf.out_npk[i])
         if not rec.write:                                        # global-budget rounds: the files follow once the pool's keep-mask is known
-            return (torch.from_numpy(buf.out_picks[i].numpy().copy()) if rec.table else rec.picks[i], k)
+            return (torch.from_numpy(rec.out_picks[i].numpy().copy()) if rec.table else rec.picks[i], k)
         if rec.compose:
             # everything the files need is host data: the image's 56 KB pick table leaves the slot's pinned buffer FIRST and the slot goes
             # back to the launching thread; the 2-3 ms of composing, encoding and writing then hold no pipeline resource (round 5: with
             # the slot held until the files were written, 8 slots / 2.7 ms bounded the round at 0.34 ms per image whatever else improved)
-            table = buf.out_picks[i].numpy().copy()
+            table = rec.out_picks[i].numpy().copy()
             keep = rec.keep
             release()
             persist_image(paths[0], paths[1], keep[2][i], keep[3][i], keep[4][i], keep[5][i], table, k, rec.radius, rec.mask_radius)
@@ -644,13 +648,8 @@ def _finish_image(rec, i, paths, slots, stats=None):
         is_png = bool(buf.out_mask[i].numel()) and str(paths[0]).lower().endswith(".png")
         mask = active = selected = None
         retire = _native_retire() if (rec.table and is_png) else None
-        # the indicator maps: the device's results in the pinned buffers, or -- composed on the host -- the loader's own maps
-        if rec.compose:
-            ind_a, ind_s, cmr = rec.keep[4][i].numpy(), rec.keep[5][i].numpy(), rec.mask_radius
-            if retire is not None and not (ind_a.flags["C_CONTIGUOUS"] and ind_s.flags["C_CONTIGUOUS"] and ind_a.itemsize == 1 and ind_s.itemsize == 1):
-                retire = None
-        else:
-            ind_a, ind_s, cmr = buf.out_active[i].numpy(), buf.out_selected[i].numpy(), -1
+        # the indicator maps: the device's results in the pinned buffers (host-composed batches returned above)
+        ind_a, ind_s = buf.out_active[i].numpy(), buf.out_selected[i].numpy()
         if retire is not None:
             # mask_staging="table": ONE call without the interpreter lock composes the mask from the loader's maps and the pick
             # table, encodes it, and writes the indicator from the pinned maps through the shape's template
@@ -658,18 +657,15 @@ def _finish_image(rec, i, paths, slots, stats=None):
             if om.flags["C_CONTIGUOUS"] and gt.flags["C_CONTIGUOUS"] and om.dtype.kind in "iub" and gt.dtype.kind in "iub" \
                     and om.ctypes.data % om.dtype.itemsize == 0 and gt.ctypes.data % gt.dtype.itemsize == 0:      # (naturally aligned elements)
                 tpl = _IndicatorTemplate.get(om.shape)
-                retire(paths[0], paths[1], om, gt, buf.out_picks[i].numpy(), k, rec.radius, ind_a, ind_s, tpl if tpl.ok else None,
-                       compose_mask_radius=cmr)
+                retire(paths[0], paths[1], om, gt, rec.out_picks[i].numpy(), k, rec.radius, ind_a, ind_s, tpl if tpl.ok else None,
+                       compose_mask_radius=-1)
                 native = True
                 if not tpl.ok:
-                    if rec.compose:
-                        active, selected = (torch.from_numpy(x) for x in compose_indicators(ind_a, ind_s, buf.out_picks[i, :k].numpy(), rec.radius, cmr))
-                    else:
-                        active, selected = torch.from_numpy(ind_a.copy()), torch.from_numpy(ind_s.copy())
+                    active, selected = torch.from_numpy(ind_a.copy()), torch.from_numpy(ind_s.copy())
                 t_png = time.perf_counter() - t1
         if not native:
             if rec.table:
-                table = buf.out_picks[i, :k].numpy().copy()
+                table = rec.out_picks[i, :k].numpy().copy()
                 origin_mask, origin_label = rec.keep[2][i].numpy(), rec.keep[3][i].numpy()
             elif is_png:
                 # the PNG encoder makes ONE pass over the mask: it reads the pinned buffer directly
@@ -680,13 +676,10 @@ def _finish_image(rec, i, paths, slots, stats=None):
             t_png = t2 - t1
             # the indicator must hold plain tensors as from `.cpu()`: one streaming copy each (numpy on purpose: a torch CPU op
             # here would wake an intra-op thread pool as wide as the host)
-            if rec.compose:
-                active, selected = (torch.from_numpy(x) for x in compose_indicators(ind_a, ind_s, table, rec.radius, cmr))
-            else:
-                active, selected = torch.from_numpy(ind_a.copy()), torch.from_numpy(ind_s.copy())
+            active, selected = torch.from_numpy(ind_a.copy()), torch.from_numpy(ind_s.copy())
             t_copy = time.perf_counter() - t2
         # the table handed back (return_tables): a copy of the pinned rows where the device tensor belongs to a replayed graph
-        out = (torch.from_numpy(buf.out_picks[i].numpy().copy()) if rec.table else rec.picks[i], k)
+        out = (torch.from_numpy(rec.out_picks[i].numpy().copy()) if rec.table else rec.picks[i], k)
     finally:
         release()
     t3 = time.perf_counter()
@@ -733,10 +726,12 @@ def persist_image(path_mask, path_indicator, origin_mask, origin_label, prior_ac
     _persist(compose_mask(om, gt, pk, active_radius), torch.from_numpy(act), torch.from_numpy(sel), path_mask, path_indicator)
 
 
-def persist_from_tables(cfg, loader, tables, counts, writer_threads=None):
+def persist_from_tables(cfg, loader, tables, counts, writer_threads=None, expect_paths=None):
     """Write the round's files for every image of `loader` (in loader order) from pick tables: image j gets the windows of the first
     counts[j] rows of tables[j] (rows (h, w, score), as RegionSelection(return_tables=True) / the all-gather deliver them).  Used by
-    the global-budget mode of halo_amd.pool.region_selection_sharded, where counts = the KEPT picks per image.  Host only."""
+    the global-budget mode of halo_amd.pool.region_selection_sharded, where counts = the KEPT picks per image.  Host only.
+    `expect_paths`: the `path_to_mask` sequence of the pass that computed the tables; a loader that yields another order (a shuffling
+    sampler, a dataset that changed in between) is refused before the first mismatched file is written."""
     from concurrent.futures import ThreadPoolExecutor
     if writer_threads is None:
         from ..._host import host_threads_per_rank
@@ -748,6 +743,10 @@ def persist_from_tables(cfg, loader, tables, counts, writer_threads=None):
     with ThreadPoolExecutor(max_workers=max(1, writer_threads)) as writers:
         for batch in loader:
             for i in range(len(batch["origin_mask"])):
+                if expect_paths is not None and (j >= len(expect_paths) or str(batch["path_to_mask"][i]) != expect_paths[j]):
+                    raise RuntimeError("persist_from_tables: image %d of the loader is %r, the tables were computed for %r -- the loader "
+                                       "must yield the same order in both passes" % (j, batch["path_to_mask"][i],
+                                                                                      expect_paths[j] if j < len(expect_paths) else None))
                 pending.append(writers.submit(persist_image, batch["path_to_mask"][i], batch["path_to_indicator"][i], batch["origin_mask"][i],
                                               batch["origin_label"][i], batch["active"][i], batch["selected"][i], tables[j], counts[j],
                                               radius, mask_radius))

@@ -19,6 +19,7 @@
  * numpy / zlib / torch.save spend ~1 ms per image holding the GIL (torch.save's record writes), which bounded RegionSelection
  * at ~1 ms per image whatever else was improved (profiles/r04_region_selection_timing.txt).
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -330,15 +331,29 @@ int halo_png_gray8_write(const char *path, const uint8_t *img, int64_t H, int64_
  * per image and thread with 4-8 threads in the build container; the pieces themselves add up to 3 ms). */
 static __thread uint8_t *tl_scratch[2];
 static __thread size_t tl_cap[2];
+/* The blocks go back when the thread exits (RegionSelection's writer pool lives for one call: ~8 MB per writer thread and call
+ * stayed allocated before -- ADVICE r5): a process-wide pthread key whose destructor frees the exiting thread's two blocks. */
+static pthread_key_t tl_key;
+static pthread_once_t tl_key_once = PTHREAD_ONCE_INIT;
+static void thread_scratch_free(void *arg)
+{
+    (void)arg;
+    for (int i = 0; i < 2; ++i) { free(tl_scratch[i]); tl_scratch[i] = 0; tl_cap[i] = 0; }
+}
+static void thread_scratch_key(void) { pthread_key_create(&tl_key, thread_scratch_free); }
 static uint8_t *thread_scratch(int which, size_t n)
 {
     if (tl_cap[which] < n) {
+        pthread_once(&tl_key_once, thread_scratch_key);
+        pthread_setspecific(tl_key, (void *)1);                 /* non-NULL: the destructor runs for this thread */
         free(tl_scratch[which]);
         tl_scratch[which] = (uint8_t *)malloc(n);
         tl_cap[which] = tl_scratch[which] ? n : 0;
     }
     return tl_scratch[which];
 }
+/* frees the calling thread's scratch now (long-lived threads that are done writing) */
+void halo_host_thread_release(void) { thread_scratch_free(0); }
 
 /* ---- one image's files from host data, the pick table and the device's indicator maps ---- */
 static inline uint8_t low_byte_at(const void *src, int itemsize, size_t i)

@@ -16,7 +16,10 @@ rank 0 only.  Bind it with `use_sharded_rounds(SourceFreeLearner)` (or assign th
 learner class with the same attributes); nothing else in the learner changes.  Optional attributes
 of the learner: `acquisition_group` (process group), `acquisition_driver` (test stand-in) and
 `acquisition_global_budget` (None = reference behaviour; an integer G switches the round to the
-pool-wide budget of halo_amd.pool.region_selection_sharded).  No Lightning import
+pool-wide budget of halo_amd.pool.region_selection_sharded).  Contract of a custom `acquisition_driver`:
+`driver(cfg, feature_extractor, classifier, loader, round_number) -> [(picks (n, 3), count)]` in loader
+order; with a global budget it is additionally passed the keyword `write_files=False` and must then write
+NO file (the files follow from the kept picks) -- a driver without that keyword is refused.  No Lightning import
 is needed here: the method only touches attributes the reference's learner already has.
 """
 import os

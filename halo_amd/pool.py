@@ -251,7 +251,11 @@ def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_load
     (core.active.build.persist_from_tables).  Files and tables are independent of the world size.
 
     `driver(cfg, feature_extractor, classifier, loader, round_number) -> [(picks (n,3), count)]` per
-    image defaults to the HIP RegionSelection; the CPU tests inject a stand-in.  `n_regions` = the
+    image defaults to the HIP RegionSelection; the CPU tests inject a stand-in.  Under `global_budget` the
+    driver is called with one more KEYWORD, `write_files=False`, and must then score and select WITHOUT
+    writing any file (a driver that cannot take the keyword is refused with a TypeError before any work
+    is done); the second pass checks that the loader yields the same `path_to_mask` sequence as the
+    first, so that every table meets the image it was computed for.  `n_regions` = the
     table width (regions per image, build.py:148-150); when None the ranks agree on the widest table
     with one scalar all-reduce first (pools of mixed image sizes)."""
     from torch.utils.data import DataLoader, Subset
@@ -268,6 +272,20 @@ def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_load
         def driver(*a, **kw):
             return RegionSelection(*a, return_tables=True, **kw)
     defer = global_budget is not None
+    seen_paths = None
+    if defer:
+        import inspect
+        try:
+            params = inspect.signature(driver).parameters
+            takes = "write_files" in params or any(p_.kind is inspect.Parameter.VAR_KEYWORD for p_ in params.values())
+        except (TypeError, ValueError):
+            takes = True                                      # builtins without a signature: let the call decide
+        if not takes:
+            raise TypeError("region_selection_sharded(global_budget=...) calls the acquisition driver with write_files=False "
+                            "(score and select only; the files follow from the pool-wide keep-mask): %r does not accept that "
+                            "keyword" % (driver,))
+        seen_paths = []
+        loader = _RecordingLoader(loader, seen_paths)
     # pipelined, async writers; under a global budget the files wait for the pool-wide keep-mask
     per_image = driver(cfg, feature_extractor, classifier, loader, round_number, **({"write_files": False} if defer else {}))
     assert len(per_image) == hi - lo
@@ -291,10 +309,31 @@ def region_selection_sharded(cfg, feature_extractor, classifier, dataset_or_load
         keep = global_budget_select(tables, counts, global_budget)
         kept = kept_counts(keep)
         from .core.active.build import persist_from_tables
-        persist_from_tables(cfg, loader, tables[lo:hi], kept[lo:hi], writer_threads=writer_threads)
+        persist_from_tables(cfg, loader.loader, tables[lo:hi], kept[lo:hi], writer_threads=writer_threads, expect_paths=seen_paths)
         if world > 1:
             dist.barrier(group=group)                                    # every rank's files are on disk when anyone returns
     return {"range": (lo, hi), "tables": tables, "counts": counts, "owner": owner, "keep": keep, "kept": kept}
+
+
+class _RecordingLoader:
+    """The rank's loader, noting the `path_to_mask` of every image it hands to the first (scoring) pass of a global-budget round."""
+
+    def __init__(self, loader, seen):
+        self.loader, self.seen = loader, seen
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):
+        return getattr(self.loader, name)
+
+    def __iter__(self):
+        for batch in self.loader:
+            try:
+                self.seen.extend(str(p_) for p_ in batch["path_to_mask"])
+            except (KeyError, TypeError):
+                pass
+            yield batch
 
 
 def _comm_device(per_image):

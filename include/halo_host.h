@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HALO_HOST_ABI_VERSION 3
+#define HALO_HOST_ABI_VERSION 4
 int halo_host_version(void);
 
 /* ---- 8-bit greyscale PNG (build.py:162-164).  What must be identical to PIL's file is the DECODED image: filter type 0 on every
@@ -65,6 +65,10 @@ int halo_retire_image(const char *path_png, const char *path_indicator, const vo
                       const void *origin_label, int label_itemsize, int64_t H, int64_t W, const double *picks, int64_t k, int64_t radius,
                       const uint8_t *active, const uint8_t *selected, int64_t compose_mask_radius, const uint8_t *tpl, size_t tpl_len,
                       size_t off_a, size_t off_s, const uint64_t *crc_fields_a, const uint64_t *crc_fields_s);
+
+/* The writer functions keep ~8 MB of scratch per calling thread between calls; it is freed when the thread exits, or now by this
+ * call (long-lived writer threads that are done for the round). */
+void halo_host_thread_release(void);
 
 #ifdef __cplusplus
 }

@@ -2725,6 +2725,47 @@ def test_region_selection_replayed_launch_groups_survive_workspace_growth(dev):
     check("s", small[2])
 
 
+def test_region_selection_two_table_widths_through_one_slot_shape(dev):
+    """One slot shape (b, H, W) served with TWO pick-table widths in one process (another ACTIVE.BUDGET): the replayed recording of
+    the first width copies into ITS pinned table; the writer must read that one and not the buffer the other width's eager launch
+    touched last (`buf.out_picks` was a mutable slot attribute the replay never updated -> silently wrong files).
+    Alternates the two budgets over seven calls, so that both widths go eager -> recorded -> replayed and interleave."""
+    from PIL import Image
+    from halo_amd.core.active.build import RegionSelection
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(977)
+    tmp = tempfile.mkdtemp(prefix="halo_rs_widths_")
+    H, W, n = 48, 96, 4
+
+    def cfg_for(budget):
+        return types.SimpleNamespace(
+            MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+            ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                         BUDGET=budget, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+    items, outs, oin = [], [], []
+    for i in range(n):
+        emb_lr = ho.expmap((rng.standard_normal((1, 8, H // 4, W // 4)) * 0.2).astype(np.float32), 1.0, dim=1)
+        logit_lr = rng.standard_normal((1, 19, H // 2, W // 2)).astype(np.float32)
+        gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+        act = rng.random((H, W)) < 0.02
+        items.append({"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [os.path.join(tmp, f"m{i}.png")],
+                      "origin_mask": torch.full((1, H, W), 255, dtype=torch.int64), "origin_label": torch.from_numpy(gt)[None],
+                      "size": torch.tensor([[H, W]]), "active": torch.from_numpy(act)[None], "selected": torch.zeros(1, H, W, dtype=torch.bool),
+                      "path_to_indicator": [os.path.join(tmp, f"i{i}.pth")], "name": [f"w{i}"]})
+        outs.append((t(logit_lr, dev), t(emb_lr, dev)))
+        oin.append(dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act, selected=np.zeros((H, W), bool),
+                        origin_mask=np.full((H, W), 255, np.int64)))
+    want = {b: ho.region_selection(cfg_for(b), oin, lowres_mode=_lr_mode()) for b in (0.05, 0.15)}
+    assert len(want[0.05][0][3]) != len(want[0.15][0][3])                 # two table widths indeed
+    for call, budget in enumerate((0.05, 0.15, 0.05, 0.15, 0.05, 0.15, 0.05)):
+        RegionSelection(cfg_for(budget), _Fake(), _Fake(outs), items, 1, in_flight=1, writer_threads=2)
+        for i, (mask, act, sel, _) in enumerate(want[budget]):
+            assert np.array_equal(np.array(Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8), mask), (call, budget, i)
+            ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+            assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), (call, budget, i)
+            os.remove(os.path.join(tmp, f"m{i}.png")); os.remove(os.path.join(tmp, f"i{i}.pth"))
+
+
 def test_more_handed_over_images_than_resume_workgroups(dev):
     """The serial kernel behind the sweep runs one workgroup per image up to 64; 70 maps that ALL hand over (NaN, constant maps) make its workgroups walk more than one image each."""
     from halo_amd.core.active.build import greedy_select

@@ -404,3 +404,30 @@ def test_sharded_hook_replaces_the_rank0_gate(tmp_path):
     ln.active_iters = [9]
     ln.on_train_batch_start("batch", 9)
     assert int(ln.last_round_tables["kept"].sum()) == 7 and ln.active_round == 2
+
+
+def test_global_budget_refuses_a_driver_without_write_files_and_a_reordering_loader(tmp_path):
+    """The driver contract of the global-budget round: a custom driver that cannot take `write_files=False` would write
+    the UNBUDGETED files -- it is refused before any work; and the second, file-writing pass must see the images in the order the
+    tables were computed in -- a loader that yields another order is refused before a mismatched file is written."""
+    from halo_amd.core.active.build import persist_from_tables
+    from halo_amd.pool import region_selection_sharded
+
+    def old_contract_driver(cfg, feature_extractor, classifier, loader, round_number):
+        raise AssertionError("must not be called")
+
+    with pytest.raises(TypeError, match="write_files"):
+        region_selection_sharded(_cfg(), None, None, _Pool(str(tmp_path), 3), 1, driver=old_contract_driver,
+                                 loader_kwargs=dict(pin_memory=False), global_budget=4)
+    # without a global budget the five-argument contract stays valid
+    res = region_selection_sharded(_cfg(), None, None, _Pool(str(tmp_path), 3), 1,
+                                   driver=lambda c, f, k, loader, r: _oracle_driver(c, f, k, loader, r), loader_kwargs=dict(pin_memory=False))
+    assert res["keep"] is None and res["tables"].shape[0] == 3
+    # the order check of the second pass
+    from torch.utils.data import DataLoader
+    pool = _Pool(str(tmp_path), 3)
+    loader = DataLoader(pool, batch_size=1, shuffle=False)
+    paths = [b["path_to_mask"][0] for b in loader]
+    with pytest.raises(RuntimeError, match="same order"):
+        persist_from_tables(_cfg(), loader, res["tables"], res["counts"], writer_threads=1, expect_paths=paths[::-1])
+    persist_from_tables(_cfg(), loader, res["tables"], res["counts"], writer_threads=1, expect_paths=paths)
