@@ -62,7 +62,7 @@ def build_host(force=False):
                 return HOST_SO
             cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc") or _hipcc()
             tmp = HOST_SO + ".tmp.%d" % os.getpid()
-            cmd = [cc, "-O3", "-std=c11", "-fPIC", "-shared", "-Wall"] + [os.path.join(CSRC, f) for f in HOST_SOURCES] + ["-o", tmp]
+            cmd = [cc, "-O3", "-std=c11", "-fPIC", "-shared", "-pthread", "-Wall"] + [os.path.join(CSRC, f) for f in HOST_SOURCES] + ["-o", tmp]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if r.returncode != 0:
                 raise RuntimeError("host library build failed:\n%s" % r.stdout)

@@ -36,7 +36,11 @@ int halo_host_version(void) { return HALO_HOST_ABI_VERSION; }
  * goes through the carry-less-multiplication folding of Gopal et al., "Fast CRC Computation for Generic Polynomials Using
  * PCLMULQDQ" (64 bytes per iteration, ~10 bytes per cycle), which tests/test_abi.py checks against zlib on random lengths. ---- */
 static uint32_t crc_table[8][256];
-static int crc_ready = 0;                           /* published with release / read with acquire: a writer thread that sees 1 sees the tables */
+/* The lazily built tables (these, the deflate code tables, the CPU feature flag) are initialised through pthread_once: up to 16
+ * writer threads enter together in the first round, and "racing initialisers store the same values" -- what rounds 3-5 relied on
+ * with a release / acquire flag -- is still a data race between one thread's stores and another's loads (ThreadSanitizer,
+ * tests/test_sanitizers.py). */
+static pthread_once_t crc_once = PTHREAD_ONCE_INIT;
 static void crc_init(void)
 {
     for (uint32_t n = 0; n < 256; ++n) {
@@ -46,12 +50,11 @@ static void crc_init(void)
     }
     for (uint32_t n = 0; n < 256; ++n)
         for (int t = 1; t < 8; ++t) crc_table[t][n] = crc_table[0][crc_table[t - 1][n] & 0xffu] ^ (crc_table[t - 1][n] >> 8);
-    __atomic_store_n(&crc_ready, 1, __ATOMIC_RELEASE);
 }
 /* raw register update (no pre/post inversion) */
 static uint32_t crc_tables_raw(uint32_t crc, const uint8_t *p, size_t n)
 {
-    if (!__atomic_load_n(&crc_ready, __ATOMIC_ACQUIRE)) crc_init();      /* idempotent: racing initialisers store the same values */
+    pthread_once(&crc_once, crc_init);
     while (n >= 8) {
         uint64_t v;
         memcpy(&v, p, 8);
@@ -116,11 +119,13 @@ __attribute__((target("pclmul,sse4.1"))) static uint32_t crc_clmul_raw(uint32_t 
     x1 = _mm_xor_si128(x1, x2);
     return (uint32_t)_mm_extract_epi32(x1, 1);
 }
+static int clmul_state;
+static pthread_once_t clmul_once = PTHREAD_ONCE_INIT;
+static void clmul_probe(void) { clmul_state = (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) ? 1 : 0; }
 static int have_clmul(void)
 {
-    static int state = -1;
-    if (state < 0) state = (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) ? 1 : 0;
-    return state;
+    pthread_once(&clmul_once, clmul_probe);
+    return clmul_state;
 }
 #endif
 static int crc_force_tables = 0;                     /* test switch: halo_crc32_mode(1) */
@@ -173,7 +178,7 @@ static uint8_t lit_len[288];
 static uint16_t len_sym[259];        /* match length 3..258 -> length symbol */
 static uint8_t len_xbits[259];
 static uint16_t len_xval[259];
-static int huff_ready = 0;
+static pthread_once_t huff_once = PTHREAD_ONCE_INIT;
 static void huff_init(void)
 {
     for (int s = 0; s < 288; ++s) {
@@ -195,7 +200,6 @@ static void huff_init(void)
         len_xbits[L] = (uint8_t)xb[k];
         len_xval[L] = (uint16_t)(L - base[k]);
     }
-    __atomic_store_n(&huff_ready, 1, __ATOMIC_RELEASE);
 }
 static inline void put_literal(bitw_t *w, unsigned v) { bw_put(w, lit_code[v], lit_len[v]); }
 static inline void put_match_d1(bitw_t *w, int L)              /* L bytes repeating the previous byte */
@@ -245,7 +249,7 @@ size_t halo_png_gray8_encode(const uint8_t *img, int64_t H, int64_t W, int64_t r
 {
     if (!img || !out || H <= 0 || W <= 0 || row_stride < W || H > 0x7fffffff || W > 0x7fffffff) return 0;
     if (cap < halo_png_gray8_bound(H, W)) return 0;
-    if (!__atomic_load_n(&huff_ready, __ATOMIC_ACQUIRE)) huff_init();
+    pthread_once(&huff_once, huff_init);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     uint8_t *p = out;
     memcpy(p, sig, 8); p += 8;

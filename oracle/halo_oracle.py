@@ -66,7 +66,7 @@ def usable_cpus():
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(os.environ.get("HALO_ORACLE_LIB") or build())      # (the variable: a sanitizer build, tests/test_sanitizers.py)
         try:
             C.CDLL("libgomp.so.1").omp_set_num_threads(usable_cpus())
         except OSError:

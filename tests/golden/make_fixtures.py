@@ -490,7 +490,6 @@ FULLSIZE = {
     "halo_c64_late_sat_peak_s3": (3, 64, "halo", ("late_round", "saturated", "peaked"), False),
     "ripu_s2": (2, 64, "ripu", (), False),
     "hyper_s1": (1, 64, "hyper", (), False),                                       # the reference's DEFAULT purity (defaults.py:69)
-    "hyper_late_s6": (6, 64, "hyper", ("late_round",), False),
 }
 
 

@@ -340,6 +340,93 @@ def test_full_size_1024x2048_c256(dev):
     assert act.sum() <= 121 * n
 
 
+def _fullsize_tags():
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_fixtures import FULLSIZE
+    return sorted(FULLSIZE)
+
+
+@pytest.mark.parametrize("tag", _fullsize_tags())
+def test_hip_reproduces_the_references_full_size_tables(dev, tag):
+    """Reference-held golden at BASELINE size: the HIP scorer + selector on the inputs the REFERENCE ran on in
+    the build container (tests/fullsize_inputs.build: numpy stream + oracle C, the digest is checked) against the reference's OWN
+    pick table, mask digest and sampled maps (tests/golden/fullsize_picks.npz) -- not against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fullsize_inputs as fi
+    from make_fixtures import FULLSIZE, SAMPLE_STRIDE, mask_digest
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps
+    d = np.load(os.path.join(GOLDEN, "fullsize_picks.npz"))
+    seed, C, branch, mods, f32 = FULLSIZE[tag]
+    unc, pur, norm, mrad, K = fi.BRANCHES[branch]
+    inp = fi.build(seed, C=C, mods=mods, f32_embed=f32)
+    assert fi.digest(inp).encode() == d[tag + "__digest"].tobytes(), "the inputs are not the ones the reference ran on"
+    H, W = inp["gt"].shape
+    n = fi.n_regions(H, W)
+    with torch.no_grad():
+        s, i, u = score_maps(t(inp["logit"], dev), t(inp["embed"], dev), unc, pur, norm, t(inp["gt"], dev)[None], size=3, K=K)
+    act = t(inp["prior"], dev)[None].clone()
+    sel = torch.zeros_like(act)
+    am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+    sc = s.clone()
+    sc[act] = -float("inf")                                                          # build.py:146
+    s0 = sc[0].cpu().numpy().copy()
+    picks, npk = greedy_select(sc, n, 1, mrad, act, sel, am, t(inp["gt"], dev)[None])
+    k = int(npk[0])
+    ref = d[tag + "__picks"]
+    got = picks[0, :k].cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, :2], ref[:, :2]), "%d of %d picks differ from the REFERENCE's" % (int((got[:, :2] != ref[:, :2]).any(axis=1).sum()), len(ref))
+    assert np.abs(got[:, 2] - ref[:, 2]).max() < 1e-4
+    res = dict(active=act[0].cpu().numpy(), selected=sel[0].cpu().numpy(), active_mask=am[0].cpu().numpy())
+    assert np.array_equal(mask_digest(res), d[tag + "__mask_digest"]), "active / selected / active_mask differ from the REFERENCE's"
+    for key, arr in (("score", s0), ("impurity", i[0].cpu().numpy()), ("uncertainty", u[0].cpu().numpy())):
+        g_, w_ = arr.ravel()[::SAMPLE_STRIDE], d[f"{tag}__{key}_sample"]
+        fin = np.isfinite(w_)
+        assert g_.dtype == w_.dtype and np.array_equal(fin, np.isfinite(g_)), key
+        assert np.abs(g_[fin].astype(np.float64) - w_[fin].astype(np.float64)).max() < 1e-4, key
+        if key == "impurity" and branch in ("ripu", "hyper"):
+            assert np.array_equal(g_, w_), "the window-histogram impurity is the reference's bit for bit"
+
+
+def test_mid_size_fixture_hip_vs_reference_bitwise_up_to_the_logarithm(dev):
+    """tests/golden/mid_112x192_c8_o19.npz (above ATen's 20480-pixel switch to oneDNN, like every production size): the HIP maps
+    against the REFERENCE's -- impurity of `ripu` / `hyper` bit for bit, box-summed entropy equal except for a handful of pixels by
+    one ulp (torch.log is MKL's closed-source vsLn; the contract's logf is the correctly rounded value), the device resize torch's
+    bit for bit, picks exact.  (tests/test_oracle_golden.py states the same for the oracle.)"""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps
+    from halo_amd.core.utils.hyperbolic import bilinear_align_corners
+    import hashlib
+    d = np.load(os.path.join(GOLDEN, "mid_112x192_c8_o19.npz"))
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    logit = bilinear_align_corners(t(d["logit_lr"], dev), (H, W))
+    embed = bilinear_align_corners(t(d["embed_lr"], dev), (H, W))
+    hsh = hashlib.sha256()
+    hsh.update(logit.cpu().numpy().tobytes())
+    hsh.update(embed.cpu().numpy().tobytes())
+    assert np.array_equal(np.frombuffer(hsh.digest(), np.uint8), d["resized_digest"]), "the device resize is not torch's CPU kernel bit for bit"
+    for tag, (unc, pur) in {"halo": ("entropy", "radius"), "ripu": ("entropy", "ripu"), "hyper": ("entropy", "hyper")}.items():
+        mrad, K, norm = (int(v) for v in d[tag + "__params"])
+        with torch.no_grad():
+            s, i, u = score_maps(logit, embed, unc, pur, bool(norm), t(d["gt"], dev)[None], size=3, K=K)
+        un, inn, sn = u[0].cpu().numpy(), i[0].cpu().numpy(), s[0].cpu().numpy()
+        nd = int((un != d[tag + "__uncertainty"]).sum())
+        assert nd <= 8 and np.abs(un - d[tag + "__uncertainty"]).max() <= 3e-7, (tag, nd)
+        if pur != "radius":
+            assert np.array_equal(inn, d[tag + "__impurity"]), tag
+            assert int((sn != d[tag + "__score"]).sum()) <= 8, tag
+        act = t(d["prior_active"], dev)[None].clone()
+        sel = torch.zeros_like(act)
+        am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+        sc = s.clone()
+        sc[act] = -float("inf")
+        picks, npk = greedy_select(sc, 40, 1, mrad, act, sel, am, t(d["gt"], dev)[None])
+        assert np.array_equal(picks[0, :int(npk[0]), :2].cpu().numpy(), d[tag + "__picks"][:, :2]), tag
+
+
 def test_batched_equals_per_image_and_is_deterministic(dev):
     from halo_amd.core.active.build import acquire_batch
     B, H, W, C, O = 3, 128, 256, 16, 19

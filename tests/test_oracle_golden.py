@@ -6,10 +6,12 @@ FloatingRegionScore.forward, two selection rounds each.
 """
 import types
 
+import os
+
 import numpy as np
 import pytest
 
-from conftest import COMBOS, all_case_combos, case_files, max_abs_diff
+from conftest import COMBOS, GOLDEN, all_case_combos, case_files, max_abs_diff
 from oracle import halo_oracle as ho
 
 TOL = 1e-4          # the contract
@@ -277,3 +279,34 @@ def test_bilinear_is_torchs_cpu_kernel_bit_for_bit(dtype, shape, threads):
         torch.set_num_threads(old)
     got = ho.bilinear(x.numpy(), (H, W))
     assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+def test_mid_size_fixture_above_atens_onednn_switch_is_matched_bitwise_up_to_the_logarithm():
+    """tests/golden/mid_112x192_c8_o19.npz (21504 pixels: above the 20480 at which ATen hands the 3 x 3 box convolution to oneDNN, like
+    every production size; the cases A-D sit below, on the im2col + MKL sgemm path whose summation order is MKL's): the oracle's x4
+    resize is torch's bit for bit (digest), the window-histogram impurity of `ripu` / `hyper` is the reference's bit for bit, and the
+    box-summed entropy differs from the reference's in at most a handful of pixels by one ulp -- the closed-source logarithm
+    (oracle/halo_oracle_math.h).  Picks and scores as everywhere."""
+    import hashlib
+    d = np.load(os.path.join(GOLDEN, "mid_112x192_c8_o19.npz"))
+    H, W, C, O = (int(v) for v in d["meta_HWCO"])
+    assert H * W > 20480
+    logit, embed = ho.bilinear(d["logit_lr"], (H, W)), ho.bilinear(d["embed_lr"], (H, W))
+    hsh = hashlib.sha256()
+    hsh.update(logit.tobytes())
+    hsh.update(embed.tobytes())
+    assert np.array_equal(np.frombuffer(hsh.digest(), np.uint8), d["resized_digest"]), "the oracle's resize is not torch's bit for bit"
+    for tag, (unc, pur) in {"halo": ("entropy", "radius"), "ripu": ("entropy", "ripu"), "hyper": ("entropy", "hyper")}.items():
+        mrad, K, norm = (int(v) for v in d[tag + "__params"])
+        s, i, u = ho.floating_region_score(logit, embed, unc, pur, bool(norm), d["gt"], size=3, purity_type=pur, K=K)
+        nd = int((u != d[tag + "__uncertainty"]).sum())
+        assert nd <= 8 and np.abs(u - d[tag + "__uncertainty"]).max() <= 3e-7, (tag, nd)
+        if pur != "radius":
+            assert np.array_equal(i, d[tag + "__impurity"]), tag
+            assert int((s != d[tag + "__score"]).sum()) <= 8, tag
+        assert np.abs(s.astype(np.float64) - d[tag + "__score"].astype(np.float64)).max() < 1e-6, tag
+        act, sel, am = d["prior_active"].copy(), np.zeros((H, W), bool), np.full((H, W), 255, np.int64)
+        sc = s.copy()
+        sc[act] = -np.inf
+        _, _, _, _, picks = ho.select_pixels_to_label(sc, 40, 1, mrad, act, sel, am, d["gt"], return_picks=True)
+        assert np.array_equal(picks[:, :2], d[tag + "__picks"][:, :2]), tag
