@@ -699,12 +699,15 @@ def main():
         ssz = pipe.score[0].element_size()
         images = n_pool
         value = images / dt
-        # k_feat_reduce per launch: features read + radius map written + (fused) logits read + entropy map written
-        launch_bytes = B * Hh * Ww * (C * esz + esz + O * 4 + 4)
-        avg_ms = float(np.mean(feat_ms)) if feat_ms else float("nan")
-        achieved = launch_bytes / (avg_ms * 1e-3) / 1e9 if feat_ms else float("nan")
+        # k_feat_reduce per launch.  kernel_bytes: what the kernel itself moves -- features read + radius map written + (fused)
+        # logits read + entropy map written.  launch_bytes: the ALGORITHMIC bytes of SURVEY.md 8(d) for the images of one launch --
+        # H W (C s_feat + O 4 + s_score) each -- which is what `achieved` / `frac` are computed from (0.2 % less).
+        kernel_bytes = B * Hh * Ww * (C * esz + esz + O * 4 + 4)
         uses_feat = pur in ("radius", "euc_norm", "hyper")
         path_bytes_per_image = Hh * Ww * ((C * esz if uses_feat else 0) + O * 4 + ssz)
+        launch_bytes = B * path_bytes_per_image
+        avg_ms = float(np.mean(feat_ms)) if feat_ms else float("nan")
+        achieved = launch_bytes / (avg_ms * 1e-3) / 1e9 if feat_ms else float("nan")
         out = {
             "metric": "acquisition-scored images/sec (1024x2048, C=256, 19 cls)",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -724,7 +727,10 @@ def main():
                                       if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": "k_feat_reduce", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "bytes_per_launch": launch_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms),
+                         "bytes_per_launch": launch_bytes, "bytes_per_image_survey_8d": path_bytes_per_image, "images_per_launch": B,
+                         "kernel_bytes_per_launch": kernel_bytes,
+                         "frac_of_kernel_bytes": round(kernel_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if feat_ms else None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(feat_ms),
                          "avg_launch_ms_even_odd_steps": [round(float(np.mean(feat_ms[0::2])), 4), round(float(np.mean(feat_ms[1::2])), 4)] if len(feat_ms) > 1 else None,
                          "scoring_call_alone_ms_per_batch": batch_alone,
                          "launch_ms": [round(v, 3) for v in feat_ms] if os.environ.get("HALO_BENCH_LAUNCH_MS") else None,
@@ -817,17 +823,25 @@ def main():
                                 float(np.mean(lr_ms["tail"])), HBM_PEAK_GBPS, "GB/s",
                                 "radius + entropy read (entropy twice: min/max pass and combine), active read, three maps written"))
             out["roofline_kernels"] = ks
-        for name in ("r05_pmc_summary.json", os.path.join("archive", "r04_pmc_summary.json")):
-            pmc = os.path.join(ROOT, "profiles", name)
+        # HBM traffic of the kernel per launch: PMC counters need their own rocprofv3 passes (--pmc FETCH_SIZE / WRITE_SIZE, gfx950
+        # correction applied by tools/distill_profiles.py).  HALO_BENCH_PMC=<file>: the summary of passes taken on THIS box in THIS
+        # call, of this exact launch shape (tools/collect_profiles.sh) -> `traffic`.  Otherwise the tracked collection's figure is
+        # quoted under its own name and `traffic` stays null.
+        same_run = os.environ.get("HALO_BENCH_PMC")
+        for name in ([same_run] if same_run else []) + ["r06_pmc_summary.json", "r05_pmc_summary.json"]:
+            pmc = name if os.path.isabs(name) or name == same_run else os.path.join(ROOT, "profiles", name)
             if out["roofline"] is None or lowres or not os.path.exists(pmc):
                 continue
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("dtype") == a.feat_dtype and rec.get("shape_HWCO") == [Hh, Ww, C, O]:
-                    # not measured in THIS run (PMC counters need their own rocprofv3 passes): the collection's figure for this
-                    # exact launch shape, under its own name; `traffic` stays null
-                    out["roofline"]["traffic_from_profile"] = rec["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/" + name
+                    if name == same_run:
+                        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_over_bytes_per_launch"] = round(rec["hbm_bytes_per_launch"] / launch_bytes, 4)
+                        out["roofline"]["traffic_source"] = "same gpurun call: " + rec.get("command", "rocprofv3 --pmc passes")
+                    else:
+                        out["roofline"]["traffic_from_profile"] = rec["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = "profiles/" + name
                     break
             except Exception:
                 pass

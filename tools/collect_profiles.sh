@@ -1,11 +1,11 @@
 #!/bin/bash
 # Measurement pass on one MI355X box: every number quoted in DESIGN.md / README.md / profiles/CURRENT.md for the current round.
-#     gpurun --timeout 3600 -- 'bash tools/collect_profiles.sh r05'
+#     gpurun --timeout 3600 -- 'bash tools/collect_profiles.sh r06'
 # Raw output lands in gpurun_out/<round>_profiles/; tools/distill_profiles.py (run afterwards in the build container) turns it into
 # the tracked files under profiles/.  EVERY step goes through run(): a step that exits non-zero -- an A/B tool whose variants
 # disagree, a bench whose tables differ from the oracle -- is recorded in <out>/FAILED with its stderr kept beside its output, and
 # the script exits 1 at the end (round 4 sent stderr to /dev/null and had no failure path at all: VERDICT r4 #3).
-RND=${1:-r05}
+RND=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${RND}_profiles
 rm -rf $OUT; mkdir -p $OUT
@@ -28,11 +28,16 @@ prof() {        # prof <trace dir> <rocprofv3 options...> -- <program...>  (the 
 }
 B="python3 $R/bench.py"
 # ---- the BASELINE line (configs[1]) with the CPU baseline and the oracle check of the timed tables, then its traces / counters
-run bench_default.json $B
-prof trace --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --cpu-images 0
-run tail_timeline.txt python3 $R/tools/tail_timeline.py $OUT/trace
+# (the two counter passes come FIRST: their summary is handed to the default run, which reports it as roofline.traffic -- HBM bytes of
+#  the same launch shape measured on this box in this call; separate --pmc passes with --kernel-trace only, as the guide prescribes)
 prof pmc_fetch --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --ring 16
 prof pmc_write --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --ring 16
+run pmc_summary.txt python3 $R/tools/distill_profiles.py $RND --pmc-only $OUT/pmc_summary.json
+export HALO_BENCH_PMC=$OUT/pmc_summary.json
+run bench_default.json $B
+unset HALO_BENCH_PMC
+prof trace --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --cpu-images 0
+run tail_timeline.txt python3 $R/tools/tail_timeline.py $OUT/trace
 # ---- variants: shapes, branches, sources, and the value distributions that stress the selector
 for v in "f32:--feat-dtype f32" "lowres_exact:--source lowres --lr-mode exact" "lowres_gram:--source lowres --lr-mode gram" \
          "c512:--channels 512 --ring 16" "ripu:--branch ripu" "hyper:--branch hyper" "pool2975:--pool-images 2975" \

@@ -3,7 +3,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = os.path.join(ROOT, "gpurun_out", RND + "_profiles")
 DST = os.path.join(ROOT, "profiles")
 
@@ -59,6 +59,39 @@ def durations(pattern, key):
 
 def short(name):
     return name.split("(")[0].replace("void ", "")
+
+
+def pmc_summary(dst):
+    """HBM traffic of the roofline kernel from the two separate --pmc passes (gfx950: FETCH_SIZE doubled) -> dst (JSON).
+    `python tools/distill_profiles.py r06 --pmc-only <file>` writes it on the GPU box between the counter passes and the default
+    bench run, which then reports it as roofline.traffic (HALO_BENCH_PMC=<file>: same box, same call, same launch shape)."""
+    fetch, write = counters("pmc_fetch/*/*counter_collection.csv"), counters("pmc_write/*/*counter_collection.csv")
+    per = {}
+    feat = None
+    for k in fetch:
+        per[short(k)] = {"FETCH_SIZE_raw": round(sum(fetch[k]["FETCH_SIZE"]) / max(1, len(fetch[k]["FETCH_SIZE"])), 1)}
+        if "k_feat_reduce" in k:
+            feat = k
+    for k in write:
+        per.setdefault(short(k), {})["WRITE_SIZE"] = round(sum(write[k]["WRITE_SIZE"]) / max(1, len(write[k]["WRITE_SIZE"])), 1)
+    if not feat:
+        return None
+    f_kb = sum(fetch[feat]["FETCH_SIZE"]) / len(fetch[feat]["FETCH_SIZE"])
+    wk = [k for k in write if "k_feat_reduce" in k][0]
+    w_kb = min(write[wk]["WRITE_SIZE"])
+    B, H, W, C, O = 16, 1024, 2048, 256, 19
+    kern = B * H * W * (C * 8 + 8 + O * 4 + 4)          # what the kernel itself moves (radius + entropy maps written)
+    alg = B * H * W * (C * 8 + O * 4 + 8)               # SURVEY 8(d): features + logits read, one float64 score written
+    hbm = int(2 * f_kb * 1024 + w_kb * 1024)
+    rec = {"round": int(RND[1:]), "kernel": short(feat), "batch": B, "dtype": "f64", "shape_HWCO": [H, W, C, O],
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
+                      "--cpu-images 0 --ring 16 (two separate passes)",
+           "FETCH_SIZE_KB_avg_per_launch": f_kb, "WRITE_SIZE_KB_min_per_launch": w_kb,
+           "correction": "gfx950: FETCH_SIZE reports 1/2 of a 16-B/lane coalesced streaming read (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
+           "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "kernel_bytes_per_launch": kern,
+           "traffic_over_algorithmic": round(hbm / alg, 4), "traffic_over_kernel_bytes": round(hbm / kern, 4), "per_kernel_KB": per}
+    json.dump(rec, open(dst, "w"), indent=1)
+    return rec
 
 
 def main():
@@ -117,30 +150,7 @@ def main():
             if t == "fuzz_head.txt":
                 keep = keep[-2:]
             open(os.path.join(DST, RND + "_" + t), "w").writelines(keep)
-    # ---- HBM traffic of the roofline kernel (two separate --pmc passes; gfx950: FETCH_SIZE doubled)
-    fetch, write = counters("pmc_fetch/*/*counter_collection.csv"), counters("pmc_write/*/*counter_collection.csv")
-    per = {}
-    feat = None
-    for k in fetch:
-        per[short(k)] = {"FETCH_SIZE_raw": round(sum(fetch[k]["FETCH_SIZE"]) / max(1, len(fetch[k]["FETCH_SIZE"])), 1)}
-        if "k_feat_reduce" in k:
-            feat = k
-    for k in write:
-        per.setdefault(short(k), {})["WRITE_SIZE"] = round(sum(write[k]["WRITE_SIZE"]) / max(1, len(write[k]["WRITE_SIZE"])), 1)
-    if feat:
-        f_kb = sum(fetch[feat]["FETCH_SIZE"]) / len(fetch[feat]["FETCH_SIZE"])
-        wk = [k for k in write if "k_feat_reduce" in k][0]
-        w_kb = min(write[wk]["WRITE_SIZE"])
-        B, H, W, C, O = 16, 1024, 2048, 256, 19
-        alg = B * H * W * (C * 8 + 8 + O * 4 + 4)
-        hbm = int(2 * f_kb * 1024 + w_kb * 1024)
-        json.dump({"round": int(RND[1:]), "kernel": short(feat), "batch": B, "dtype": "f64", "shape_HWCO": [H, W, C, O],
-                   "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-                              "--cpu-images 0 --ring 16 (two separate passes)",
-                   "FETCH_SIZE_KB_avg_per_launch": f_kb, "WRITE_SIZE_KB_min_per_launch": w_kb,
-                   "correction": "gfx950: FETCH_SIZE reports 1/2 of a 16-B/lane coalesced streaming read (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
-                   "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(hbm / alg, 4),
-                   "per_kernel_KB": per}, open(os.path.join(DST, RND + "_pmc_summary.json"), "w"), indent=1)
+    pmc_summary(os.path.join(DST, RND + "_pmc_summary.json"))
     # ---- HyperMLR on the matrix cores
     mlr = counters("pmc_mlr/*/*counter_collection.csv")
     clk = counters("pmc_mlr_clk/*/*counter_collection.csv")
@@ -166,4 +176,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--pmc-only" in sys.argv:
+        r = pmc_summary(sys.argv[sys.argv.index("--pmc-only") + 1])
+        print("pmc summary:", None if r is None else {k: r[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")})
+    else:
+        main()
