@@ -163,7 +163,11 @@ static inline void bw_put(bitw_t *w, uint32_t bits, int n)      /* n <= 24 */
 {
     w->acc |= (uint64_t)bits << w->nbits;
     w->nbits += n;
-    if (w->nbits >= 32) bw_flush_bytes(w);
+    if (w->nbits >= 32) {                                        /* four whole bytes at once (little-endian hosts) */
+        if (w->p + 4 <= w->end) { const uint32_t lo = (uint32_t)w->acc; memcpy(w->p, &lo, 4); w->p += 4; } else w->overflow = 1;
+        w->acc >>= 32;
+        w->nbits -= 32;
+    }
 }
 static inline uint32_t rev_bits(uint32_t v, int n)
 {
@@ -178,6 +182,8 @@ static uint8_t lit_len[288];
 static uint16_t len_sym[259];        /* match length 3..258 -> length symbol */
 static uint8_t len_xbits[259];
 static uint16_t len_xval[259];
+static uint32_t match_d1_code[259];  /* the whole "L bytes at distance 1" token: length code, extra bits, distance code 0 -- <= 18 bits */
+static uint8_t match_d1_bits[259];
 static pthread_once_t huff_once = PTHREAD_ONCE_INIT;
 static void huff_init(void)
 {
@@ -199,15 +205,19 @@ static void huff_init(void)
         len_sym[L] = (uint16_t)(257 + k);
         len_xbits[L] = (uint8_t)xb[k];
         len_xval[L] = (uint16_t)(L - base[k]);
+        const int s_ = 257 + k;
+        uint32_t code = lit_code[s_];
+        int nb = lit_len[s_];
+        code |= (uint32_t)(L - base[k]) << nb; nb += xb[k];
+        nb += 5;                                                 /* distance code 0 (5 zero bits) = distance 1, no extra bits */
+        match_d1_code[L] = code;
+        match_d1_bits[L] = (uint8_t)nb;
     }
 }
 static inline void put_literal(bitw_t *w, unsigned v) { bw_put(w, lit_code[v], lit_len[v]); }
 static inline void put_match_d1(bitw_t *w, int L)              /* L bytes repeating the previous byte */
 {
-    const unsigned s = len_sym[L];
-    bw_put(w, lit_code[s], lit_len[s]);
-    if (len_xbits[L]) bw_put(w, len_xval[L], len_xbits[L]);
-    bw_put(w, 0u, 5);                                            /* distance code 0 = distance 1, no extra bits */
+    bw_put(w, match_d1_code[L], match_d1_bits[L]);               /* length symbol + extra bits + distance code 0 in one token */
 }
 /* a run of n >= 1 equal bytes v whose first byte has NOT been sent yet */
 static inline void put_run(bitw_t *w, unsigned v, size_t n)
@@ -223,15 +233,38 @@ static inline void put_run(bitw_t *w, unsigned v, size_t n)
     while (n--) put_literal(w, v);
 }
 
+#if defined(__x86_64__)
+static int avx2_state;
+static pthread_once_t avx2_once = PTHREAD_ONCE_INIT;
+static void avx2_probe(void) { avx2_state = __builtin_cpu_supports("avx2") ? 1 : 0; }
+static int have_avx2(void) { pthread_once(&avx2_once, avx2_probe); return avx2_state; }
+/* number of leading bytes of p[0..n) equal to v, counted in whole 32-byte steps plus the position inside the first step that differs
+ * (the caller finishes the last < 32 bytes) */
+__attribute__((target("avx2"))) static size_t run_scan_avx2(const uint8_t *p, size_t n, uint8_t v)
+{
+    const __m256i pat = _mm256_set1_epi8((char)v);
+    size_t j = 0;
+    while (j + 32 <= n) {
+        const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + j)), pat));
+        if (m != 0xffffffffu) return j + (size_t)__builtin_ctz(~m);
+        j += 32;
+    }
+    return j;
+}
+#endif
+
 #define ADLER_MOD 65521u
-static inline void adler_run(uint32_t *a, uint32_t *b, unsigned v, size_t n)
+/* Adler-32 over a run of n bytes of value v, on UNREDUCED 64-bit sums: a <- a + n v, b <- b + n a + v n (n + 1) / 2.  The two
+ * remainders are taken only when a sum nears 2^62 and once at the end -- three 64-bit divisions per run were a third of the encoder's
+ * time on a mask with 20 000 labelled pixels (round 6). */
+static inline void adler_run(uint64_t *a, uint64_t *b, unsigned v, size_t n)
 {
     while (n) {
-        const uint64_t m = n > (1u << 20) ? (1u << 20) : n;
-        const uint64_t a0 = *a;
-        *b = (uint32_t)((*b + m * a0 + (uint64_t)v * (m * (m + 1) / 2 % ADLER_MOD)) % ADLER_MOD);
-        *a = (uint32_t)((a0 + m * v) % ADLER_MOD);
+        const uint64_t m = n > (1u << 16) ? (1u << 16) : n;
+        *b += m * *a + (uint64_t)v * (m * (m + 1) / 2);          /* a < 2^40, m <= 2^16: every term < 2^57 */
+        *a += m * v;
         n -= (size_t)m;
+        if ((*b >> 62) || (*a >> 40)) { *a %= ADLER_MOD; *b %= ADLER_MOD; }
     }
 }
 
@@ -267,7 +300,10 @@ size_t halo_png_gray8_encode(const uint8_t *img, int64_t H, int64_t W, int64_t r
     bitw_t w = {p, out + cap - 32, 0, 0, 0};                /* room for the Adler-32, the chunk CRC and IEND */
     bw_put(&w, 1u, 1);                                           /* BFINAL */
     bw_put(&w, 1u, 2);                                           /* BTYPE = 01: fixed Huffman codes */
-    uint32_t a = 1, b = 0;
+    uint64_t a = 1, b = 0;
+#if defined(__x86_64__)
+    const int avx2 = have_avx2();
+#endif
     for (int64_t y = 0; y < H; ++y) {
         const uint8_t *row = img + (size_t)y * (size_t)row_stride;
         /* the scanline's filter byte (type 0) joins a leading run of zeros, if the row starts with one */
@@ -280,6 +316,14 @@ size_t halo_png_gray8_encode(const uint8_t *img, int64_t H, int64_t W, int64_t r
             const unsigned v = row[i];
             size_t j = i + 1;
             const uint64_t pat = 0x0101010101010101ull * v;
+            if (j < n && row[j] != v) goto found;          /* a single byte: most runs inside a labelled window */
+#if defined(__x86_64__)
+            if (j + 32 <= n && avx2) {                     /* long runs (an unlabelled mask is one value): 32 bytes per compare */
+                const size_t adv = run_scan_avx2(row + j, n - j, (uint8_t)v);
+                j += adv;
+                if (j < n && row[j] != v) goto found;
+            }
+#endif
             while (j + 8 <= n) {
                 uint64_t x;
                 memcpy(&x, row + j, 8);
@@ -300,7 +344,7 @@ size_t halo_png_gray8_encode(const uint8_t *img, int64_t H, int64_t W, int64_t r
     bw_flush_bytes(&w);
     if (w.overflow) return 0;
     p = w.p;
-    put_be32(p, (b << 16) | a); p += 4;                          /* Adler-32 of the filtered stream */
+    put_be32(p, (uint32_t)(((b % ADLER_MOD) << 16) | (a % ADLER_MOD))); p += 4;   /* Adler-32 of the filtered stream */
     const uint32_t idat_len = (uint32_t)(p - (idat + 8));
     put_be32(idat, idat_len);
     put_be32(p, crc32_update(0, idat + 4, 4 + (size_t)idat_len)); p += 4;
@@ -364,9 +408,59 @@ static inline uint8_t low_byte_at(const void *src, int itemsize, size_t i)
 {
     return ((const uint8_t *)src)[i * (size_t)itemsize];           /* little-endian hosts (x86-64, the GPU boxes) */
 }
+#if defined(__x86_64__)
+/* int64 -> low bytes, the loader's 16.8 MB `origin_mask` per 1024 x 2048 image (core/datasets/cityscapes.py:234 hands the uint8 PNG
+ * as int64): one vpmovqb per 8 elements where the host has AVX-512 (every GPU box of the pool: EPYC 9004 / Xeon), else two shuffles and
+ * a permute per 8 under AVX2.  The loop is then bound by the one streaming read of the source (round 5's scalar loop ran at half of it). */
+__attribute__((target("avx512f,avx512bw,avx512vl"))) static void low_bytes_q_avx512(uint8_t *dst, const uint64_t *s, size_t n)
+{
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m128i a = _mm512_cvtepi64_epi8(_mm512_loadu_si512((const void *)(s + i)));
+        const __m128i b = _mm512_cvtepi64_epi8(_mm512_loadu_si512((const void *)(s + i + 8)));
+        const __m128i c = _mm512_cvtepi64_epi8(_mm512_loadu_si512((const void *)(s + i + 16)));
+        const __m128i d = _mm512_cvtepi64_epi8(_mm512_loadu_si512((const void *)(s + i + 24)));
+        _mm_storeu_si128((__m128i *)(dst + i), _mm_unpacklo_epi64(a, b));
+        _mm_storeu_si128((__m128i *)(dst + i + 16), _mm_unpacklo_epi64(c, d));
+    }
+    for (; i < n; ++i) dst[i] = (uint8_t)s[i];
+}
+__attribute__((target("avx2"))) static void low_bytes_q_avx2(uint8_t *dst, const uint64_t *s, size_t n)
+{
+    /* byte 0 of each 64-bit lane to the low bytes of each 128-bit half, then the two halves side by side */
+    const __m256i pick = _mm256_setr_epi8(0, 8, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 8, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        uint16_t h[8];
+        for (int j = 0; j < 4; ++j) {
+            const __m256i v = _mm256_shuffle_epi8(_mm256_loadu_si256((const __m256i *)(s + i + 4 * j)), pick);
+            h[2 * j] = (uint16_t)_mm256_extract_epi16(v, 0);
+            h[2 * j + 1] = (uint16_t)_mm256_extract_epi16(v, 8);
+        }
+        memcpy(dst + i, h, 16);
+    }
+    for (; i < n; ++i) dst[i] = (uint8_t)s[i];
+}
+static int low_bytes_isa;                             /* 2: AVX-512, 1: AVX2, 0: scalar */
+static pthread_once_t low_bytes_once = PTHREAD_ONCE_INIT;
+static void low_bytes_probe(void)
+{
+    low_bytes_isa = (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl")) ? 2
+                    : (__builtin_cpu_supports("avx2") ? 1 : 0);
+}
+#endif
+static int low_bytes_force = 0;                       /* test switch, halo_low_bytes_mode: 0 best available, 1 scalar, 2 at most AVX2 */
+void halo_low_bytes_mode(int mode) { low_bytes_force = mode; }
 static void low_bytes(uint8_t *dst, const void *src, int itemsize, size_t n)
 {
     if (itemsize == 1) { memcpy(dst, src, n); return; }
+#if defined(__x86_64__)
+    if (itemsize == 8 && low_bytes_force != 1) {
+        pthread_once(&low_bytes_once, low_bytes_probe);
+        if (low_bytes_isa == 2 && low_bytes_force != 2) { low_bytes_q_avx512(dst, (const uint64_t *)src, n); return; }
+        if (low_bytes_isa >= 1) { low_bytes_q_avx2(dst, (const uint64_t *)src, n); return; }
+    }
+#endif
     if (itemsize == 8) { const uint64_t *s = (const uint64_t *)src; for (size_t i = 0; i < n; ++i) dst[i] = (uint8_t)s[i]; return; }
     if (itemsize == 4) { const uint32_t *s = (const uint32_t *)src; for (size_t i = 0; i < n; ++i) dst[i] = (uint8_t)s[i]; return; }
     if (itemsize == 2) { const uint16_t *s = (const uint16_t *)src; for (size_t i = 0; i < n; ++i) dst[i] = (uint8_t)s[i]; return; }

@@ -66,6 +66,10 @@ int halo_retire_image(const char *path_png, const char *path_indicator, const vo
                       const uint8_t *active, const uint8_t *selected, int64_t compose_mask_radius, const uint8_t *tpl, size_t tpl_len,
                       size_t off_a, size_t off_s, const uint64_t *crc_fields_a, const uint64_t *crc_fields_s);
 
+/* halo_compose_mask narrows 64-bit elements with AVX-512 / AVX2 where the host has them; halo_low_bytes_mode(1) forces the scalar
+ * loop, (2) at most AVX2, (0) the best available (test switch, like halo_crc32_mode). */
+void halo_low_bytes_mode(int mode);
+
 /* The writer functions keep ~8 MB of scratch per calling thread between calls; it is freed when the thread exits, or now by this
  * call (long-lived writer threads that are done for the round). */
 void halo_host_thread_release(void);

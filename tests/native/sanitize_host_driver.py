@@ -109,6 +109,18 @@ for dt in (np.uint8, np.int16, np.int32, np.int64):
         assert np.array_equal(mask, want), (dt, radius)
     assert h.halo_compose_mask(mask.ctypes.data, om.ctypes.data, om.itemsize, None, 0, H, W, None, 0, 1) == 0
 assert h.halo_compose_mask(mask.ctypes.data, om.ctypes.data, 3, gt.ctypes.data, 8, H, W, picks.ctypes.data, 1, 1) == -1
+# the three statements of the 64-bit narrowing (AVX-512, AVX2, scalar): ragged lengths, high bytes set, unaligned starts
+h.halo_low_bytes_mode.argtypes = [C.c_int]
+for hh, ww in ((1, 1), (1, 31), (3, 33), (5, 67), (7, 129), (64, 130)):
+    wide = rng.integers(-2 ** 62, 2 ** 62, hh * ww + 1, dtype=np.int64)
+    src = wide[1:]                                              # 8-byte aligned but not 64-byte aligned
+    want = (src & 0xff).astype(np.uint8).reshape(hh, ww)
+    for mode in (0, 1, 2):
+        h.halo_low_bytes_mode(mode)
+        got = np.zeros((hh, ww), np.uint8)
+        assert h.halo_compose_mask(got.ctypes.data, src.ctypes.data, 8, None, 0, hh, ww, None, 0, 1) == 0
+        assert np.array_equal(got, want), (hh, ww, mode)
+h.halo_low_bytes_mode(0)
 pa, ps = (rng.random((H, W)) < 0.02).astype(np.uint8), np.zeros((H, W), np.uint8)
 a, s = np.empty((H, W), np.uint8), np.empty((H, W), np.uint8)
 assert h.halo_compose_indicators(a.ctypes.data, s.ctypes.data, pa.ctypes.data, ps.ctypes.data, H, W, picks.ctypes.data, len(picks), 1, 5) == 0

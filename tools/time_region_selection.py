@@ -78,7 +78,8 @@ def batched(items, nb):
 STAGING = os.environ.get("HALO_RS_STAGING", "table")
 REPEATS = int(os.environ.get("HALO_RS_REPEATS", "5"))
 for MODE, busy in (() if os.environ.get("HALO_RS_FLOOR_ONLY") else (("none", 0.0), ("sleep", 30.0), ("gemm", 30.0))):
-    CONFIGS = ((0, 1, 1, "serial (in_flight=0, 1 writer)"), (8, 8, 1, "pipelined (in_flight=8, 4 streams, 8 writers)"), (8, 16, 1, "pipelined (in_flight=8, 4 streams, 16 writers)"),
+    CONFIGS = ((0, 1, 1, "serial (in_flight=0, 1 writer)"), (8, 2, 1, "pipelined (in_flight=8, 4 streams, 2 writers: a rank's share of 16 cores under 8 ranks)"),
+               (8, 8, 1, "pipelined (in_flight=8, 4 streams, 8 writers)"), (8, 16, 1, "pipelined (in_flight=8, 4 streams, 16 writers)"),
                (8, 12, 1, "pipelined (in_flight=8, 4 streams, 12 writers)"), (None, None, 1, "pipelined (defaults)"),
                (None, None, 2, "pipelined (defaults), loader batch 2"), (None, None, 4, "pipelined (defaults), loader batch 4"))
     if os.environ.get("HALO_RS_SWEEP"):            # depth x writers sweep (no backbone only)
@@ -86,7 +87,7 @@ for MODE, busy in (() if os.environ.get("HALO_RS_FLOOR_ONLY") else (("none", 0.0
             continue
         CONFIGS = tuple((d, w, 1, "in_flight=%d, %d writers" % (d, w)) for d in (8, 12, 16, 24) for w in (8, 12, 16))
     for (infl, wr, nb, tag) in CONFIGS:
-        if MODE != "none" and (wr in (12, 16) or nb > 1):
+        if MODE != "none" and (wr in (2, 12, 16) or nb > 1):
             continue
         tmp = tempfile.mkdtemp(prefix="halo_rs_t_")
         items = batched(pool(tmp), nb) if nb > 1 else pool(tmp)
@@ -147,5 +148,5 @@ def writers_alone(n_threads):
 
 
 if not os.environ.get("HALO_RS_SWEEP"):
-    for nt in (1, 4, 8, 16):
+    for nt in (1, 2, 4, 8, 16):
         print(f"host floor: {nt:2d} writer thread(s) alone, no GPU in the loop (halo_retire_image x {N}): {writers_alone(nt):6.2f} ms/image", flush=True)
