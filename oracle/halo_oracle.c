@@ -34,6 +34,7 @@ enum { HALO_F32 = 0, HALO_F64 = 1 };
 float halo_o_expf(float x) { return ho_expf(x); }
 float halo_o_logf(float x) { return ho_logf(x); }
 double halo_o_log(double x) { return ho_log(x); }
+double halo_o_log_cr(double x) { return ho_log_cr(x); }
 
 void halo_o_expf_v(const float *x, float *y, i64 n)
 {
@@ -55,7 +56,7 @@ static double artanh_clamped(double z)
     const double lim = 1.0 - 1e-7;
     if (z > lim) z = lim;
     if (z < -lim) z = -lim;
-    return (ho_log(1.0 + z) - ho_log(1.0 - z)) * 0.5;
+    return (ho_log_cr(1.0 + z) - ho_log_cr(1.0 - z)) * 0.5;
 }
 
 /* sum of squares over a strided vector, sequential fma chain in float64 */

@@ -77,6 +77,8 @@ def lib():
         _lib.halo_o_logf.argtypes = [C.c_float]
         _lib.halo_o_log.restype = _dbl
         _lib.halo_o_log.argtypes = [_dbl]
+        _lib.halo_o_log_cr.restype = _dbl
+        _lib.halo_o_log_cr.argtypes = [_dbl]
         _lib.halo_o_select.restype = _i64
     return _lib
 

@@ -76,7 +76,10 @@ int main(int argc, char **argv)
         if (i % 11 == 0) u = (u & 0x000fffffffffffffull) | 0x3fe0000000000000ull;
         const double x = __longlong_as_double((long long)u);
         cmpd("log", u, halo::det_log(x), ho_log(x));
-        if (u >= 0x0010000000000000ull && u < 0x7ff0000000000000ull) cmpd("log_core", u, halo::det_log_core(x), ho_log(x));
+        if (u >= 0x0010000000000000ull && u < 0x7ff0000000000000ull) {
+            cmpd("log_core", u, halo::det_log_core(x), ho_log(x));
+            cmpd("log_cr_core", u, halo::det_log_cr_core(x), ho_log_cr(x));
+        }
     }
     const double sp[] = {0.0, -0.0, INFINITY, -INFINITY, NAN, 1.0, 5e-324, 2.2250738585072014e-308, -1.0, 1.7976931348623157e308};
     for (double x : sp) cmpd("log", (uint64_t)__double_as_longlong(x), halo::det_log(x), ho_log(x));

@@ -1334,6 +1334,43 @@ def test_hypermlr_epilogue_forms_agree(dev):
             assert float((an[ok] - rn[ok]).abs().max()) < 2e-12 * max(1.0, float(rn[ok].abs().max()))
 
 
+def test_both_hypermlr_epilogues_feed_the_acquisition_the_same_files(golden, dev):
+    """the acquisition's parity "starts from the logits", and in the real pipeline the logits are this package's own
+    HyperMLR -- whose matrix-core epilogue (one quotient per logit, refined v_rcp / v_rsq, log-form asinh) is within ~4e-15 of the
+    reference-order statement, not bit-equal to it.  Here the head tail runs on the reference's own latents and parameters
+    (tests/golden/case_*.npz: z, P_MLR, A_MLR) with BOTH epilogues; the float32 logits must agree with the reference's float32
+    logits except where a float64 value sits within the epilogue's error of a float32 rounding boundary (counted, bounded), and the
+    masks / indicators / picks that the acquisition derives from each must be the reference's."""
+    from halo_amd.core.active.build import greedy_select
+    from halo_amd.core.active.floating_region import score_maps_lowres
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR
+    for case in ("case_a_32x64_c8_o19", "case_b_64x128_c16_o19"):
+        d = golden(case)
+        H, W, C, O = (int(v) for v in d["meta_HWCO"])
+        n = int(d["meta_n_regions"][0])
+        mlr = HyperMLR(C, O, c=1.0).to(dev)
+        with torch.no_grad():
+            mlr.P_MLR.copy_(t(d["P_MLR"], dev)); mlr.A_MLR.copy_(t(d["A_MLR"], dev))
+            emb = HyperMapper(1.0).expmap(t(d["z"], dev), dim=1)
+            outs = {"one-quotient": mlr._hyper_logits(emb, out_dtype=torch.float32),
+                    "reference-order": _with_env({"HALO_MLR_EPI_REF": "1"}, lambda: mlr._hyper_logits(emb, out_dtype=torch.float32))}
+        for name, lg in outs.items():
+            nd = int((lg.cpu().numpy() != d["logit_lr"]).sum())
+            assert nd <= max(2, lg.numel() // 20000), (case, name, nd)          # float32 roundings of float64 values ~1e-15 apart
+            assert np.abs(lg.cpu().numpy() - d["logit_lr"]).max() < 2e-6
+            with torch.no_grad():
+                s, _, _ = score_maps_lowres(lg, emb, (H, W), "entropy", "radius", True, t(d["gt"], dev)[None], ksize=3, K=100)
+            act = t(d["prior_active"], dev)[None].clone()
+            sel = torch.zeros_like(act)
+            am = torch.full((1, H, W), 255, dtype=torch.int64, device=dev)
+            sc = s.clone()
+            sc[act] = -float("inf")
+            picks, npk = greedy_select(sc, n, 1, 5, act, sel, am, t(d["gt"], dev)[None])
+            assert np.array_equal(picks[0, :int(npk[0]), :2].cpu().numpy(), d["halo__r1_picks"][:, :2]), (case, name)
+            assert np.array_equal(act[0].cpu().numpy(), d["halo__r1_active"]) and np.array_equal(sel[0].cpu().numpy(), d["halo__r1_selected"]), (case, name)
+            assert np.array_equal(am[0].cpu().numpy(), d["halo__r1_active_mask"]), (case, name)
+
+
 def test_selection_is_stable_beside_streaming_kernels(dev):
     """The selector's window stores are drained one step late and masked analytically meanwhile
     (halo_select.hip); its loads see HBM latencies several times longer when the feature stream

@@ -5,8 +5,15 @@ halo_amd/csrc/halo_devmath.hpp `det_logf_core`) with mpmath, as C hexadecimal fl
     r_j     1 / (centre of the bin) rounded to 16 significant bits (so m r_j is exact in binary64); exactly 1 for the bin holding m = 1
     L_j     -log(r_j) rounded to binary64 (exactly 0 for that bin)
 
-    python tools/gen_logf_table.py            prints both tables; the two headers hold these lines verbatim
-    python tools/gen_logf_table.py --check    compares with what the two headers hold (tests/test_oracle_kat.py runs this)
+The binary64 logarithm of the contract (`ho_log_cr` / `det_log_cr_core`: geoopt's artanh, core/utils/hyperbolic.py:83) has its own
+table, 256 bins over the same mantissa range indexed by the high word:
+
+    r_j     1 / (centre of the bin) on a 9-bit grid (multiples of 2^-8 above 1, of 2^-9 below), so that z = m r_j - 1 is EXACT in
+            binary64 and |z| < 2^-8 over the whole bin (both asserted here in rational arithmetic); exactly 1 for the bin holding m = 1
+    L_j     -log(r_j) as a double-double (hi, lo)
+
+    python tools/gen_logf_table.py            prints the tables; the two headers hold these lines verbatim
+    python tools/gen_logf_table.py --check    compares with what the two headers hold (tests/test_aten_exact.py runs this)
 """
 import re
 import struct
@@ -45,9 +52,40 @@ def lines():
     return ["    {%s, %s}," % (float.hex(r), float.hex(L)) for r, L in table()]
 
 
-def held(path):
+B64 = 0x3FE6A09E
+
+
+def f64_hw(hw):
+    return struct.unpack("<d", struct.pack("<II", 0, hw))[0]
+
+
+def table64():
+    from fractions import Fraction
+    rows = []
+    for j in range(256):
+        lo, hi = Fraction(f64_hw(B64 + j * 4096)), Fraction(f64_hw(B64 + (j + 1) * 4096))
+        if lo <= 1 < hi:
+            r = Fraction(1)
+        else:
+            inv = 1 / ((lo + hi) / 2)
+            step = Fraction(1, 256) if inv > 1 else Fraction(1, 512)
+            r = round(inv / step) * step
+        for m in (lo, hi - Fraction(1, 2 ** 60)):
+            z = abs(m * r - 1)
+            assert z < Fraction(1, 256), (j, float(z))                       # => m r - 1 fits 53 bits: exact under one fma
+        L = -mp.log(mp.mpf(r.numerator) / mp.mpf(r.denominator))
+        Lh = float(L)
+        rows.append((float(r), Lh, float(L - mp.mpf(Lh))))
+    return rows
+
+
+def lines64():
+    return ["    {%s, %s, %s}," % (float.hex(r), float.hex(h), float.hex(l)) for r, h, l in table64()]
+
+
+def held(path, tag="LOGF_TABLE"):
     txt = open(path).read()
-    m = re.search(r"LOGF_TABLE_BEGIN.*?\n(.*?)\n[^\n]*LOGF_TABLE_END", txt, re.S)
+    m = re.search(tag + r"_BEGIN.*?\n(.*?)\n[^\n]*" + tag + "_END", txt, re.S)
     return [l.rstrip() for l in m.group(1).splitlines()]
 
 
@@ -55,10 +93,12 @@ if __name__ == "__main__":
     if "--check" in sys.argv:
         import os
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        want = lines()
+        want, want64 = lines(), lines64()
         for p in ("oracle/halo_oracle_math.h", "halo_amd/csrc/halo_devmath.hpp"):
-            got = held(os.path.join(root, p))
-            assert got == want, p + ": table differs from the generator's"
-        print("both headers hold the generated table (128 rows)")
+            assert held(os.path.join(root, p)) == want, p + ": float32 table differs from the generator's"
+            assert held(os.path.join(root, p), "LOG64_TABLE") == want64, p + ": binary64 table differs from the generator's"
+        print("both headers hold the generated tables (128 + 256 rows)")
+    elif "--f64" in sys.argv:
+        print("\n".join(lines64()))
     else:
         print("\n".join(lines()))
