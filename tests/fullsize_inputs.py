@@ -61,3 +61,22 @@ def digest(inp):
     for k in ("logit_lr", "embed_lr", "gt", "prior"):
         hsh.update(np.ascontiguousarray(inp[k]).tobytes())
     return hsh.hexdigest()[:16]
+
+
+def build_driver_inputs(seed, C=64, O=19, H=1024, W=2048):
+    """The REAL pipeline's geometry at the RegionSelection boundary (core/active/build.py:103-135 behind a DeepLab-v3+ head): a
+    C-channel float64 embedding at (H/6.4, W/6.4) = 160 x 320 and float32 logits that the head itself already resized to the network
+    input size 640 x 1280 (classifier.py:556-557); labels 1024 x 2048.  numpy + oracle C only."""
+    import oracle.halo_oracle as ho
+    rng = np.random.default_rng(seed)
+    h, w = int(round(H / 6.4)), int(round(W / 6.4))
+    z = rng.standard_normal((1, C, h, w), dtype=np.float32) * np.float32(0.1)
+    prng = np.random.default_rng(7)
+    b = 1.0 / math.sqrt(C)
+    P, A = prng.uniform(-b, b, (O, C)), prng.uniform(-b, b, (O, C))
+    embed_lr = ho.expmap(z, dim=1)
+    logit_head = ho.hypermlr(embed_lr, P, A).astype(np.float32)
+    logit_lr = ho.bilinear(logit_head, (int(round(H / 1.6)), int(round(W / 1.6))))
+    gt = rng.integers(0, O, (H, W), dtype=np.int64)
+    gt[rng.random((H, W)) < 0.05] = 255
+    return dict(embed_lr=embed_lr, logit_lr=logit_lr, gt=gt, prior=np.zeros((H, W), bool))

@@ -546,6 +546,54 @@ def gen_fullsize(cfg, fr, ab):
     np.savez_compressed(os.path.join(OUT_DIR, "fullsize_picks.npz"), **out)
 
 
+def files_digest(mask_png, active, selected):
+    import hashlib
+    hsh = hashlib.sha256()
+    for a in (mask_png, active, selected):
+        hsh.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(hsh.digest(), dtype=np.uint8).copy()
+
+
+DRIVER_SEEDS = (41,)
+
+
+def gen_fullsize_driver(cfg, hyp, fr, ab):
+    """The reference's OWN RegionSelection (core/active/build.py:71-186: its two F.interpolate calls, scorer, selector, PNG and
+    torch.save) over the real pipeline's geometry at full label size, two rounds: digests of the files it leaves behind."""
+    import fullsize_inputs as fi
+    from PIL import Image
+    H, W, C, O = 1024, 2048, 64, 19
+    cfg.MODEL.NUM_CLASSES, cfg.MODEL.HYPER = O, True
+    cfg.ACTIVE.UNCERTAINTY, cfg.ACTIVE.PURITY, cfg.ACTIVE.NORMALIZE = "entropy", "radius", True
+    cfg.ACTIVE.RADIUS_K, cfg.ACTIVE.MASK_RADIUS_K, cfg.ACTIVE.BUDGET, cfg.ACTIVE.SELECT_ITER = 1, 5, 0.05, [0, 1, 2, 3, 4]
+    cfg.ACTIVE.K, cfg.ACTIVE.VIZ_MASK = 100, False
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="halo_fix_drv_")
+    for seed in DRIVER_SEEDS:
+        inp = fi.build_driver_inputs(seed, C=C, O=O, H=H, W=W)
+        out[f"s{seed}__digest"] = np.frombuffer(fi.digest(inp).encode(), dtype=np.uint8).copy()
+        pm, pi = os.path.join(tmp, f"m{seed}.png"), os.path.join(tmp, f"i{seed}.pth")
+        Image.fromarray(np.full((H, W), 255, dtype=np.uint8)).save(pm)
+        torch.save({"active": torch.tensor([0], dtype=torch.bool), "selected": torch.tensor([0], dtype=torch.bool)}, pi)
+        gt = torch.from_numpy(inp["gt"])
+        for rnd in (1, 2):
+            ind = torch.load(pi)
+            a, s_ = ind["active"], ind["selected"]
+            if a.size() == (1,):                                                # cityscapes.py:249-251
+                a, s_ = torch.zeros(H, W, dtype=torch.bool), torch.zeros(H, W, dtype=torch.bool)
+            mask = torch.from_numpy(np.array(Image.open(pm), dtype=np.uint8)).long()
+            item = {"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [pm], "origin_mask": mask[None], "origin_label": gt[None],
+                    "size": torch.tensor([[H, W]]), "active": a[None], "selected": s_[None], "path_to_indicator": [pi], "name": [f"s{seed}"]}
+            clf = _FakeClassifier([(torch.from_numpy(inp["logit_lr"]), torch.from_numpy(inp["embed_lr"]))])
+            ab.RegionSelection(cfg, _FakeExtractor(), clf, [item], rnd)
+            ind = torch.load(pi)
+            png = np.array(Image.open(pm), dtype=np.uint8)
+            out[f"s{seed}__r{rnd}_files_digest"] = files_digest(png, ind["active"].numpy(), ind["selected"].numpy())
+            out[f"s{seed}__r{rnd}_counts"] = np.array([int(ind["selected"].sum()), int(ind["active"].sum()), int((png != 255).sum())], dtype=np.int64)
+            print(f"  fullsize driver seed {seed} round {rnd}: selected px {int(ind['selected'].sum())}, labelled px {int((png != 255).sum())}")
+    np.savez_compressed(os.path.join(OUT_DIR, "fullsize_driver.npz"), **out)
+
+
 def gen_mid(cfg, hyp, fr, ab):
     """A case ABOVE 20480 pixels (112 x 192), where the reference's 3 x 3 box convolution runs in oneDNN like at every production
     size (aten/src/ATen/native/Convolution.cpp:use_mkldnn; the cases A-D take the im2col + MKL sgemm path, whose summation order is
@@ -599,6 +647,9 @@ def main():
     if only == "fullsize":
         gen_fullsize(cfg, fr, ab)
         return
+    if only == "fullsize_driver":
+        gen_fullsize_driver(cfg, hyp, fr, ab)
+        return
     if only == "mid":
         gen_mid(cfg, hyp, fr, ab)
         return
@@ -628,6 +679,8 @@ def main():
     gen_mid(cfg, hyp, fr, ab)
     print("reference pick tables at 1024 x 2048")
     gen_fullsize(cfg, fr, ab)
+    print("the reference's RegionSelection driver at 1024 x 2048, real head geometry")
+    gen_fullsize_driver(cfg, hyp, fr, ab)
 
 
 if __name__ == "__main__":

@@ -1859,6 +1859,43 @@ def test_region_selection_full_size_real_geometry_vs_oracle(dev):
     assert np.array_equal(ind["active"].numpy(), a_o) and np.array_equal(ind["selected"].numpy(), s_o)
 
 
+def test_region_selection_writes_the_references_files_at_full_size(dev):
+    """Reference-held golden for the path every real RegionSelection call runs (N1 + N2): the HIP driver over the real pipeline's
+    geometry (64-channel float64 embedding at 160 x 320, logits at 640 x 1280, labels 1024 x 2048, 2331 regions), two rounds through
+    its own PNG / indicator files, against the digests of the files the REFERENCE's RegionSelection wrote for the same arrays in the
+    build container (tests/golden/fullsize_driver.npz, tests/golden/make_fixtures.py:gen_fullsize_driver)."""
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, GOLDEN)
+    import fullsize_inputs as fi
+    from make_fixtures import DRIVER_SEEDS, files_digest
+    from halo_amd.core.active.build import RegionSelection
+    d = np.load(os.path.join(GOLDEN, "fullsize_driver.npz"))
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+    tmp = tempfile.mkdtemp(prefix="halo_rs_ref_")
+    for seed in DRIVER_SEEDS:
+        inp = fi.build_driver_inputs(seed)
+        assert fi.digest(inp).encode() == d[f"s{seed}__digest"].tobytes()
+        H, W = inp["gt"].shape
+        pm, pi = os.path.join(tmp, f"m{seed}.png"), os.path.join(tmp, f"i{seed}.pth")
+        mask, act, sel = torch.full((H, W), 255, dtype=torch.int64), torch.zeros(H, W, dtype=torch.bool), torch.zeros(H, W, dtype=torch.bool)
+        outs = [(t(inp["logit_lr"], dev), t(inp["embed_lr"], dev))]
+        for rnd in (1, 2):
+            item = {"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [pm], "origin_mask": mask[None], "origin_label": torch.from_numpy(inp["gt"])[None],
+                    "size": torch.tensor([[H, W]]), "active": act[None], "selected": sel[None], "path_to_indicator": [pi], "name": [f"s{seed}"]}
+            RegionSelection(cfg, _Fake(), _Fake(outs), [item], rnd)
+            png = np.array(Image.open(pm), dtype=np.uint8)
+            ind = torch.load(pi)
+            act, sel = ind["active"], ind["selected"]
+            assert [int(sel.sum()), int(act.sum()), int((png != 255).sum())] == list(d[f"s{seed}__r{rnd}_counts"]), rnd
+            assert np.array_equal(files_digest(png, act.numpy(), sel.numpy()), d[f"s{seed}__r{rnd}_files_digest"]), "round %d: not the REFERENCE's files" % rnd
+            mask = torch.from_numpy(png).long()                                    # what the loader reads back (cityscapes.py:234)
+
+
 def test_autograd_gradcheck_float64(dev):
     """Finite-difference check (torch.autograd.gradcheck, float64) of the HIP backward kernels: expmap over the
     last dim and over dim=1 (inside the ball, tanh-clamped + projected, and mixed), HyperMLR w.r.t. x, P, A."""

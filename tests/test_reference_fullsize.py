@@ -92,3 +92,34 @@ def test_live_reference_at_full_size(branch, seed, C, mods):
         assert np.array_equal(res["impurity"], ref["impurity"])           # bit for bit
         nd = int((res["uncertainty"] != ref["uncertainty"]).sum())
         assert nd < 2048, "uncertainty: %d pixels differ (the closed-source logarithm accounts for ~80)" % nd
+
+
+def _driver_cfg():
+    import types
+    return types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+        ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                     BUDGET=0.05, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+
+
+def test_oracle_driver_reproduces_the_references_region_selection_files_at_full_size():
+    """tests/golden/fullsize_driver.npz: digests of the mask PNG and the two indicator maps the REFERENCE's RegionSelection
+    (core/active/build.py:71-186, its own F.interpolate calls included) wrote for the real pipeline's geometry -- a 64-channel
+    float64 embedding at 160 x 320, logits at 640 x 1280, labels 1024 x 2048 -- over two rounds.  The oracle driver, fed the same
+    low-res arrays and carrying its own files from round 1 into round 2, must leave the same bytes."""
+    import oracle.halo_oracle as ho
+    from make_fixtures import DRIVER_SEEDS, files_digest
+    d = np.load(os.path.join(GOLDEN, "fullsize_driver.npz"))
+    cfg = _driver_cfg()
+    for seed in DRIVER_SEEDS:
+        inp = fi.build_driver_inputs(seed)
+        assert fi.digest(inp).encode() == d[f"s{seed}__digest"].tobytes()
+        H, W = inp["gt"].shape
+        mask, act, sel = np.full((H, W), 255, np.int64), np.zeros((H, W), bool), np.zeros((H, W), bool)
+        for rnd in (1, 2):
+            (m8, act, sel, picks), = ho.region_selection(cfg, [dict(logit_lr=inp["logit_lr"], embed_lr=inp["embed_lr"], origin_label=inp["gt"],
+                                                                    active=act, selected=sel, origin_mask=mask)])
+            assert len(picks) == 2331
+            assert [int(sel.sum()), int(act.sum()), int((m8 != 255).sum())] == list(d[f"s{seed}__r{rnd}_counts"]), rnd
+            assert np.array_equal(files_digest(m8, act, sel), d[f"s{seed}__r{rnd}_files_digest"]), "round %d: not the reference's files" % rnd
+            mask = m8.astype(np.int64)
