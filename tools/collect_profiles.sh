@@ -49,6 +49,10 @@ for d in late_round saturated peaked late_round+saturated+peaked plateau; do
   run bench_data_$d.json $B --cpu-images 4 --data $d
 done
 run bench_ripu_peaked.json $B --cpu-images 2 --branch ripu --data peaked
+# the reference's DEFAULT purity under the same stress: near-tie-dense maps, each oracle-checked on 2 images
+for d in gaussian peaked late_round+saturated+peaked; do
+  run bench_hyper_data_$d.json $B --cpu-images 2 --branch hyper --data $d
+done
 for br in ripu hyper; do
   prof trace_$br --kernel-trace --stats --output-format csv -d $OUT/trace_$br -- python3 $R/bench.py --branch $br --cpu-images 0 --steps 8 --warmup 2
 done
@@ -60,6 +64,7 @@ for rep in 1 2 3 4; do
   $B --cpu-images 0 --settle 0 2> /dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('run $rep: %.1f images/s  ms_per_step %.3f  k_feat_reduce %.3f ms (frac %.4f)  rest of the step %.3f ms  flat read of the same tensors %.0f GB/s' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], d['ms_per_step'] - r['avg_launch_ms'], r['flat_read']['GB/s']))" >> $OUT/bench_repeats.txt
 done
+run coissue.txt $R/tools/micro/coissue
 # ---- A/B tools (each ASSERTS that its variants agree bit for bit)
 run ab_feat_map.txt python3 $R/tools/ab_feat_map.py
 run ab_lowres_dma.txt python3 $R/tools/ab_lowres_dma.py

@@ -100,7 +100,8 @@ def main():
     copy_json("bench_under_rocprof.json", RND + "_bench_under_rocprof.json")
     for v in ("f32", "lowres", "lowres_exact", "lowres_gram", "c512", "ripu", "hyper", "pool2975", "resets_kernel", "resets_fills",
               "pool96_one_rank", "pool96_two_ranks_one_gpu", "r02_equivalent", "world8_one_gpu_tiny", "f32_selprio0", "hyper_inline_tail",
-              "data_late_round", "data_saturated", "data_peaked", "data_late_round+saturated+peaked", "data_plateau", "ripu_peaked"):
+              "data_late_round", "data_saturated", "data_peaked", "data_late_round+saturated+peaked", "data_plateau", "ripu_peaked",
+              "hyper_data_gaussian", "hyper_data_peaked", "hyper_data_late_round+saturated+peaked"):
         copy_json("bench_%s.json" % v, RND + "_bench_%s.json" % v)
     stats_csv("trace/*/*_kernel_stats.csv", RND + "_kernel_stats.csv")
     stats_csv("trace_ripu/*/*_kernel_stats.csv", RND + "_kernel_stats_ripu.csv", 25)
@@ -143,7 +144,7 @@ def main():
               "select16_breakdown.txt", "bench_repeats.txt", "ab_feat_map.txt", "region_selection_timing_device_staging.txt",
               "region_selection_timing_python_writer.txt", "host_pieces.txt", "hw_queues.txt", "gram_ab.txt", "op_rate.txt",
               "lowres_overlap_probe.txt", "head_timing.txt", "region_selection_timing_eager_launches.txt", "ab_mlr_epilogue.txt", "mlr_backward.txt",
-              "region_selection_host_floor_tmpfs.txt", "region_selection_host_floor_mask_only.txt", "fuzz_head.txt", "FAILED"):
+              "region_selection_host_floor_tmpfs.txt", "region_selection_host_floor_mask_only.txt", "fuzz_head.txt", "coissue.txt", "pmc_summary.txt", "FAILED"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]
