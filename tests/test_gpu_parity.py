@@ -309,6 +309,24 @@ def test_odd_sizes_take_the_scalar_paths(dev):
         assert bits_equal(s[0].cpu().numpy(), so) and bits_equal(i[0].cpu().numpy(), io) and bits_equal(u[0].cpu().numpy(), uo)
 
 
+@pytest.mark.parametrize("K", [16, 17, 100, 256, 300, 5000])
+def test_histogram_class_sum_follows_torchs_cascade_for_any_bin_count(dev, K):
+    """compute_region_impurity sums K one-hot channels with torch.sum, whose accumulator cascade flushes every 16 / 256 / 4096 terms
+    (oracle: ATen's loop literally; device: the flush decided from the class index alone, ClassSum in halo_score.hip): both window
+    kernels against the oracle bit for bit with bins on either side of every flush boundary."""
+    from halo_amd.core.active.floating_region import score_maps
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(K)
+    H, W, C, O = 40, 72, 6, 19
+    logit = rng.standard_normal((1, O, H, W)).astype(np.float32)
+    emb = rng.standard_normal((1, C, H, W)) * rng.uniform(0.01, 0.6, (1, 1, H, W))          # radii spread over the whole bin range
+    gt = rng.integers(0, O, (H, W)).astype(np.int64)
+    for size, env in ((3, {}), (3, {"HALO_IMPURITY_GENERIC": "1"}), (5, {})):
+        so, io, uo = ho.floating_region_score(logit, emb, "entropy", "hyper", True, gt, size=size, purity_type="hyper", K=K)
+        s, i, u = _with_env(env, lambda: score_maps(t(logit, dev), t(emb, dev), "entropy", "hyper", True, t(gt, dev)[None], size=size, K=K))
+        assert bits_equal(i[0].cpu().numpy(), io) and bits_equal(u[0].cpu().numpy(), uo) and bits_equal(s[0].cpu().numpy(), so), (K, size, env)
+
+
 def test_wider_windows(dev):
     """RADIUS_K = 2 (5x5 windows) and a 7x7 entropy window: the generic window paths."""
     from halo_amd.core.active.floating_region import score_maps
