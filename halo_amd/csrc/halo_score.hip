@@ -547,7 +547,10 @@ __global__ void __launch_bounds__(TPB) k_quantize(const T *__restrict__ r, const
         const float lo = (float)(-0.5 + 1e-5), hi = (float)((double)K - 0.5 - 1e-5);
         p = p < lo ? lo : p;
         p = p > hi ? hi : p;
-        pred[(size_t)b * hw + i] = (TO)__builtin_rintf(p);
+        // float32 and K > 128: K - 0.5 - 1e-5 rounds to K - 0.5, which rounds half-even to K -- one past the last bin, where the
+        // reference's F.one_hot raises.  The last bin takes it here (and in the oracle).
+        const float q = __builtin_rintf(p);
+        pred[(size_t)b * hw + i] = (TO)(q > (float)(K - 1) ? (float)(K - 1) : q);
     }
 }
 

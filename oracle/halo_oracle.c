@@ -577,7 +577,10 @@ static void quantize_f32(float *r, i64 n, i64 K, i64 *pred)
         float p = r[i] * (float)K - 0.5f;
         if (p < lo) p = lo;
         if (p > hi) p = hi;
-        pred[i] = (i64)rintf(p);
+        /* float32 and K > 128: (float)(K - 0.5 - 1e-5) is K - 0.5, which rounds half-even to K -- one past the last bin, where the
+         * reference's F.one_hot raises ("Class values must be smaller than num_classes").  The last bin takes it. */
+        const float q = rintf(p);
+        pred[i] = (i64)(q > (float)(K - 1) ? (float)(K - 1) : q);
     }
 }
 

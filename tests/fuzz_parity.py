@@ -50,7 +50,7 @@ def one_case(i):
     size = int(rng.choice([1, 3, 3, 3, 5, 7]))
     if pad == "reflect" and size // 2 >= min(H, W):
         size = 3
-    K = int(rng.choice([2, 10, 100]))
+    K = int(rng.choice([2, 10, 100, 100, 17, 300, 4100]))          # (bins on either side of the class sum's flush boundaries: 16, 256, 4096)
     f32 = rng.random() < 0.25
     c = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
     psize = 3 if pur == "hyper" else size

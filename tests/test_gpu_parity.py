@@ -323,7 +323,8 @@ def test_histogram_class_sum_follows_torchs_cascade_for_any_bin_count(dev, K):
     gt = rng.integers(0, O, (H, W)).astype(np.int64)
     for size, env in ((3, {}), (3, {"HALO_IMPURITY_GENERIC": "1"}), (5, {})):
         so, io, uo = ho.floating_region_score(logit, emb, "entropy", "hyper", True, gt, size=size, purity_type="hyper", K=K)
-        s, i, u = _with_env(env, lambda: score_maps(t(logit, dev), t(emb, dev), "entropy", "hyper", True, t(gt, dev)[None], size=size, K=K))
+        # (the module forces the 'hyper' purity window to 3 x 3 whatever `size` is, floating_region.py:54-55; score_maps takes it explicitly)
+        s, i, u = _with_env(env, lambda: score_maps(t(logit, dev), t(emb, dev), "entropy", "hyper", True, t(gt, dev)[None], size=size, purity_size=3, K=K))
         assert bits_equal(i[0].cpu().numpy(), io) and bits_equal(u[0].cpu().numpy(), uo) and bits_equal(s[0].cpu().numpy(), so), (K, size, env)
 
 
