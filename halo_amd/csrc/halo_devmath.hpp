@@ -227,13 +227,15 @@ static __device__ const double logf_tab_[128][2] = {
 
 // logf of the positive normal float whose bits are u, plus e0 * ln 2: v = bits - bits(sqrt(1/2)) holds the exponent of the
 // mantissa range [sqrt(1/2), sqrt(2)) in its top 9 bits (arithmetic shift) and the table index in the next 7.
-__device__ __forceinline__ float logf_core_(uint32_t u, int e0)
+// `tab`: the table to read -- logf_tab_ itself (device memory: a 16-byte gather through the vector cache per logarithm) or a copy of it
+// a kernel staged in LDS (stage_logf_table): kernels that stream HBM through the same texture path read it from LDS instead.
+__device__ __forceinline__ float logf_core_t(uint32_t u, int e0, const double (*tab)[2])
 {
     const uint32_t v = u - 0x3f3504f3u;
     const int e = e0 + ((int)v >> 23);
     const float m = __uint_as_float(u - (v & 0xff800000u));
     const int j = (int)((v >> 16) & 0x7fu);
-    const double r = logf_tab_[j][0], L = logf_tab_[j][1];
+    const double r = tab[j][0], L = tab[j][1];
     const double z = __builtin_fma((double)m, r, -1.0);              // exact: 24 x 16 bits
     const double z2 = z * z;
     double q = -0x1.5555555555555p-3;                                // -1/6
@@ -246,8 +248,21 @@ __device__ __forceinline__ float logf_core_(uint32_t u, int e0)
     return (float)(y + p);
 }
 
+__device__ __forceinline__ float logf_core_(uint32_t u, int e0) { return logf_core_t(u, e0, logf_tab_); }
+
 // logf for positive normal finite x
 __device__ __forceinline__ float det_logf_core(float x) { return logf_core_(__float_as_uint(x), 0); }
+__device__ __forceinline__ float det_logf_core(float x, const double (*tab)[2]) { return logf_core_t(__float_as_uint(x), 0, tab); }
+
+#ifndef HALO_DEVMATH_HOST_CHECK
+// copy of the logarithm's table in LDS: every thread of the block calls this before its first logarithm (a barrier inside)
+template <int NTHREADS>
+__device__ __forceinline__ void stage_logf_table(double (*lds_tab)[2])
+{
+    for (int j = threadIdx.x; j < 128; j += NTHREADS) { lds_tab[j][0] = logf_tab_[j][0]; lds_tab[j][1] = logf_tab_[j][1]; }
+    __syncthreads();
+}
+#endif
 
 __device__ __forceinline__ float det_logf(float x)
 {

@@ -103,6 +103,12 @@ __global__ void __launch_bounds__(FIN_TPB) k_minmax_finalize2(const double *__re
 // independent chains (that fills the two-cycle hazard slots between v_cmp / v_cndmask pairs).  Built without SLP
 // vectorisation (_build.py): packed v_pk_fma_f32 would save 10 % of the instructions and cost 40 VGPRs.
 
+// The logarithm's 2 KB table: read from an LDS copy in the kernels below (HALO_LOGF_LDS=0 at build time: from device memory through
+// the vector cache, the A/B twin -- same values either way).
+#ifndef HALO_LOGF_LDS
+#define HALO_LOGF_LDS 1
+#endif
+
 // torch.sum over the class axis in ATen's order (SumKernel.cpp, multi_row_sum; floating_region.py:72,119): terms enter acc[0]
 // one by one; every 16 terms acc[0] is flushed into acc[1], every 256 acc[1] into acc[2], every 4096 acc[2] into acc[3]; the result
 // is ((acc[0] + acc[1]) + acc[2]) + acc[3].  For 19 classes: (t16 + t17 + t18) + (t0 + ... + t15).  Stated here on the class
@@ -241,7 +247,7 @@ __device__ __forceinline__ void softmax_general(float (&p)[NP][O_T])
 // From the probabilities of NP pixels: ent (per unc_type) and pred (per pur_type).  LEAN: p came from softmax_lean.
 template <int O_T, int NP, bool LEAN>
 __device__ __forceinline__ void finish_px(float (&p)[NP][O_T], int unc_type, int pur_type, const long long (&g)[NP],
-                                          float (&ent)[NP], int (&pred)[NP], bool want_pred = true)
+                                          float (&ent)[NP], int (&pred)[NP], bool want_pred = true, const double (*ltab)[2] = logf_tab_)
 {
     int am[NP];               // torch.argmax: first maximal class
     float best[NP];
@@ -266,7 +272,7 @@ __device__ __forceinline__ void finish_px(float (&p)[NP][O_T], int unc_type, int
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const float q = p[j][c] + 1e-6f;
-                a0[j] = a0[j] + (-p[j][c]) * (LEAN ? det_logf_core(q) : det_logf(q));
+                a0[j] = a0[j] + (-p[j][c]) * (LEAN ? det_logf_core(q, ltab) : det_logf(q));
             }
             if ((c & 15) == 15 && c + 1 < O_T) {
 #pragma unroll
@@ -300,6 +306,13 @@ __global__ void __launch_bounds__(TPB) k_logit_maps(const float *__restrict__ lo
 {
     const int b = blockIdx.y;
     const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * VEC;
+#if HALO_LOGF_LDS
+    __shared__ double s_ltab[128][2];
+    stage_logf_table<TPB>(s_ltab);
+    const double (*ltab)[2] = s_ltab;
+#else
+    const double (*ltab)[2] = logf_tab_;
+#endif
     if (i0 >= hw) return;
     const float *lp = logit + (size_t)b * bstride + i0;
     const bool need_gt = unc_type == HALO_UNC_ORACLE_ACC || pur_type == HALO_PUR_ORACLE_RIPU;
@@ -320,7 +333,7 @@ __global__ void __launch_bounds__(TPB) k_logit_maps(const float *__restrict__ lo
 #pragma unroll
     for (int j = 0; j < VEC; ++j) g[j] = need_gt ? gt[(size_t)b * hw + i0 + j] : 0;
     if (softmax_lean<O_T, VEC>(v)) {
-        finish_px<O_T, VEC, true>(v, unc_type, pur_type, g, e, pr, pred != nullptr);
+        finish_px<O_T, VEC, true>(v, unc_type, pur_type, g, e, pr, pred != nullptr, ltab);
     } else {
 #pragma unroll 1
         for (int j = 0; j < VEC; ++j) px_general(lp + j, O_T, hw, 0, unc_type, pur_type, g[j], e[j], pr[j]);
@@ -415,6 +428,13 @@ __global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, HA
     const unsigned lane0 = threadIdx.x * VEC;
     const long long i0 = blk0 + lane0;
     const bool live = i0 < hw;
+#if HALO_LOGF_LDS
+    __shared__ double s_ltab[FO > 0 ? 128 : 1][2];
+    if constexpr (FO > 0) stage_logf_table<FTPB>(s_ltab);
+    const double (*ltab)[2] = s_ltab;
+#else
+    const double (*ltab)[2] = logf_tab_;
+#endif
     T acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = (T)0;
@@ -452,7 +472,7 @@ __global__ void __launch_bounds__(FTPB) __attribute__((amdgpu_waves_per_eu(1, HA
 #pragma unroll
                     for (int j = 0; j < NP; ++j) gz[j] = 0;
                     if (softmax_lean<FO, NP>(lv)) {
-                        finish_px<FO, NP, true>(lv, unc_type, HALO_PUR_NONE, gz, e, pr, false);
+                        finish_px<FO, NP, true>(lv, unc_type, HALO_PUR_NONE, gz, e, pr, false, ltab);
                     } else {
 #pragma unroll 1
                         for (int j = 0; j < NP; ++j) px_general(lp + off + j, FO, hw, 0, unc_type, HALO_PUR_NONE, 0, e[j], pr[j]);
@@ -2146,6 +2166,13 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__
     const int b = blockIdx.y;
     const long long hw = (long long)H * W;
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+#if HALO_LOGF_LDS
+    __shared__ double s_ltab[128][2];
+    stage_logf_table<TPB>(s_ltab);
+    const double (*ltab)[2] = s_ltab;
+#else
+    const double (*ltab)[2] = logf_tab_;
+#endif
     if (i >= hw) return;
     const int y = (int)(i / W), x = (int)(i % W);
     const Taps<float> ty = make_taps<float>(y, sh, h), tx = make_taps<float>(x, sw, w);
@@ -2165,7 +2192,7 @@ __global__ void __launch_bounds__(TPB) k_logit_maps_lr(const float *__restrict__
     float e[1];
     int pr[1];
     if (softmax_lean<O_T, 1>(p)) {
-        finish_px<O_T, 1, true>(p, unc_type, pur_type, g, e, pr, pred != nullptr);
+        finish_px<O_T, 1, true>(p, unc_type, pur_type, g, e, pr, pred != nullptr, ltab);
     } else {
         softmax_general<O_T, 1>(p);
         finish_px<O_T, 1, false>(p, unc_type, pur_type, g, e, pr, pred != nullptr);
