@@ -41,32 +41,12 @@ def reference():
 
 
 def run_reference(inp, branch, O=19, n=None):
-    """-> dict(score, impurity, uncertainty, active, selected, active_mask, picks): the reference's own outputs."""
+    """-> dict(score, impurity, uncertainty, active, selected, active_mask, picks): the reference's own outputs
+    (tests/golden/make_fixtures.py:run_reference_fullsize, the function that produced tests/golden/fullsize_picks.npz)."""
+    from make_fixtures import run_reference_fullsize
     cfg, hyp, fr, ab = reference()
-    unc, pur, norm, mrad, K = fi.BRANCHES[branch]
     cfg.MODEL.NUM_CLASSES = O
-    logit = torch.from_numpy(inp["logit"])
-    embed = torch.from_numpy(inp["embed"])
-    gt = torch.from_numpy(inp["gt"])
-    H, W = gt.shape
-    n = fi.n_regions(H, W) if n is None else n
-    frs = fr.FloatingRegionScore(in_channels=O, size=3, purity_type=pur, K=K)
-    with torch.no_grad():
-        score, imp, uncm = frs(logit.clone(), decoder_out=embed, unc_type=unc, pur_type=pur, normalize=norm,
-                               ground_truth=gt.clone())
-    active = torch.from_numpy(inp["prior"].copy())
-    selected = torch.zeros(H, W, dtype=torch.bool)
-    amask = torch.full((H, W), 255, dtype=torch.int64)
-    score = score.clone()
-    score[active] = -float("inf")                                                   # build.py:146
-    s0 = score.numpy().copy()
-    ab.select_pixels_to_label(score, n, 1, mrad, active, selected, amask, gt)        # build.py:151-160
-    # the table: the oracle's selector replayed on the REFERENCE's score map, checked against the reference's masks
-    a2, s2, m2 = inp["prior"].copy(), np.zeros((H, W), bool), np.full((H, W), 255, np.int64)
-    _, _, _, _, picks = ho.select_pixels_to_label(s0.copy(), n, 1, mrad, a2, s2, m2, inp["gt"], return_picks=True)
-    assert np.array_equal(a2, active.numpy()) and np.array_equal(s2, selected.numpy()) and np.array_equal(m2, amask.numpy()), \
-        "the replayed table does not reproduce the reference's masks"
-    return dict(score=s0, impurity=imp.numpy(), uncertainty=uncm.numpy(), active=a2, selected=s2, active_mask=m2, picks=picks)
+    return run_reference_fullsize(fr, ab, inp, branch, O=O, n=n)
 
 
 def run_oracle(inp, branch, O=19, n=None):
@@ -124,7 +104,8 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     mods = tuple(m for m in a.mods.split("+") if m)
-    print(f"# oracle vs reference (torch {torch.__version__}, {torch.backends.cpu.get_cpu_capability()}), branch {a.branch} "
+    print(f"# oracle vs reference (torch {torch.__version__}, ATen {torch.backends.cpu.get_cpu_capability()}, "
+          f"MKL_ENABLE_INSTRUCTIONS={os.environ.get('MKL_ENABLE_INSTRUCTIONS', 'unset: the best the CPU has')}), branch {a.branch} "
           f"{fi.BRANCHES[a.branch]}, {a.height}x{a.width}, C={a.channels}, mods={mods or '-'}, f32 embedding={a.f32}", flush=True)
     ok = tot = 0
     for seed in parse_seeds(a.seeds):
