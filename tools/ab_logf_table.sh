@@ -1,3 +1,9 @@
+#!/bin/bash
+# A/B on one MI355X box: the logarithm's 2 KB table read from an LDS copy (the default build) against a -DHALO_LOGF_LDS=0 build that
+# gathers it from device memory through the vector cache (halo_amd/csrc/variants/libhalo_hip_logf_global.so, loaded through
+# HALO_LIB_PATH).  Same values either way (the GPU suite passes with both); prints images/s, ms per step and the feature kernel's
+# average launch per bench line.  Run from the repository root: bash tools/ab_logf_table.sh
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 V=halo_amd/csrc/variants/libhalo_hip_logf_global.so
 for rep in 1 2; do
 for args in "" "--feat-dtype f32" "--branch ripu" "--source lowres"; do

@@ -70,6 +70,9 @@ run ab_feat_map.txt python3 $R/tools/ab_feat_map.py
 run ab_lowres_dma.txt python3 $R/tools/ab_lowres_dma.py
 run gram_ab.txt python3 $R/tools/ab_gram.py
 run ab_mlr_epilogue.txt python3 $R/tools/ab_mlr_epilogue.py
+# (the logarithm's table from LDS against a -DHALO_LOGF_LDS=0 build reading it from device memory; the variant library travels when it
+#  was built in the container: python -c "from halo_amd import _build; _build.FLAGS.append('-DHALO_LOGF_LDS=0'); _build._build_locked(False, objdir='/tmp/obj_nolds', so='halo_amd/csrc/variants/libhalo_hip_logf_global.so')")
+[ -f $R/halo_amd/csrc/variants/libhalo_hip_logf_global.so ] && (cd $R && run ab_logf_table.txt bash $R/tools/ab_logf_table.sh)
 # ---- selection, the RegionSelection driver, the head tail, training ops
 METHODS=auto,serial run select_timing.txt python3 $R/tools/time_select.py
 METHODS=auto RANGED=1 run select_timing_ranged.txt python3 $R/tools/time_select.py
