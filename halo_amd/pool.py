@@ -19,7 +19,6 @@ still proposes its n_regions greedy picks, the gathered tables are re-ranked poo
 image's files are written from the KEPT prefix of its table -- also independent of the world size.
 """
 import math
-import os
 
 import torch
 import torch.distributed as dist
