@@ -88,10 +88,13 @@ def test_concurrent_writers_under_thread_sanitizer(tmp_path):
     out = tmp_path / "files"
     out.mkdir()
     # (setarch -R: ThreadSanitizer of this gcc cannot map its shadow under the kernel's high-entropy ASLR)
-    cmd = [exe, str(out), "16", "4"]
-    if shutil.which("setarch"):
-        cmd = ["setarch", os.uname().machine, "-R"] + cmd
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    base = [exe, str(out), "16", "4"]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    r = None
+    for cmd in ([["setarch", os.uname().machine, "-R"] + base] if shutil.which("setarch") else []) + [base]:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        if "0 failed calls" in r.stdout or "ThreadSanitizer: data race" in r.stderr:
+            break                                     # the program ran (clean or not); anything else: setarch refused, try without it
     if "unexpected memory mapping" in r.stderr:
         pytest.skip("ThreadSanitizer cannot run under this kernel's address-space layout")
     assert r.returncode == 0 and "0 failed calls" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
