@@ -36,6 +36,7 @@ SIGNATURES = {
     "halo_pdist": (_int, [_vp, _vp, _vp, _i64, _i64, _dbl, _vp]),
     "halo_hypermlr_workspace_bytes": (_sz, [_i64, _i64]),
     "halo_hypermlr_logits": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _vp, _sz, _vp]),
+    "halo_head_tail": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _vp, _sz, _vp]),
     "halo_expmap0_project_bwd": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _dbl, _vp]),
     "halo_hypermlr_bwd_terms": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _sz, _vp]),
@@ -86,7 +87,7 @@ SIGNATURES = {
 
 # must equal HALO_ABI_VERSION of include/halo_hip.h; bumped whenever an exported signature changes, so a stale
 # library with the same symbol names but older argument lists is refused instead of being called with shifted arguments
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lock = threading.Lock()
 _handle = None

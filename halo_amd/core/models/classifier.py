@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..configs import cfg
-from ..utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners
+from ..utils.hyperbolic import HyperMapper, HyperMLR, bilinear_align_corners, head_tail_fused
 
 
 def hyper_head_tail(feat, mapper: HyperMapper, conv_seg: HyperMLR, size=None, resize_embed=False):
@@ -43,8 +43,14 @@ def hyper_head_tail(feat, mapper: HyperMapper, conv_seg: HyperMLR, size=None, re
                 embed = F.interpolate(embed, size=size, mode="bilinear", align_corners=True)
         return out, embed
     with torch.no_grad():
-        embed = mapper.expmap(feat, dim=1)
-        out = conv_seg._hyper_logits(embed, out_dtype=torch.float32)
+        # the heads' own shape (64 channels): expmap -> HyperMLR -> .float() in ONE kernel, the embedding never re-read; any other
+        # shape: the two calls (same bits either way)
+        fused = head_tail_fused(feat, conv_seg.P_MLR, conv_seg.A_MLR, conv_seg.c) if (feat.is_cuda and feat.dim() == 4 and float(mapper.c) == float(conv_seg.c)) else None
+        if fused is not None:
+            out, embed = fused
+        else:
+            embed = mapper.expmap(feat, dim=1)
+            out = conv_seg._hyper_logits(embed, out_dtype=torch.float32)
         if size is not None:
             out = bilinear_align_corners(out, size)
             if resize_embed:

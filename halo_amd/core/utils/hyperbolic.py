@@ -163,6 +163,29 @@ def _mlr_forward(x, P, A, c, out_dtype):
     return out
 
 
+def head_tail_fused(feat, P, A, c, out_dtype=torch.float32):
+    """embed = expmap(feat, dim=1) (float64) and out = HyperMLR(embed) in ONE kernel (halo_head_tail: the heads' own 64 channels,
+    <= 32 classes, an even pixel count) -- or None when the shape is not served; the caller then makes the two calls, whose results
+    the fused kernel reproduces bit for bit.  Inference only (no autograd)."""
+    dev = _lib.require_device(feat, P, A)
+    if feat.dim() != 4 or feat.dtype != torch.float32 or feat.shape[1] != 64 or feat.numel() == 0:
+        return None
+    feat = feat.contiguous()
+    B, Cc, H, W = feat.shape
+    O = P.shape[0]
+    embed = torch.empty((B, Cc, H, W), dtype=torch.float64, device=dev)
+    out = torch.empty((B, O, H, W), dtype=out_dtype, device=dev)
+    L = _lib.lib()
+    nws = L.halo_hypermlr_workspace_bytes(O, Cc)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    rc = L.halo_head_tail(_lib.ptr(feat), _lib.ptr(P.detach().contiguous()), _lib.ptr(A.detach().contiguous()), _lib.ptr(embed), _lib.ptr(out),
+                          _lib.dtype_code(out), B, Cc, O, H * W, float(c), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+    if rc == 1:
+        return None
+    _lib.check(rc, "halo_head_tail")
+    return out, embed
+
+
 def _pixel_contraction(D, X, chunk=512):
     """sum over batch and pixels of D[b,:,n] X[b,:,n]^T  ->  (rows(D), rows(X)).  The output is tiny (2O x C)
     and the contraction very long (B*H*W): as ONE GEMM the BLAS library runs it on a handful of workgroups

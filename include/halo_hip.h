@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 7
+#define HALO_ABI_VERSION 8
 
 enum { HALO_F32 = 0, HALO_F64 = 1 };
 
@@ -81,6 +81,14 @@ size_t halo_hypermlr_workspace_bytes(int64_t O, int64_t C);
 int halo_hypermlr_logits(const double *x, const double *P, const double *A, void *out, int out_dtype,
                          int64_t B, int64_t C, int64_t O, int64_t hw, double c, void *workspace,
                          size_t workspace_bytes, void *stream);
+
+/* The inference tail of both hyperbolic heads in one call (classifier.py:364-379: ASPP_Classifier_V2_Hyper.forward, :552-558:
+ * DepthwiseSeparableASPP_Hyper.forward):  embed = mapper.expmap(feat, dim=1)  (B,C,hw) f64;  out = conv_seg(embed)[.float()]
+ * (B,O,hw) in out_dtype.  feat (B,C,hw) f32.  Returns 1 and enqueues NOTHING when the shape is not served by the fused kernel
+ * (C != 64, O > 32, odd hw, unaligned bases): the caller then makes the two calls above, whose results this call reproduces bit
+ * for bit.  workspace: halo_hypermlr_workspace_bytes(O, C). */
+int halo_head_tail(const float *feat, const double *P, const double *A, double *embed, void *out, int out_dtype, int64_t B,
+                   int64_t C, int64_t O, int64_t hw, double c, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the head tail for training (classifier.py:553-554 under autograd).
  *  - halo_expmap0_project_bwd: gx = J^T gy for y = HyperMapper.expmap(x, dim); gy f64, gx in x's dtype.

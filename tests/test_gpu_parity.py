@@ -1328,6 +1328,55 @@ def test_hypermlr_matrix_core_path_matches_valu_path(golden, dev):
     assert max_abs_diff(got, ho.hypermlr(x, mlr.P_MLR.detach().cpu().numpy(), mlr.A_MLR.detach().cpu().numpy(), 1.0)) < 1e-11
 
 
+@pytest.mark.parametrize("B,O,h,w,c,out_dtype", [(2, 19, 160, 320, 1.0, "float32"), (1, 19, 6, 10, 1.0, "float32"), (1, 16, 10, 14, 0.7, "float64"),
+                                                 (3, 2, 4, 6, 1.0, "float32"), (1, 32, 8, 12, 2.0, "float32"), (1, 24, 9, 14, 1.0, "float64"),
+                                                 (1, 19, 1, 2, 1.0, "float32")])
+def test_fused_head_tail_equals_the_two_kernel_path_bit_for_bit(dev, B, O, h, w, c, out_dtype):
+    """halo_head_tail (expmap -> project -> HyperMLR -> .float() in ONE kernel at the heads' own 64 channels, classifier.py:364-379,
+    552-558) against the two calls it replaces: the SAME embedding and the SAME logits, bit for bit -- ordinary pixels, pixels far
+    outside the ball (tanh clamp + projection), an exact-origin pixel, pixel counts that leave the last 32-pixel tile ragged,
+    2 / 16 / 19 / 24 / 32 classes (all three column-tile counts), float32 and float64 logits, curvatures != 1; and the embedding
+    within the oracle's tolerance.  HALO_HEAD_TAIL_SPLIT=1 and shapes the kernel does not serve take the two-kernel path."""
+    from halo_amd.core.models.classifier import hyper_head_tail
+    from halo_amd.core.utils.hyperbolic import HyperMapper, HyperMLR, head_tail_fused
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(B * 1000 + O)
+    C = 64
+    z = (rng.standard_normal((B, C, h, w)) * 0.1).astype(np.float32)
+    z[0, :, 0, 0] *= 400.0                       # tanh clamp + project
+    if h * w > 6:
+        z[0, :, h // 2, w // 3] *= 60.0          # project only
+        z[-1, :, h - 1, w - 1] = 0.0             # exact origin
+    mapper = HyperMapper(c)
+    mlr = HyperMLR(C, O, c=c).to(dev)
+    odt = getattr(torch, out_dtype)
+    zt = t(z, dev)
+    with torch.no_grad():
+        fused = head_tail_fused(zt, mlr.P_MLR, mlr.A_MLR, c, odt)
+        if O > 24:               # 32 classes: the weight image + eight waves' staging rows exceed the 160 KB of LDS -> the two kernels
+            assert fused is None
+            o1, e1 = hyper_head_tail(zt, mapper, mlr)
+            assert bits_equal(e1.cpu().numpy(), mapper.expmap(zt, dim=1).cpu().numpy())
+            return
+        assert fused is not None, "the fused kernel serves this shape"
+        out_f, emb_f = fused
+        emb_s = mapper.expmap(zt, dim=1)
+        out_s = mlr._hyper_logits(emb_s, out_dtype=odt)
+    assert emb_f.dtype == torch.float64 and out_f.dtype == odt
+    assert bits_equal(emb_f.cpu().numpy(), emb_s.cpu().numpy()), "embedding differs from k_expmap0_project's"
+    assert bits_equal(out_f.cpu().numpy(), out_s.cpu().numpy()), "logits differ from k_hypermlr_mfma_res's"
+    assert np.abs(emb_f.cpu().numpy() - ho.expmap(z, c, dim=1)).max() < 1e-14
+    # the head-tail function itself: fused by default, the two kernels under the switch, other channel counts as before
+    with torch.no_grad():
+        o1, e1 = hyper_head_tail(zt, mapper, mlr)
+        o2, e2 = _with_env({"HALO_HEAD_TAIL_SPLIT": "1"}, lambda: hyper_head_tail(zt, mapper, mlr))
+        o3, e3 = hyper_head_tail(zt[:, :48].contiguous(), mapper, HyperMLR(48, O, c=c).to(dev))
+    assert bits_equal(o1.cpu().numpy(), o2.cpu().numpy()) and bits_equal(e1.cpu().numpy(), e2.cpu().numpy())
+    assert e3.shape[1] == 48 and bool(torch.isfinite(o3).all())
+    if out_dtype == "float32":
+        assert bits_equal(o1.cpu().numpy(), out_f.cpu().numpy())
+
+
 def test_hypermlr_epilogue_forms_agree(dev):
     """The matrix-core HyperMLR's one-quotient epilogue (default) against the reference-order statement it replaced
     (HALO_MLR_EPI_REF=1: also its rare arm): ordinary embeddings, every x on the ball's boundary, curvatures != 1, an exact-origin

@@ -67,7 +67,16 @@ def main():
             e = m.expmap(z, dim=1)
             o = mlr._hyper_logits(e, out_dtype=torch.float32)
             return bilinear_align_corners(o, up), e
-        line(f"{tag}: whole tail (expmap -> HyperMLR -> .float() -> resize of the logits)", n * 12 + n * 8 + O * h * w * 8 + O * up[0] * up[1] * 4, tail)
+        line(f"{tag}: whole tail, two kernels (expmap -> HyperMLR -> .float() -> resize of the logits)", n * 12 + n * 8 + O * h * w * 8 + O * up[0] * up[1] * 4, tail)
+        if C == 64:          # the heads' own channel count: halo_head_tail, one kernel for expmap -> project -> HyperMLR -> .float()
+            from halo_amd.core.utils.hyperbolic import head_tail_fused
+            line(f"{tag}: FUSED expmap + HyperMLR (halo_head_tail: embedding written, never re-read)", n * 12 + O * h * w * 4,
+                 lambda: head_tail_fused(z, mlr.P_MLR, mlr.A_MLR, 1.0))
+
+            def tail_fused():
+                o, e = head_tail_fused(z, mlr.P_MLR, mlr.A_MLR, 1.0)
+                return bilinear_align_corners(o, up), e
+            line(f"{tag}: whole tail, FUSED (what the head's forward runs under no_grad)", n * 12 + O * h * w * 8 + O * up[0] * up[1] * 4, tail_fused)
 
 
 if __name__ == "__main__":
