@@ -16,11 +16,12 @@ def configure(hw_queues=None):
     process it is imported into).
 
     hw_queues: ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and the variable is read once, when the
-    HIP runtime initialises.  The acquisition keeps up to six streams busy (RegionSelection: 4 side streams + the caller's;
-    bench.py: 1 + 3 + 1) and measured fastest on TWO queues (kernels of different streams still overlap inside a queue; with
-    three or more, the short kernels that follow a long one on the scoring stream start late: bench.py +1.4 %, --source lowres
-    +12 %, --branch ripu +9 %, profiles/archive/r03_hw_queues.txt).  That was measured on the acquisition ALONE: the same setting also
-    governs the training iterations' streams (DDP / RCCL communication, H2D copies), which is why it is the caller's decision.
+    HIP runtime initialises.  Pool scoring in 16-image steps (bench.py: 1 + 3 + 1 streams) measures fastest on TWO queues (kernels
+    of different streams still overlap inside a queue; with three or more, the short kernels that follow a long one on the scoring
+    stream start late: bench.py +2 %, --source lowres +10 %, --branch ripu +6 %).  RegionSelection at the reference's loader batch
+    of one does NOT: an image's GPU time is mostly one single-workgroup selection sweep, a queue holds one of them, and the driver
+    runs 0.47-0.51 ms/image on ROCm's default of four against 0.58 on two (profiles/r06_hw_queues.txt) -- leave the default alone
+    for it.  The setting also governs the training iterations' streams (DDP / RCCL communication, H2D copies): the caller's decision.
     Call this before the first HIP call of the process (bench.py and tools/ do); returns the value in force, or raises
     RuntimeError when the runtime is already up with a different one."""
     if hw_queues is None:

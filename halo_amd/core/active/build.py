@@ -236,22 +236,27 @@ class _SlotGraph:
 
 _SIDE = {}
 _SLOTS = {}
-_QUEUE_WARNED = False
+_CAPTURE = {}
 
 
-def _check_hw_queues(n_streams):
-    """Tell the user once that the acquisition alone measured faster on two hardware queues than on ROCm's default of four, when
-    nobody chose a value.  Only a hint: the setting is process-wide (it also governs the training iterations' streams), so the
-    package never sets it by itself -- halo_amd.configure(hw_queues=2), INTEGRATION.md section 3."""
-    global _QUEUE_WARNED
-    if _QUEUE_WARNED or "GPU_MAX_HW_QUEUES" in os.environ:
-        return
-    _QUEUE_WARNED = True
-    import warnings
-    warnings.warn("halo_amd RegionSelection drives %d side streams beside the caller's and GPU_MAX_HW_QUEUES is unset (ROCm's "
-                  "default: 4 hardware queues).  The acquisition alone measured 2-12 %% faster on 2; if that suits the training "
-                  "process too, call halo_amd.configure(hw_queues=2) (or export the variable) before the first HIP call "
-                  "(INTEGRATION.md section 3)." % n_streams, RuntimeWarning, stacklevel=3)
+def _capture_stream(dev):
+    """The stream a slot's launch group is RECORDED on: one HIP stream per device, created outside torch's stream pool and
+    used for nothing else.  A recording that fails (the runtime invalidates a capture for reasons outside this code: seen once
+    in ~1700 captures under GPU_MAX_HW_QUEUES=8) leaves its stream in capture mode for good on ROCm 7.2 -- hipStreamEndCapture
+    returns the error without ending anything -- so it must not be the slot's own stream (every later copy, launch and event on
+    it failed: the round died in a writer thread's event wait) nor one of torch's 32 pooled streams (handed out again later).
+    The graph replays on the slot's stream whatever stream recorded it."""
+    s = _CAPTURE.get(dev.index)
+    if s is None:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")                       # the runtime torch already loaded
+        raw = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            err = hip.hipStreamCreateWithFlags(ctypes.byref(raw), ctypes.c_uint(1))     # hipStreamNonBlocking
+        if err != 0 or not raw.value:
+            raise RuntimeError("hipStreamCreateWithFlags failed (%d)" % err)
+        s = _CAPTURE[dev.index] = torch.cuda.ExternalStream(raw.value, device=dev)
+    return s
 
 
 def _side_streams(dev, n):
@@ -363,13 +368,15 @@ def _launch(prm, logits_lr, embed_lr, size, origin_mask, origin_label, active_in
                         g_.logits, g_.embed = torch.empty_like(logits_lr), torch.empty_like(embed_lr)
                         g_.graph = torch.cuda.CUDAGraph()
                         from .floating_region import private_workspaces
-                        with private_workspaces() as pw, torch.cuda.graph(g_.graph, stream=stream, capture_error_mode="thread_local"):
+                        with private_workspaces() as pw, torch.cuda.graph(g_.graph, stream=_capture_stream(dev), capture_error_mode="thread_local"):
                             g_.picks, g_.npk = body(g_.logits, g_.embed)
                         g_.out_picks = rec.out_picks              # the pinned table the recording copies into
                         g_.scratch = pw.held                      # the recording owns the scratch buffers it points to
                         slot.graphs[gkey] = g_
                     except Exception as exc:                      # capture refused (driver / torch build): stay eager, say so once
                         slot.graphs[gkey] = -(1 << 30)
+                        _CAPTURE.pop(dev.index, None)             # that stream may be stuck in capture mode: never used again
+                        torch.cuda.set_stream(stream)             # (torch's context manager raises before it restores the stream)
                         import warnings
                         warnings.warn("halo_amd RegionSelection: HIP graph capture of the launch group failed (%s); launching eagerly" % exc,
                                       RuntimeWarning)
@@ -798,7 +805,6 @@ def RegionSelection(cfg, feature_extractor, classifier, tgt_epoch_loader, round_
         writer_threads = host_threads_per_rank(cap=8)
     depth = max(1, in_flight)
     side = _side_streams(dev, max(1, min(streams, depth)))
-    _check_hw_queues(len(side))
     # the slots (and their pinned / device staging buffers) live as long as the side streams: the next round reuses them
     have = _SLOTS.setdefault(dev.index, [])
     while len(have) < depth:

@@ -2995,6 +2995,70 @@ def test_region_selection_two_table_widths_through_one_slot_shape(dev):
             os.remove(os.path.join(tmp, f"m{i}.png")); os.remove(os.path.join(tmp, f"i{i}.pth"))
 
 
+def test_region_selection_survives_a_failed_recording_of_its_launch_group(dev, monkeypatch):
+    """A HIP-graph recording that fails must cost nothing but the replay: the launch group is recorded on a stream of its own
+    (build._capture_stream), so the slot's stream -- where this batch's eager run, its copies and its event live -- never enters
+    capture mode.  (Round 6: one recording in ~1700 was invalidated by the runtime under GPU_MAX_HW_QUEUES=8; it had been made on
+    the slot's own stream, which ROCm 7.2 then left in capture mode for good, and the round died in a writer thread's event wait.)
+    Here the second batch's recording is broken on purpose -- a device synchronisation inside the capture -- and the five images
+    still give the oracle's files, eagerly; afterwards another launch group of the same process records and replays normally."""
+    from PIL import Image
+    from halo_amd.core.active import build
+    from oracle import halo_oracle as ho
+    rng = np.random.default_rng(4242)
+    tmp = tempfile.mkdtemp(prefix="halo_rs_badcapture_")
+    H, W, n = 40, 88, 5
+
+    def cfg_for(budget):
+        return types.SimpleNamespace(
+            MODEL=types.SimpleNamespace(NUM_CLASSES=19, HYPER=True, CURVATURE=1.0),
+            ACTIVE=types.SimpleNamespace(UNCERTAINTY="entropy", PURITY="radius", NORMALIZE=True, RADIUS_K=1, MASK_RADIUS_K=5,
+                                         BUDGET=budget, SELECT_ITER=[0, 1, 2, 3, 4], K=100, VIZ_MASK=False))
+    items, outs, oin = [], [], []
+    for i in range(n):
+        emb_lr = ho.expmap((rng.standard_normal((1, 8, H // 4, W // 4)) * 0.2).astype(np.float32), 1.0, dim=1)
+        logit_lr = rng.standard_normal((1, 19, H // 2, W // 2)).astype(np.float32)
+        gt = rng.integers(0, 19, (H, W)).astype(np.int64)
+        act = rng.random((H, W)) < 0.02
+        items.append({"img": torch.zeros(1, 3, 8, 8), "path_to_mask": [os.path.join(tmp, f"m{i}.png")],
+                      "origin_mask": torch.full((1, H, W), 255, dtype=torch.int64), "origin_label": torch.from_numpy(gt)[None],
+                      "size": torch.tensor([[H, W]]), "active": torch.from_numpy(act)[None], "selected": torch.zeros(1, H, W, dtype=torch.bool),
+                      "path_to_indicator": [os.path.join(tmp, f"i{i}.pth")], "name": [f"c{i}"]})
+        outs.append((t(logit_lr, dev), t(emb_lr, dev)))
+        oin.append(dict(logit_lr=logit_lr, embed_lr=emb_lr, origin_label=gt, active=act, selected=np.zeros((H, W), bool),
+                        origin_mask=np.full((H, W), 255, np.int64)))
+
+    def check(budget):
+        for i, (mask, act, sel, _) in enumerate(ho.region_selection(cfg_for(budget), oin, lowres_mode=_lr_mode())):
+            assert np.array_equal(np.array(Image.open(os.path.join(tmp, f"m{i}.png")), dtype=np.uint8), mask), (budget, i)
+            ind = torch.load(os.path.join(tmp, f"i{i}.pth"))
+            assert np.array_equal(ind["active"].numpy(), act) and np.array_equal(ind["selected"].numpy(), sel), (budget, i)
+            os.remove(os.path.join(tmp, f"m{i}.png")); os.remove(os.path.join(tmp, f"i{i}.pth"))
+
+    real = build.acquire_batch_lowres
+    broke = []
+
+    def breaks_a_capture(*a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            broke.append(1)
+            torch.cuda.synchronize()                     # not permitted inside a capture: invalidates it and raises
+        return real(*a, **k)
+    monkeypatch.setattr(build, "acquire_batch_lowres", breaks_a_capture)
+    with pytest.warns(RuntimeWarning, match="graph capture of the launch group failed"):
+        build.RegionSelection(cfg_for(0.05), _Fake(), _Fake(outs), items, 1, in_flight=1, writer_threads=2)
+    assert broke == [1]                                  # one recording was attempted, none after it failed
+    check(0.05)
+    build.RegionSelection(cfg_for(0.05), _Fake(), _Fake(outs), items, 1, in_flight=1, writer_threads=2)    # the same group again: eager
+    assert broke == [1]
+    check(0.05)
+    monkeypatch.setattr(build, "acquire_batch_lowres", real)
+    mine = lambda: [g for sl in build._SLOTS.values() for s_ in sl for k_, g in s_.graphs.items() if k_[:3] == (1, H, W)]
+    assert not any(isinstance(g, build._SlotGraph) for g in mine())
+    build.RegionSelection(cfg_for(0.15), _Fake(), _Fake(outs), items, 1, in_flight=1, writer_threads=2)    # another group: eager, record, replay x 3
+    assert sum(isinstance(g, build._SlotGraph) for g in mine()) == 1
+    check(0.15)
+
+
 def test_more_handed_over_images_than_resume_workgroups(dev):
     """The serial kernel behind the sweep runs one workgroup per image up to 64; 70 maps that ALL hand over (NaN, constant maps) make its workgroups walk more than one image each."""
     from halo_amd.core.active.build import greedy_select

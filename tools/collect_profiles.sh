@@ -78,6 +78,8 @@ METHODS=auto,serial run select_timing.txt python3 $R/tools/time_select.py
 METHODS=auto RANGED=1 run select_timing_ranged.txt python3 $R/tools/time_select.py
 run region_selection_timing.txt python3 $R/tools/time_region_selection.py
 HALO_RS_GRAPH=0 run region_selection_timing_eager_launches.txt python3 $R/tools/time_region_selection.py
+HALO_RS_HW_QUEUES=2 run region_selection_timing_two_queues.txt python3 $R/tools/time_region_selection.py
+(cd $R && run hw_queues.txt bash $R/tools/hw_queues_ab.sh)
 run head_timing.txt python3 $R/tools/time_head.py
 run secondary_kernels.txt python3 $R/tools/time_secondary.py
 run branches.txt python3 $R/tools/time_branches.py

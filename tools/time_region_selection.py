@@ -4,7 +4,12 @@ stand-in that only sleeps on the GPU for a configurable time, so the number isol
 import os, shutil, sys, tempfile, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
+import halo_amd
+# hardware queues: ROCm's default (4) unless HALO_RS_HW_QUEUES says otherwise -- what a training process gets without asking, and
+# what this driver measures fastest on since round 6 (two queues: two single-workgroup sweeps in flight, 0.58 ms/image; four or
+# eight: the writers' floor, 0.47-0.51: profiles/r06_hw_queues.txt; bench.py's 16-image steps still prefer two)
+if os.environ.get("HALO_RS_HW_QUEUES"):
+    halo_amd.configure(hw_queues=int(os.environ["HALO_RS_HW_QUEUES"]))
 from halo_amd.core.active.build import RegionSelection
 from halo_amd.core.utils.hyperbolic import HyperMapper
 
@@ -92,6 +97,8 @@ for MODE, busy in (() if os.environ.get("HALO_RS_FLOOR_ONLY") else (("none", 0.0
         tmp = tempfile.mkdtemp(prefix="halo_rs_t_")
         items = batched(pool(tmp), nb) if nb > 1 else pool(tmp)
         kw = {} if infl is None else {"in_flight": infl}
+        if os.environ.get("HALO_RS_STREAMS"):
+            kw["streams"] = int(os.environ["HALO_RS_STREAMS"])
         RegionSelection(cfg, Ident(), Head(busy), items[:8], 1, writer_threads=wr, mask_staging=STAGING, **kw)
         torch.cuda.synchronize()
         # without a backbone a round over the pool takes ~0.1 s and its 0.4 GB of files land in the page cache: the number is

@@ -2,7 +2,7 @@
 import os, sys, tempfile, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import halo_amd; halo_amd.configure(hw_queues=2)      # before the first HIP call: the acquisition's measured optimum
+import halo_amd      # hardware queues: ROCm's default (tools/time_region_selection.py says why)
 from halo_amd.core.active import build as B
 from halo_amd.core.utils.hyperbolic import HyperMapper
 
