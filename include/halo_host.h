@@ -60,7 +60,9 @@ int halo_compose_indicators(uint8_t *active, uint8_t *selected, const uint8_t *p
 
 /* ---- both files of one image in one call: halo_compose_mask -> halo_png_gray8_encode -> write, then halo_write_indicator
  * (skipped when tpl is NULL).  compose_mask_radius < 0: `active` / `selected` are the round's RESULTS (copied back from the device);
- * >= 0: they are the maps the image entered the round with and halo_compose_indicators (that mask radius) runs first. */
+ * >= 0: they are the maps the image entered the round with and halo_compose_indicators (that mask radius) runs first.
+ * Files (here, halo_png_gray8_write, halo_write_indicator): the bytes open(path, "wb") + write would leave, but an existing file is
+ * rewritten IN PLACE and cut to length afterwards -- a round rewrites the files of the round before, and their page-cache pages stay. */
 int halo_retire_image(const char *path_png, const char *path_indicator, const void *origin_mask, int mask_itemsize,
                       const void *origin_label, int label_itemsize, int64_t H, int64_t W, const double *picks, int64_t k, int64_t radius,
                       const uint8_t *active, const uint8_t *selected, int64_t compose_mask_radius, const uint8_t *tpl, size_t tpl_len,

@@ -145,6 +145,9 @@ def writers_alone(n_threads):
     runs = []
     for _ in range(REPEATS + 1):
         nxt[0] = 0
+        if os.environ.get("HALO_RS_FRESH"):          # every round into NEW files (the default: rewritten in place, as the rounds of a run do)
+            for f in os.listdir(tmp):
+                os.remove(os.path.join(tmp, f))
         th = [threading.Thread(target=work) for _ in range(n_threads)]
         t0 = time.perf_counter()
         [x.start() for x in th]; [x.join() for x in th]
