@@ -89,6 +89,7 @@ run training_ops.txt python3 $R/tools/time_training_ops.py
 run mlr_backward.txt python3 $R/tools/time_mlr_bwd.py
 HALO_RS_FLOOR_ONLY=1 HALO_RS_TMP=/dev/shm run region_selection_host_floor_tmpfs.txt python3 $R/tools/time_region_selection.py
 HALO_RS_FLOOR_ONLY=1 HALO_RS_NO_INDICATOR=1 run region_selection_host_floor_mask_only.txt python3 $R/tools/time_region_selection.py
+HALO_RS_FLOOR_ONLY=1 HALO_RS_FRESH=1 run region_selection_host_floor_fresh_files.txt python3 $R/tools/time_region_selection.py
 run fuzz_head.txt python3 $R/tests/fuzz_head.py 1500 11
 prof trace_head_bwd --kernel-trace --stats --output-format csv -d $OUT/trace_head_bwd -- python3 $R/tools/prof_head_bwd.py
 prof trace_feat_alone --kernel-trace --stats --output-format csv -d $OUT/trace_feat_alone -- python3 $R/tools/time_feat.py
