@@ -64,6 +64,8 @@ for rep in 1 2 3 4; do
   $B --cpu-images 0 --settle 0 2> /dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('run $rep: %.1f images/s  ms_per_step %.3f  k_feat_reduce %.3f ms (frac %.4f)  rest of the step %.3f ms  flat read of the same tensors %.0f GB/s' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], d['ms_per_step'] - r['avg_launch_ms'], r['flat_read']['GB/s']))" >> $OUT/bench_repeats.txt
 done
+# (built in the container, travels with the snapshot: hipcc --offload-arch=gfx950 -O3 tools/micro/coissue.hip -o tools/micro/coissue)
+[ -x $R/tools/micro/coissue ] || hipcc --offload-arch=gfx950 -O3 $R/tools/micro/coissue.hip -o $R/tools/micro/coissue
 run coissue.txt $R/tools/micro/coissue
 # ---- A/B tools (each ASSERTS that its variants agree bit for bit)
 run ab_feat_map.txt python3 $R/tools/ab_feat_map.py
