@@ -118,6 +118,14 @@ def _preload_torch_hip_runtime():
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
+def hip_runtime():
+    """ctypes handle of the HIP runtime torch itself runs on (its bundled libamdhip64.so where the wheel has one): for the few
+    plain runtime calls the host code makes directly (a stream outside torch's pool, core/active/build.py:_capture_stream)."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    return C.CDLL(cand if os.path.exists(cand) else "libamdhip64.so", mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load (building first if the in-tree .so is missing or stale) and type the library."""
     global _handle

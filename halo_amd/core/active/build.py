@@ -249,7 +249,7 @@ def _capture_stream(dev):
     s = _CAPTURE.get(dev.index)
     if s is None:
         import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")                       # the runtime torch already loaded
+        hip = _lib.hip_runtime()                                  # the runtime torch runs on, not a second copy
         raw = ctypes.c_void_p()
         with torch.cuda.device(dev):
             err = hip.hipStreamCreateWithFlags(ctypes.byref(raw), ctypes.c_uint(1))     # hipStreamNonBlocking
