@@ -92,7 +92,9 @@ run mlr_backward.txt python3 $R/tools/time_mlr_bwd.py
 HALO_RS_FLOOR_ONLY=1 HALO_RS_TMP=/dev/shm run region_selection_host_floor_tmpfs.txt python3 $R/tools/time_region_selection.py
 HALO_RS_FLOOR_ONLY=1 HALO_RS_NO_INDICATOR=1 run region_selection_host_floor_mask_only.txt python3 $R/tools/time_region_selection.py
 HALO_RS_FLOOR_ONLY=1 HALO_RS_FRESH=1 run region_selection_host_floor_fresh_files.txt python3 $R/tools/time_region_selection.py
-run fuzz_head.txt python3 $R/tests/fuzz_head.py 1500 11
+run fuzz_head.txt python3 $R/tests/fuzz_head.py 3000 21
+run fuzz_parity.txt python3 $R/tests/fuzz_parity.py 3000 801
+run fuzz_select.txt python3 $R/tests/fuzz_select.py 1500 41
 prof trace_head_bwd --kernel-trace --stats --output-format csv -d $OUT/trace_head_bwd -- python3 $R/tools/prof_head_bwd.py
 prof trace_feat_alone --kernel-trace --stats --output-format csv -d $OUT/trace_feat_alone -- python3 $R/tools/time_feat.py
 prof trace_head --kernel-trace --stats --output-format csv -d $OUT/trace_head -- python3 $R/tools/time_head.py

@@ -144,7 +144,7 @@ def main():
               "select16_breakdown.txt", "bench_repeats.txt", "ab_feat_map.txt", "region_selection_timing_device_staging.txt",
               "region_selection_timing_python_writer.txt", "host_pieces.txt", "hw_queues.txt", "gram_ab.txt", "op_rate.txt",
               "lowres_overlap_probe.txt", "head_timing.txt", "region_selection_timing_eager_launches.txt", "region_selection_timing_two_queues.txt", "ab_mlr_epilogue.txt", "mlr_backward.txt",
-              "region_selection_host_floor_tmpfs.txt", "region_selection_host_floor_mask_only.txt", "region_selection_host_floor_fresh_files.txt", "fuzz_head.txt", "coissue.txt", "pmc_summary.txt", "ab_logf_table.txt", "FAILED"):
+              "region_selection_host_floor_tmpfs.txt", "region_selection_host_floor_mask_only.txt", "region_selection_host_floor_fresh_files.txt", "fuzz_head.txt", "fuzz_parity.txt", "fuzz_select.txt", "coissue.txt", "pmc_summary.txt", "ab_logf_table.txt", "FAILED"):
         p = os.path.join(SRC, t)
         if os.path.exists(p):
             keep = [ln for ln in open(p) if "amdgpu.ids" not in ln]
