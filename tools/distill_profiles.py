@@ -1,5 +1,6 @@
 """Turn gpurun_out/<round>/ (tools/collect_profiles.sh on an MI355X box) into the tracked summaries under profiles/.
     python tools/distill_profiles.py [r03]"""
+import re
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,7 +84,7 @@ def pmc_summary(dst):
     kern = B * H * W * (C * 8 + 8 + O * 4 + 4)          # what the kernel itself moves (radius + entropy maps written)
     alg = B * H * W * (C * 8 + O * 4 + 8)               # features + logits read, one float64 score written
     hbm = int(2 * f_kb * 1024 + w_kb * 1024)
-    rec = {"round": int(RND[1:]), "kernel": short(feat), "batch": B, "dtype": "f64", "shape_HWCO": [H, W, C, O],
+    rec = {"round": int(re.match(r'r(\d+)', RND).group(1)), "kernel": short(feat), "batch": B, "dtype": "f64", "shape_HWCO": [H, W, C, O],
            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
                       "--cpu-images 0 --ring 16 (two separate passes)",
            "FETCH_SIZE_KB_avg_per_launch": f_kb, "WRITE_SIZE_KB_min_per_launch": w_kb,
@@ -136,7 +137,7 @@ def main():
                     # (float32 kernels: two waves overlap, the ratio tops out at 2)
                     rec["valu_active_cycles_per_SIMD_cycle"] = rec["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * gui)
             per[short(k)] = rec
-        json.dump({"round": int(RND[1:]), "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_lowres.py (three passes: SQ activity, "
+        json.dump({"round": int(re.match(r'r(\d+)', RND).group(1)), "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_lowres.py (three passes: SQ activity, "
                                                       "GRBM_GUI_ACTIVE for the clock, instruction counts)",
                    "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all waves; GRBM_GUI_ACTIVE / 8 = shader cycles",
                    "per_kernel_avg_per_launch": per}, open(os.path.join(DST, RND + "_pmc_lowres.json"), "w"), indent=1)
@@ -163,7 +164,7 @@ def main():
             dur_clk = durations("pmc_mlr_clk/*/*kernel_trace.csv", "hypermlr")
             cycles = gui[0] / 8 if gui else None          # summed over the 8 XCDs
             util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cycles if cycles else None
-            json.dump({"round": int(RND[1:]), "kernel": short(k), "shape": "x (1,256,1024,2048) f64, 19 classes, float32 logits",
+            json.dump({"round": int(re.match(r'r(\d+)', RND).group(1)), "kernel": short(k), "shape": "x (1,256,1024,2048) f64, 19 classes, float32 logits",
                        "command": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 tools/prof_mlr.py ; second pass --pmc GRBM_GUI_ACTIVE",
                        "counters_avg_per_launch": c, "duration_ms": dur, "duration_ms_clock_pass": dur_clk,
                        "shader_cycles_per_launch": cycles, "effective_clock_GHz": (cycles / (sum(dur_clk) / len(dur_clk) * 1e-3) / 1e9) if cycles and dur_clk else None,
