@@ -242,8 +242,8 @@ _CAPTURE = {}
 def _capture_stream(dev):
     """The stream a slot's launch group is RECORDED on: one HIP stream per device, created outside torch's stream pool and
     used for nothing else.  A recording that fails (the runtime invalidates a capture for reasons outside this code: seen once
-    in ~1700 captures under GPU_MAX_HW_QUEUES=8) leaves its stream in capture mode for good on ROCm 7.2 -- hipStreamEndCapture
-    returns the error without ending anything -- so it must not be the slot's own stream (every later copy, launch and event on
+    in ~1700 captures under GPU_MAX_HW_QUEUES=8) leaves its stream in capture mode on ROCm 7.2 / torch 2.10 (observed: after torch's
+    capture_end raised, the stream still refused copies and 'recorded' events into the dead capture) -- so it must not be the slot's own stream (every later copy, launch and event on
     it failed: the round died in a writer thread's event wait) nor one of torch's 32 pooled streams (handed out again later).
     The graph replays on the slot's stream whatever stream recorded it."""
     s = _CAPTURE.get(dev.index)
